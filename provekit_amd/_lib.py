@@ -1,0 +1,77 @@
+"""ctypes binding of libprovekit_hip.so (the C ABI declared in include/provekit_hip.h).
+
+The HIP library is the product: there is no CPU fallback.  Importing this module
+without the built library raises, and creating a Context without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libprovekit_hip.so")
+
+PK_OK = 0
+PK_LEAF_MAJOR = 0
+PK_COL_MAJOR = 1
+
+_ERR_NAMES = {-1: "PK_ERR_BAD_ARG", -2: "PK_ERR_OOM", -3: "PK_ERR_HIP", -4: "PK_ERR_RCCL", -5: "PK_ERR_NO_DEVICE"}
+
+
+class ProveKitHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{_ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C provekit_amd/csrc`). provekit_amd has no CPU fallback."
+        )
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+sz = C.c_size_t
+
+# name -> (restype, argtypes); kept in the same order as include/provekit_hip.h
+SIGNATURES = {
+    "pk_abi_version": (C.c_int, []),
+    "pk_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pk_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "pk_ctx_destroy": (C.c_int, [vp]),
+    "pk_last_error": (C.c_char_p, [vp]),
+    "pk_ctx_set_stream": (C.c_int, [vp, vp]),
+    "pk_ctx_sync": (C.c_int, [vp]),
+    "pk_ctx_set_hash_version": (C.c_int, [vp, C.c_int]),
+    "pk_malloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
+    "pk_free": (C.c_int, [vp, vp]),
+    "pk_memcpy_h2d": (C.c_int, [vp, vp, vp, sz]),
+    "pk_memcpy_d2h": (C.c_int, [vp, vp, vp, sz]),
+    "pk_memcpy_d2d": (C.c_int, [vp, vp, vp, sz]),
+    "pk_memset_zero": (C.c_int, [vp, vp, sz]),
+    "pk_timer_start": (C.c_int, [vp]),
+    "pk_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "pk_fe_add": (C.c_int, [vp, vp, vp, vp, sz]),
+    "pk_fe_sub": (C.c_int, [vp, vp, vp, vp, sz]),
+    "pk_fe_mul": (C.c_int, [vp, vp, vp, vp, sz]),
+    "pk_fe_to_mont": (C.c_int, [vp, vp, vp, sz]),
+    "pk_fe_from_mont": (C.c_int, [vp, vp, vp, sz]),
+    "pk_compress_many": (C.c_int, [vp, vp, vp, sz]),
+    "pk_compress_many_host": (C.c_int, [vp, vp, sz, vp, sz]),
+    "pk_leaf_hash": (C.c_int, [vp, vp, sz, sz, C.c_int, vp]),
+    "pk_merkle_inner": (C.c_int, [vp, vp, sz]),
+    "pk_merkle_commit": (C.c_int, [vp, vp, sz, sz, C.c_int, vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here == header/library mismatch: fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args

@@ -1,0 +1,190 @@
+// ctx.hip -- context, memory and timing entry points of the C ABI, plus the
+// elementwise field kernels (rows A1/A2).
+#include "ctx.hpp"
+#include "fe.hpp"
+
+using namespace pk;
+
+extern "C" {
+
+int pk_abi_version(void) { return 1; }
+
+int pk_device_count(int* n) {
+    if (!n) return PK_ERR_BAD_ARG;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *n = 0;
+        return PK_ERR_NO_DEVICE;
+    }
+    *n = c;
+    return PK_OK;
+}
+
+int pk_ctx_create(int device, pk_ctx** out) {
+    if (!out) return PK_ERR_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PK_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return PK_ERR_BAD_ARG;
+    pk_ctx* ctx = new (std::nothrow) pk_ctx();
+    if (!ctx) return PK_ERR_OOM;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        delete ctx;
+        return PK_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+        ctx->num_cus = prop.multiProcessorCount;
+    *out = ctx;
+    return PK_OK;
+}
+
+int pk_ctx_destroy(pk_ctx* ctx) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->d_scratch) hipFree(ctx->d_scratch);
+    if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return PK_OK;
+}
+
+const char* pk_last_error(const pk_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int pk_ctx_set_stream(pk_ctx* ctx, void* hip_stream) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return PK_OK;
+}
+
+int pk_ctx_sync(pk_ctx* ctx) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PK_OK;
+}
+
+int pk_ctx_set_hash_version(pk_ctx* ctx, int version) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, version == 1 || version == 2, "hash version must be 1 or 2");
+    ctx->hash_version = version;
+    return PK_OK;
+}
+
+int pk_malloc(pk_ctx* ctx, size_t bytes, void** d_ptr) {
+    if (!ctx || !d_ptr) return PK_ERR_BAD_ARG;
+    *d_ptr = nullptr;
+    PK_HIP(ctx, hipSetDevice(ctx->device));
+    PK_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 1));
+    return PK_OK;
+}
+int pk_free(pk_ctx* ctx, void* d_ptr) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    if (!d_ptr) return PK_OK;
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PK_HIP(ctx, hipFree(d_ptr));
+    return PK_OK;
+}
+int pk_memcpy_h2d(pk_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, bytes == 0 || (d_dst && src), "null pointer");
+    if (!bytes) return PK_OK;
+    PK_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PK_OK;
+}
+int pk_memcpy_d2h(pk_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, bytes == 0 || (dst && d_src), "null pointer");
+    if (!bytes) return PK_OK;
+    PK_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PK_OK;
+}
+int pk_memcpy_d2d(pk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, bytes == 0 || (d_dst && d_src), "null pointer");
+    if (!bytes) return PK_OK;
+    PK_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return PK_OK;
+}
+int pk_memset_zero(pk_ctx* ctx, void* d_dst, size_t bytes) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, bytes == 0 || d_dst, "null pointer");
+    if (!bytes) return PK_OK;
+    PK_HIP(ctx, hipMemsetAsync(d_dst, 0, bytes, ctx->stream));
+    return PK_OK;
+}
+int pk_timer_start(pk_ctx* ctx) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    return PK_OK;
+}
+int pk_timer_stop(pk_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return PK_ERR_BAD_ARG;
+    PK_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    PK_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
+    PK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    return PK_OK;
+}
+
+}  // extern "C"
+
+namespace pk {
+int ensure_scratch(pk_ctx* ctx, size_t bytes) {
+    if (ctx->scratch_bytes >= bytes) return PK_OK;
+    if (ctx->d_scratch) {
+        PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PK_HIP(ctx, hipFree(ctx->d_scratch));
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    size_t sz = bytes < (1u << 20) ? (1u << 20) : bytes;
+    PK_HIP(ctx, hipMalloc(&ctx->d_scratch, sz));
+    ctx->scratch_bytes = sz;
+    return PK_OK;
+}
+}  // namespace pk
+
+// ------------------------------------------------------------------ elementwise field kernels
+enum { OP_ADD, OP_SUB, OP_MUL, OP_TO_MONT, OP_FROM_MONT };
+
+template <int OP>
+__global__ __launch_bounds__(256) void fe_elementwise_kernel(const fe* __restrict__ a, const fe* __restrict__ b,
+                                                             fe* __restrict__ out, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        fe x = fe_load(a + i);
+        fe r;
+        if (OP == OP_ADD) r = fe_add(x, fe_load(b + i));
+        if (OP == OP_SUB) r = fe_sub(x, fe_load(b + i));
+        if (OP == OP_MUL) r = fe_mul(x, fe_load(b + i));
+        if (OP == OP_TO_MONT) r = fe_to_mont(fe_reduce_any(x));
+        if (OP == OP_FROM_MONT) r = fe_from_mont(x);
+        fe_store(out + i, r);
+    }
+}
+
+template <int OP>
+static int launch_elementwise(pk_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, n == 0 || (a && out && (b || OP >= OP_TO_MONT)), "null pointer");
+    if (!n) return PK_OK;
+    fe_elementwise_kernel<OP><<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((const fe*)a, (const fe*)b, (fe*)out, n);
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+extern "C" {
+int pk_fe_add(pk_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return launch_elementwise<OP_ADD>(ctx, a, b, o, n); }
+int pk_fe_sub(pk_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return launch_elementwise<OP_SUB>(ctx, a, b, o, n); }
+int pk_fe_mul(pk_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* o, size_t n) { return launch_elementwise<OP_MUL>(ctx, a, b, o, n); }
+int pk_fe_to_mont(pk_ctx* ctx, const uint64_t* a, uint64_t* o, size_t n) { return launch_elementwise<OP_TO_MONT>(ctx, a, nullptr, o, n); }
+int pk_fe_from_mont(pk_ctx* ctx, const uint64_t* a, uint64_t* o, size_t n) { return launch_elementwise<OP_FROM_MONT>(ctx, a, nullptr, o, n); }
+}

@@ -1,0 +1,75 @@
+// ctx.hpp -- library context shared by all translation units of libprovekit_hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/provekit_hip.h"
+
+struct pk_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // the stream work is enqueued on (own or borrowed)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    int hash_version = 2;
+    int num_cus = 256;
+    char err[512] = {0};
+    // small device scratch for reductions (partials + results)
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void* h_pinned = nullptr;  // pinned host staging for small results
+    size_t pinned_bytes = 0;
+};
+
+namespace pk {
+
+inline int set_err(pk_ctx* ctx, int code, const char* fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define PK_HIP(ctx, expr)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return pk::set_err(ctx, _e == hipErrorOutOfMemory ? PK_ERR_OOM : PK_ERR_HIP,           \
+                               "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                               __LINE__);                                                          \
+    } while (0)
+
+#define PK_REQUIRE(ctx, cond, msg)                                                \
+    do {                                                                          \
+        if (!(cond)) return pk::set_err(ctx, PK_ERR_BAD_ARG, "bad argument: %s", msg); \
+    } while (0)
+
+#define PK_LAUNCH_CHECK(ctx) PK_HIP(ctx, hipGetLastError())
+
+inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+inline unsigned ilog2(size_t x) {
+    unsigned l = 0;
+    while (x > 1) {
+        x >>= 1;
+        l++;
+    }
+    return l;
+}
+
+// grid size for a flat elementwise / grid-stride launch
+inline unsigned grid_for(const pk_ctx* ctx, size_t n, unsigned block, unsigned max_blocks_per_cu = 8) {
+    size_t need = (n + block - 1) / block;
+    size_t cap = (size_t)ctx->num_cus * max_blocks_per_cu;
+    if (need < 1) need = 1;
+    return (unsigned)(need < cap ? need : cap);
+}
+
+int ensure_scratch(pk_ctx* ctx, size_t bytes);
+
+}  // namespace pk

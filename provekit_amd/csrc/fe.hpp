@@ -1,0 +1,230 @@
+// fe.hpp -- BN254-Fr arithmetic for gfx950 device code.
+//
+// Replaces, on the GPU, the two multipliers the reference uses on the CPU:
+//   * ark-ff Fp256<MontBackend<.., 4>> (+,-,*)            -- SURVEY 8a row A2
+//   * block_multiplier::scalar_{mul,sqr}                   -- row A1
+//       (skyscraper/block-multiplier/src/scalar.rs:12-132)
+// Both compute a*b*2^-256 mod p; here it is one routine on 8 x 32-bit limbs so
+// that every partial product is a single v_mad_u64_u32 (32x32+64 -> 64).
+//
+// In-memory format is the reference's: 4 x u64 little-endian limbs, Montgomery
+// form, 32 B per element (== 8 x u32 little-endian).  Values held in registers
+// are always fully reduced (< p) unless a function says otherwise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pk {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+struct fe {
+    u32 v[8];
+};
+
+// p, little-endian u32 limbs (skyscraper/block-multiplier/src/constants.rs:3-8)
+#define PK_P0 0xf0000001u
+#define PK_P1 0x43e1f593u
+#define PK_P2 0x79b97091u
+#define PK_P3 0x2833e848u
+#define PK_P4 0x8181585du
+#define PK_P5 0xb85045b6u
+#define PK_P6 0xe131a029u
+#define PK_P7 0x30644e72u
+#define PK_NP0 0xefffffffu  // -p^-1 mod 2^32 (low half of U64_NP0, constants.rs:1)
+
+__host__ __device__ __forceinline__ constexpr u32 kPlimb(int i) {
+    constexpr u32 P[8] = {PK_P0, PK_P1, PK_P2, PK_P3, PK_P4, PK_P5, PK_P6, PK_P7};
+    return P[i];
+}
+
+template <int K>
+__device__ __forceinline__ constexpr u32 p_mul_limb(int i) {
+    // limb i of K*p, K in 1..4 (4p < 2^256)
+    constexpr u32 P[8] = {PK_P0, PK_P1, PK_P2, PK_P3, PK_P4, PK_P5, PK_P6, PK_P7};
+    u64 c = 0;
+    u32 out = 0;
+    for (int j = 0; j <= i; j++) {
+        c += (u64)P[j] * K;
+        out = (u32)c;
+        c >>= 32;
+    }
+    return out;
+}
+
+__device__ __forceinline__ fe fe_zero() {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = 0;
+    return r;
+}
+// R mod p = Montgomery one (constants.rs:17-22)
+__device__ __forceinline__ fe fe_one() {
+    fe r;
+    r.v[0] = 0x4ffffffbu; r.v[1] = 0xac96341cu; r.v[2] = 0x9f60cd29u; r.v[3] = 0x36fc7695u;
+    r.v[4] = 0x7879462eu; r.v[5] = 0x666ea36fu; r.v[6] = 0x9a07df2fu; r.v[7] = 0x0e0a77c1u;
+    return r;
+}
+// R^2 mod p (constants.rs:25-30)
+__device__ __forceinline__ fe fe_r2() {
+    fe r;
+    r.v[0] = 0xae216da7u; r.v[1] = 0x1bb8e645u; r.v[2] = 0xe35c59e3u; r.v[3] = 0x53fe3ab1u;
+    r.v[4] = 0x53bb8085u; r.v[5] = 0x8c49833du; r.v[6] = 0x7f4e44a5u; r.v[7] = 0x0216d0b1u;
+    return r;
+}
+
+__device__ __forceinline__ fe fe_load(const void* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    fe r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void fe_store(void* p, const fe& x) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    q[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+
+// r = a - K*p if a >= K*p else a      (a any 256-bit value)
+template <int K>
+__device__ __forceinline__ fe cond_sub_kp(const fe& a) {
+    fe d;
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 t = (u64)a.v[i] - p_mul_limb<K>(i) - borrow;
+        d.v[i] = (u32)t;
+        borrow = (u32)(t >> 32) & 1u;
+    }
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = borrow ? a.v[i] : d.v[i];
+    return r;
+}
+// any 256-bit value -> [0, p)   (2^256 < 6p)
+__device__ __forceinline__ fe fe_reduce_any(const fe& a) {
+    return cond_sub_kp<1>(cond_sub_kp<2>(cond_sub_kp<4>(a)));
+}
+
+__device__ __forceinline__ fe fe_add(const fe& a, const fe& b) {  // a,b < p -> < p
+    fe s;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 t = (u64)a.v[i] + b.v[i] + c;
+        s.v[i] = (u32)t;
+        c = (u32)(t >> 32);
+    }
+    return cond_sub_kp<1>(s);  // a+b < 2p < 2^255: no carry out
+}
+__device__ __forceinline__ fe fe_sub(const fe& a, const fe& b) {  // a,b < p -> < p
+    fe d;
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 t = (u64)a.v[i] - b.v[i] - borrow;
+        d.v[i] = (u32)t;
+        borrow = (u32)(t >> 32) & 1u;
+    }
+    u32 mask = 0u - borrow;
+    u32 c = 0;
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 t = (u64)d.v[i] + (kPlimb(i) & mask) + c;
+        r.v[i] = (u32)t;
+        c = (u32)(t >> 32);
+    }
+    return r;
+}
+__device__ __forceinline__ fe fe_dbl(const fe& a) { return fe_add(a, a); }
+__device__ __forceinline__ fe fe_neg(const fe& a) { return fe_sub(fe_zero(), a); }
+
+__device__ __forceinline__ bool fe_lt(const fe& a, const fe& b) {  // a < b as 256-bit integers
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 t = (u64)a.v[i] - b.v[i] - borrow;
+        borrow = (u32)(t >> 32) & 1u;
+    }
+    return borrow != 0;
+}
+__device__ __forceinline__ bool fe_eq(const fe& a, const fe& b) {
+    u32 d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d |= a.v[i] ^ b.v[i];
+    return d == 0;
+}
+
+// Montgomery product a*b*2^-256 mod p.  Requires a < 2^255, b < 2^255 (e.g. < 2p);
+// returns a value < 2p (LAZY) -- see SURVEY 8a row A1: the reference's scalar_mul
+// has the same contract ("[0,2P)" in, "< 2^256-2p" out).
+// CIOS on 32-bit limbs: 64 + 64 v_mad_u64_u32 and 8 v_mul_lo_u32.
+__device__ __forceinline__ fe mont_mul_lazy(const fe& a, const fe& b) {
+    u32 t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            c += (u64)a.v[j] * b.v[i] + t[j];
+            t[j] = (u32)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[8] = (u32)c;  // < 2^288 overall for a,b < 2^255: no further carry
+        u32 m = t[0] * PK_NP0;
+        c = (u64)m * PK_P0 + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            c += (u64)m * kPlimb(j) + t[j];
+            t[j - 1] = (u32)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[7] = (u32)c;
+        t[8] = (u32)(c >> 32);
+    }
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    return r;
+}
+__device__ __forceinline__ fe fe_mul(const fe& a, const fe& b) { return cond_sub_kp<1>(mont_mul_lazy(a, b)); }
+__device__ __forceinline__ fe fe_sqr(const fe& a) { return cond_sub_kp<1>(mont_mul_lazy(a, a)); }
+
+// Montgomery -> canonical: x*2^-256 mod p (reduction half only; into_bigint())
+__device__ __forceinline__ fe fe_from_mont(const fe& a) {
+    u32 t[9];
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = a.v[i];
+    t[8] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 m = t[0] * PK_NP0;
+        u64 c = (u64)m * PK_P0 + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            c += (u64)m * kPlimb(j) + t[j];
+            t[j - 1] = (u32)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[7] = (u32)c;
+        t[8] = (u32)(c >> 32);
+    }
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = t[i];
+    return cond_sub_kp<1>(r);
+}
+__device__ __forceinline__ fe fe_to_mont(const fe& a) { return fe_mul(a, fe_r2()); }
+
+}  // namespace pk

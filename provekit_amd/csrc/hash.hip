@@ -1,0 +1,174 @@
+// hash.hip -- Skyscraper batch compression and Merkle-tree kernels.
+//
+// One lane = one compression chain.  The work is integer-ALU bound (12 Montgomery
+// squarings per compression, ~1.6k quarter-rate v_mad_u64_u32 per lane), so the
+// kernels are organised for occupancy and coalesced 32-byte-per-lane traffic, not
+// for LDS reuse:
+//   compress_many : lane i reads message i (64 B contiguous), writes hash i (32 B).
+//   leaf_hash     : lane i owns leaf i; in PK_COL_MAJOR (the layout pk_commit keeps
+//                   in HBM) column j of all leaves is contiguous, so every step of
+//                   the 31-deep left fold is one coalesced 2 KiB wave read.
+//   merkle_level  : lane i owns inner node i of one level; children 2i,2i+1 are
+//                   adjacent in the heap, so a wave reads 4 KiB contiguous.
+#include "ctx.hpp"
+#include "skyscraper.hpp"
+
+using namespace pk;
+
+template <int VERSION>
+__global__ __launch_bounds__(256) void compress_many_kernel(const fe* __restrict__ msgs, fe* __restrict__ out, size_t n) {
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        fe l = fe_reduce_any(fe_load(msgs + 2 * i));
+        fe r = fe_reduce_any(fe_load(msgs + 2 * i + 1));
+        fe_store(out + i, compress_v<VERSION>(l, r));
+    }
+}
+
+// SkyscraperCRH::evaluate (provekit/common/src/skyscraper/whir.rs:30-48): h = x0; h = C(h, x_j)
+template <int VERSION, int LAYOUT>
+__global__ __launch_bounds__(256) void leaf_hash_kernel(const fe* __restrict__ leaves, size_t n_leaves, unsigned width,
+                                                        fe* __restrict__ digests) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_leaves) return;
+    size_t step = LAYOUT == PK_COL_MAJOR ? n_leaves : 1;
+    const fe* p = leaves + (LAYOUT == PK_COL_MAJOR ? i : i * (size_t)width);
+    fe h = fe_from_mont(fe_load(p));  // into_bigint(), whir.rs:21
+    fe nxt = width > 1 ? fe_load(p + step) : fe_zero();
+    for (unsigned j = 1; j < width; j++) {
+        fe x = fe_from_mont(nxt);
+        if (j + 1 < width) nxt = fe_load(p + (size_t)(j + 1) * step);  // prefetch next column
+        h = compress_v<VERSION>(h, x);
+    }
+    fe_store(digests + i, h);
+}
+
+// one level of ark MerkleTree::new: nodes[i] = C(nodes[2i], nodes[2i+1]) for i in [first, first+count)
+template <int VERSION>
+__global__ __launch_bounds__(256) void merkle_level_kernel(fe* __restrict__ nodes, size_t first, size_t count) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    size_t i = first + t;
+    fe l = fe_load(nodes + 2 * i), r = fe_load(nodes + 2 * i + 1);
+    fe_store(nodes + i, compress_v<VERSION>(l, r));
+}
+
+// the top of the tree (<= 512 nodes per level) in one workgroup: no launch per level
+template <int VERSION>
+__global__ __launch_bounds__(512) void merkle_top_kernel(fe* __restrict__ nodes, size_t top_leaves) {
+    for (size_t lvl = top_leaves / 2; lvl >= 1; lvl >>= 1) {
+        if (threadIdx.x < lvl) {
+            size_t i = lvl + threadIdx.x;
+            fe l = fe_load(nodes + 2 * i), r = fe_load(nodes + 2 * i + 1);
+            fe_store(nodes + i, compress_v<VERSION>(l, r));
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+static int leaf_hash_launch(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, uint64_t* d_digests) {
+    unsigned block = 256;
+    unsigned grid = (unsigned)((n_leaves + block - 1) / block);
+    const fe* L = (const fe*)d_leaves;
+    fe* D = (fe*)d_digests;
+    unsigned w = (unsigned)width;
+    if (ctx->hash_version == 2) {
+        if (layout == PK_COL_MAJOR)
+            leaf_hash_kernel<2, PK_COL_MAJOR><<<grid, block, 0, ctx->stream>>>(L, n_leaves, w, D);
+        else
+            leaf_hash_kernel<2, PK_LEAF_MAJOR><<<grid, block, 0, ctx->stream>>>(L, n_leaves, w, D);
+    } else {
+        if (layout == PK_COL_MAJOR)
+            leaf_hash_kernel<1, PK_COL_MAJOR><<<grid, block, 0, ctx->stream>>>(L, n_leaves, w, D);
+        else
+            leaf_hash_kernel<1, PK_LEAF_MAJOR><<<grid, block, 0, ctx->stream>>>(L, n_leaves, w, D);
+    }
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+extern "C" {
+
+int pk_compress_many(pk_ctx* ctx, const uint8_t* d_messages, uint8_t* d_hashes, size_t n) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, n == 0 || (d_messages && d_hashes), "null pointer");
+    if (!n) return PK_OK;
+    unsigned grid = grid_for(ctx, n, 256, 16);
+    if (ctx->hash_version == 2)
+        compress_many_kernel<2><<<grid, 256, 0, ctx->stream>>>((const fe*)d_messages, (fe*)d_hashes, n);
+    else
+        compress_many_kernel<1><<<grid, 256, 0, ctx->stream>>>((const fe*)d_messages, (fe*)d_hashes, n);
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+int pk_compress_many_host(pk_ctx* ctx, const uint8_t* messages, size_t messages_len, uint8_t* hashes, size_t hashes_len) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    // generic.rs:18-25: "Message length not a multiple of 64" / "Hashes length not a multiple of 32" / mismatch
+    PK_REQUIRE(ctx, messages_len % 64 == 0, "message length not a multiple of 64");
+    PK_REQUIRE(ctx, hashes_len % 32 == 0, "hashes length not a multiple of 32");
+    PK_REQUIRE(ctx, messages_len == 2 * hashes_len, "messages and hashes length mismatch");
+    size_t n = hashes_len / 32;
+    if (!n) return PK_OK;
+    PK_REQUIRE(ctx, messages && hashes, "null pointer");
+    void *dm = nullptr, *dh = nullptr;
+    int rc = pk_malloc(ctx, messages_len, &dm);
+    if (rc) return rc;
+    rc = pk_malloc(ctx, hashes_len, &dh);
+    if (rc) {
+        pk_free(ctx, dm);
+        return rc;
+    }
+    rc = pk_memcpy_h2d(ctx, dm, messages, messages_len);
+    if (!rc) rc = pk_compress_many(ctx, (const uint8_t*)dm, (uint8_t*)dh, n);
+    if (!rc) rc = pk_memcpy_d2h(ctx, hashes, dh, hashes_len);
+    pk_free(ctx, dm);
+    pk_free(ctx, dh);
+    return rc;
+}
+
+int pk_leaf_hash(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, uint64_t* d_digests) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, width >= 1, "leaf width must be >= 1 (IncorrectInputLength(0))");  // whir.rs:47
+    PK_REQUIRE(ctx, width < (1u << 20), "leaf width too large");
+    PK_REQUIRE(ctx, layout == PK_LEAF_MAJOR || layout == PK_COL_MAJOR, "unknown layout");
+    PK_REQUIRE(ctx, n_leaves == 0 || (d_leaves && d_digests), "null pointer");
+    if (!n_leaves) return PK_OK;
+    return leaf_hash_launch(ctx, d_leaves, n_leaves, width, layout, d_digests);
+}
+
+int pk_merkle_inner(pk_ctx* ctx, uint64_t* d_nodes, size_t n_leaves) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, is_pow2(n_leaves), "n_leaves must be a power of two");  // ark MerkleTree::new asserts this
+    PK_REQUIRE(ctx, d_nodes, "null pointer");
+    fe* N = (fe*)d_nodes;
+    PK_HIP(ctx, hipMemsetAsync(d_nodes, 0, 32, ctx->stream));
+    size_t lvl = n_leaves / 2;
+    for (; lvl > 512; lvl >>= 1) {
+        unsigned grid = (unsigned)((lvl + 255) / 256);
+        if (ctx->hash_version == 2)
+            merkle_level_kernel<2><<<grid, 256, 0, ctx->stream>>>(N, lvl, lvl);
+        else
+            merkle_level_kernel<1><<<grid, 256, 0, ctx->stream>>>(N, lvl, lvl);
+    }
+    if (lvl >= 1) {
+        if (ctx->hash_version == 2)
+            merkle_top_kernel<2><<<1, 512, 0, ctx->stream>>>(N, lvl * 2);
+        else
+            merkle_top_kernel<1><<<1, 512, 0, ctx->stream>>>(N, lvl * 2);
+    }
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+int pk_merkle_commit(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, uint64_t* d_nodes) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, is_pow2(n_leaves), "n_leaves must be a power of two");
+    PK_REQUIRE(ctx, d_nodes, "null pointer");
+    int rc = pk_leaf_hash(ctx, d_leaves, n_leaves, width, layout, d_nodes + 4 * n_leaves);
+    if (rc) return rc;
+    return pk_merkle_inner(ctx, d_nodes, n_leaves);
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+"""Context and device buffers over the C ABI (host-side plumbing only)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import ProveKitHipError, lib
+
+
+class DeviceBuffer:
+    """A hipMalloc'ed buffer owned through pk_malloc/pk_free."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        ctx._check(lib.pk_malloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr is not None and self.ctx.handle is not None:
+            lib.pk_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def at(self, byte_offset: int) -> int:
+        return self.ptr + int(byte_offset)
+
+    def view_fe(self, fe_offset: int) -> int:
+        return self.ptr + 32 * int(fe_offset)
+
+
+class Context:
+    """One device, one stream (pk_ctx).  Not thread-safe, like the C ABI."""
+
+    def __init__(self, device: int = 0):
+        self.handle = None
+        n = C.c_int(0)
+        rc = lib.pk_device_count(C.byref(n))
+        if rc != 0 or n.value <= 0:
+            raise ProveKitHipError(rc or -5, "no HIP device visible; provekit_amd has no CPU fallback")
+        h = C.c_void_p()
+        rc = lib.pk_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise ProveKitHipError(rc, f"pk_ctx_create({device}) failed")
+        self.handle = h.value
+        self.device = device
+
+    def close(self):
+        if self.handle is not None:
+            lib.pk_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = lib.pk_last_error(self.handle)
+            raise ProveKitHipError(rc, msg.decode() if msg else "")
+
+    # -- memory ------------------------------------------------------------
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def alloc_fe(self, n: int) -> DeviceBuffer:
+        return DeviceBuffer(self, 32 * int(n))
+
+    def upload(self, arr: np.ndarray) -> DeviceBuffer:
+        arr = np.ascontiguousarray(arr)
+        buf = DeviceBuffer(self, arr.nbytes)
+        self._check(lib.pk_memcpy_h2d(self.handle, buf.ptr, arr.ctypes.data, arr.nbytes))
+        return buf
+
+    def upload_into(self, dptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._check(lib.pk_memcpy_h2d(self.handle, dptr, arr.ctypes.data, arr.nbytes))
+
+    def download(self, dptr, shape, dtype=np.uint64) -> np.ndarray:
+        if isinstance(dptr, DeviceBuffer):
+            dptr = dptr.ptr
+        out = np.empty(shape, dtype=dtype)
+        self._check(lib.pk_memcpy_d2h(self.handle, out.ctypes.data, dptr, out.nbytes))
+        return out
+
+    def download_fe(self, dptr, n: int) -> np.ndarray:
+        return self.download(dptr, (int(n), 4), np.uint64)
+
+    def zero(self, dptr, nbytes):
+        if isinstance(dptr, DeviceBuffer):
+            dptr = dptr.ptr
+        self._check(lib.pk_memset_zero(self.handle, dptr, nbytes))
+
+    def sync(self):
+        self._check(lib.pk_ctx_sync(self.handle))
+
+    def set_stream(self, hip_stream: int | None):
+        self._check(lib.pk_ctx_set_stream(self.handle, hip_stream))
+
+    def set_hash_version(self, version: int):
+        self._check(lib.pk_ctx_set_hash_version(self.handle, version))
+
+    def timer_start(self):
+        self._check(lib.pk_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self._check(lib.pk_timer_stop(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+
+_default_ctx: Context | None = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx

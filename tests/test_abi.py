@@ -1,0 +1,58 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/provekit_hip.h declares
+(no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "provekit_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_something():
+    syms = declared_symbols()
+    assert "pk_ctx_create" in syms and "pk_compress_many" in syms and len(syms) >= 20
+
+
+def test_library_exports_every_declared_symbol():
+    from provekit_amd import _lib
+
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, f"declared in provekit_hip.h but not exported: {missing}"
+
+
+def test_python_binding_covers_header():
+    from provekit_amd import _lib
+
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_no_gpu_fails_loudly():
+    """Without a device the product path must raise, never fall back to the CPU."""
+    import provekit_amd
+    from provekit_amd import _lib
+
+    n = ctypes.c_int(-1)
+    rc = _lib.lib.pk_device_count(ctypes.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(provekit_amd.ProveKitHipError):
+        provekit_amd.Context(0)
+
+
+def test_product_never_imports_oracle():
+    """provekit_amd/ must not reference oracle/ (parity rule: the oracle is test infrastructure)."""
+    pkg = os.path.join(ROOT, "provekit_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pk_oracle" not in txt and "pyref" not in txt and "oracle_lib" not in txt, f

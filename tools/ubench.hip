@@ -1,0 +1,158 @@
+// ubench.hip -- VALU issue-rate microbenchmark for gfx950.
+// Measures cycles per wave64 instruction per SIMD for the instructions the
+// 256-bit modular multiplier can be built from, so that DESIGN.md can state a
+// measured integer-multiply roofline next to the HBM one.
+// Build: hipcc -O3 --offload-arch=gfx950 tools/ubench.hip -o tools/ubench
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#define CHECK(x)                                                                      \
+    do {                                                                              \
+        hipError_t e = (x);                                                           \
+        if (e != hipSuccess) {                                                        \
+            printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+            exit(1);                                                                  \
+        }                                                                             \
+    } while (0)
+
+constexpr int ITERS = 2048;
+constexpr int UNROLL = 8;  // independent chains per lane
+
+#define BODY8(stmt) stmt(0) stmt(1) stmt(2) stmt(3) stmt(4) stmt(5) stmt(6) stmt(7)
+
+template <int OP>
+__global__ __launch_bounds__(256) void bench(unsigned* out, unsigned seed) {
+    unsigned a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9e3779b9u;
+    unsigned long long acc[UNROLL];
+    double facc[UNROLL];
+    for (int k = 0; k < UNROLL; k++) {
+        acc[k] = (unsigned long long)a * (k + 3) + b;
+        facc[k] = (double)(a & 0xfffff) + k;
+    }
+    double fa = (double)(a & 0xffff) + 1.0, fb = (double)(b & 0xffff) + 3.0;
+    for (int it = 0; it < ITERS; it++) {
+        if (OP == 0) {
+#define S(k) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[k]) : "v"(a), "v"(b) : "vcc");
+            BODY8(S)
+#undef S
+        } else if (OP == 1) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(lo) : "v"(b)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 2) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(lo) : "v"(b)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 3) {
+#define S(k) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(facc[k]) : "v"(fa), "v"(fb));
+            BODY8(S)
+#undef S
+        } else if (OP == 4) {
+#define S(k) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(acc[k]) : "v"(acc[(k + 1) & 7]));
+            BODY8(S)
+#undef S
+        } else if (OP == 5) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_add_co_u32 %0, vcc, %0, %1" : "+v"(lo) : "v"(b) : "vcc"); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 6) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(lo) : "v"(b), "v"(a)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 7) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_add_u32 %0, %0, %1" : "+v"(lo) : "v"(b)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 8) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(lo) : "v"(b) : "vcc"); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 9) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(lo) : "v"(b)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 10) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(lo) : "v"(a), "v"(b)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 11) {
+#define S(k) asm volatile("v_add_f64 %0, %0, %1" : "+v"(facc[k]) : "v"(fa));
+            BODY8(S)
+#undef S
+        } else if (OP == 12) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(lo) : "v"(b) : "vcc"); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 13) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_mov_b32 %0, %1" : "+v"(lo) : "v"(b)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 14) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_dot2_u32_u16 %0, %1, %2, %0" : "+v"(lo) : "v"(a), "v"(b)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 15) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(lo) : "v"(a), "v"(b)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        }
+    }
+    unsigned long long r = 0;
+    for (int k = 0; k < UNROLL; k++) r ^= acc[k] ^ (unsigned long long)__double_as_longlong(facc[k]);
+    if (r == 0x1234567887654321ull) out[0] = (unsigned)r;  // keep results live
+}
+
+template <int OP>
+void run(const char* name, unsigned* d_out, int cus, double ghz) {
+    int waves_per_simd = 4;
+    int blocks = cus * waves_per_simd;  // 256 threads = 4 waves = one per SIMD
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    bench<OP><<<blocks, 256>>>(d_out, 1);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; rep++) {
+        CHECK(hipEventRecord(e0));
+        bench<OP><<<blocks, 256>>>(d_out, rep);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    double wave_instr_per_simd = (double)ITERS * UNROLL * waves_per_simd;
+    double cycles = best * 1e-3 * ghz * 1e9 / wave_instr_per_simd;
+    double lane_ops_per_s = (double)blocks * 256 * ITERS * UNROLL / (best * 1e-3);
+    printf("%-18s %8.3f ms  %6.2f cyc/wave-instr/SIMD (at %.2f GHz)  %8.2f Tlane-op/s\n", name, best, cycles, ghz,
+           lane_ops_per_s * 1e-12);
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    double ghz = prop.clockRate * 1e-6;
+    printf("device %s  CUs %d  clock %.2f GHz\n", prop.name, prop.multiProcessorCount, ghz);
+    unsigned* d_out;
+    CHECK(hipMalloc(&d_out, 64));
+    int cus = prop.multiProcessorCount;
+    run<7>("v_add_u32", d_out, cus, ghz);
+    run<13>("v_mov_b32", d_out, cus, ghz);
+    run<5>("v_add_co_u32", d_out, cus, ghz);
+    run<8>("v_addc_co_u32", d_out, cus, ghz);
+    run<12>("v_cndmask_b32", d_out, cus, ghz);
+    run<4>("v_lshl_add_u64", d_out, cus, ghz);
+    run<0>("v_mad_u64_u32", d_out, cus, ghz);
+    run<1>("v_mul_lo_u32", d_out, cus, ghz);
+    run<2>("v_mul_hi_u32", d_out, cus, ghz);
+    run<6>("v_mad_u32_u24", d_out, cus, ghz);
+    run<9>("v_mul_hi_u32_u24", d_out, cus, ghz);
+    run<15>("v_mad_u32_u16", d_out, cus, ghz);
+    run<10>("v_dot4_u32_u8", d_out, cus, ghz);
+    run<14>("v_dot2_u32_u16", d_out, cus, ghz);
+    run<3>("v_fma_f64", d_out, cus, ghz);
+    run<11>("v_add_f64", d_out, cus, ghz);
+    return 0;
+}
