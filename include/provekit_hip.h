@@ -110,6 +110,20 @@ int pk_merkle_inner(pk_ctx *ctx, uint64_t *d_nodes, size_t n_leaves);
 int pk_merkle_commit(pk_ctx *ctx, const uint64_t *d_leaves, size_t n_leaves, size_t width, int layout,
                      uint64_t *d_nodes);
 
+/* ------------------------------------------------------------------ N1/N2: Reed-Solomon encode (NTT)
+ * Replaces the RS-encode inside whir's CommitmentWriter::commit_batch / round re-commit
+ * (call site provekit/prover/src/whir_r1cs.rs:200-206).  For each of `batch` coefficient
+ * vectors c_b (2^n_vars FEs, univariate order): rows = 2^(n_vars+log_inv_rate-fold),
+ *   leaf_i[b*2^fold + j] = sum_t c_b[2^fold t + j] * w^(i t),  w = generator of the order-rows subgroup
+ * (recursive-verifier/app/circuit/whir_utilities.go:180-186, whir.go:99,141).
+ * d_coeffs: HOST array of `batch` DEVICE pointers.  d_leaves: COLUMN-major matrix
+ * [batch*2^fold][rows].  d_scratch: 2 * batch * 2^fold * rows FEs of device scratch. */
+int pk_rs_encode(pk_ctx *ctx, const uint64_t *const *d_coeffs, unsigned batch, unsigned n_vars,
+                 unsigned log_inv_rate, unsigned fold, uint64_t *d_leaves, uint64_t *d_scratch);
+/* plain NTT of `ncols` contiguous vectors of 2^log_n FEs, natural order in and out:
+ * out[c][k] = sum_i in[c][i] * w_N^(i k)   (helper of pk_rs_encode; exposed for tests/bench) */
+int pk_ntt(pk_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned ncols);
+
 #ifdef __cplusplus
 }
 #endif

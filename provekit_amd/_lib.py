@@ -69,6 +69,8 @@ SIGNATURES = {
     "pk_leaf_hash": (C.c_int, [vp, vp, sz, sz, C.c_int, vp]),
     "pk_merkle_inner": (C.c_int, [vp, vp, sz]),
     "pk_merkle_commit": (C.c_int, [vp, vp, sz, sz, C.c_int, vp]),
+    "pk_rs_encode": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
+    "pk_ntt": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -45,13 +45,14 @@ int pk_ctx_create(int device, pk_ctx** out) {
 
 int pk_ctx_destroy(pk_ctx* ctx) {
     if (!ctx) return PK_ERR_BAD_ARG;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    if (ctx->d_scratch) hipFree(ctx->d_scratch);
-    if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
-    if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
-    if (ctx->ev_stop) hipEventDestroy(ctx->ev_stop);
-    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    pk::ntt_release_ctx(ctx);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return PK_OK;
 }

@@ -71,5 +71,6 @@ inline unsigned grid_for(const pk_ctx* ctx, size_t n, unsigned block, unsigned m
 }
 
 int ensure_scratch(pk_ctx* ctx, size_t bytes);
+void ntt_release_ctx(pk_ctx* ctx);  // ntt.hip: frees the per-context twiddle tables
 
 }  // namespace pk

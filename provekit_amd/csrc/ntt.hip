@@ -1,0 +1,465 @@
+// ntt.hip -- Reed-Solomon low-degree extension over BN254-Fr.
+//
+// What it replaces: the NTT engine of the external `whir` crate as used by
+// CommitmentWriter::commit_batch and the per-round re-commit (call site
+// provekit/prover/src/whir_r1cs.rs:200-206).  Semantics (pinned by the Go verifier,
+// recursive-verifier/app/circuit/whir_utilities.go:180-186 and whir.go:99,141):
+//   coeffs c[0..2^n), fold 2^k, domain D = 2^(n+rho), rows = D / 2^k
+//   leaf_i[j] = sum_t c[2^k t + j] * w^(i t),  w = generator of the order-`rows` subgroup
+// i.e. 2^k independent size-`rows` NTTs of the (zero-padded) stride-2^k sub-sequences.
+//
+// MI355X design.  The codeword matrix lives in HBM COLUMN-major: M[col][row]
+// (col = b*2^k + j).  Then (1) every NTT is a contiguous vector, (2) the leaf hash
+// reads one column per step fully coalesced, (3) nothing is ever transposed back --
+// only the ~100 opened leaves are gathered to leaf-major at the boundary.
+//
+// A size-N transform is 1..3 passes (N = R1*R2*R3, R <= 512).  Each pass is one
+// kernel: a workgroup pulls a [R x 4] tile (4 adjacent 32-byte elements = one 128 B
+// line per row) into LDS, runs log2(R) radix-2 DIF stages there (twiddles w_R^j staged
+// in LDS), and writes the tile back multiplied by the inter-pass twiddle w_N^(k*m) read
+// from a per-size table.  The index maps are Cooley-Tukey so that natural-order input
+// gives natural-order output with no bit-reversal pass over HBM:
+//   n = n1*R2*R3 + n2*R3 + n3,   k = k1 + R1*k2 + R1*R2*k3.
+#include <map>
+#include <vector>
+
+#include "ctx.hpp"
+#include "fe.hpp"
+
+using namespace pk;
+
+namespace {
+
+constexpr int BT = 4;        // batch of adjacent elements per tile row (128 B)
+constexpr int NTHREADS = 256;
+
+// 2^28-th root of unity 5^((p-1)/2^28) (ark-bn254 Fr::TWO_ADIC_ROOT_OF_UNITY), canonical
+// 19103219067921713944291392827692070036145651957329286315305642004821462161904 -> Montgomery
+__device__ __forceinline__ fe root28_mont() {
+    fe r;
+    r.v[0] = 0x725b19f0u; r.v[1] = 0x9bd61b6eu; r.v[2] = 0x41112ed4u; r.v[3] = 0x402d111eu;
+    r.v[4] = 0x8ef62abcu; r.v[5] = 0x00e0a7ebu; r.v[6] = 0xa58a7e85u; r.v[7] = 0x2a3c09f0u;
+    return fe_to_mont(r);
+}
+
+// W[e] = w_N^e for e in [0, N): W[0] = 1, then doubling: W[h + j] = W[j] * w^h
+__global__ void twiddle_init_kernel(fe* W, unsigned log_n) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        fe_store(W, fe_one());
+        fe w = root28_mont();
+        for (unsigned i = log_n; i < 28; i++) w = fe_sqr(w);
+        if (log_n > 0) fe_store(W + 1, w);
+    }
+}
+__global__ __launch_bounds__(256) void twiddle_double_kernel(fe* W, size_t h) {
+    // W[h + j] = W[j] * W[h]  for j in [1, h)   (W[h] itself is written by the caller chain)
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= h) return;
+    fe wh = fe_load(W + h);
+    if (j == 0) return;
+    fe_store(W + h + j, fe_mul(fe_load(W + j), wh));
+}
+__global__ void twiddle_seed_kernel(fe* W, size_t h) {
+    // W[h] = W[h/2]^2
+    if (threadIdx.x == 0 && blockIdx.x == 0) fe_store(W + h, fe_sqr(fe_load(W + h / 2)));
+}
+
+struct PassParams {
+    const fe* in;
+    fe* out;
+    size_t in_col_stride, out_col_stride;  // elements between consecutive columns
+    size_t in_stride_r, in_stride_v, in_stride_u;
+    size_t out_stride_r, out_stride_v, out_stride_u;
+    unsigned log_v;     // extent of the v axis = 2^log_v (tiles take BT of them)
+    size_t nonzero;     // pass 1 only: natural input indices >= nonzero read as zero
+    size_t in_nat_r, in_nat_v, in_nat_u;  // natural-index weights for the zero test
+    const fe* W;        // w_N^e table, N entries
+    size_t n_mask;      // N - 1
+    size_t tw_mul;      // twiddle exponent = tw_mul * k * v  (0 = no twiddle)
+    size_t wr_step;     // w_R^j = W[j * wr_step]
+};
+
+template <int LOG_R, bool IN_R_CONTIG>
+__global__ __launch_bounds__(NTHREADS) void ntt_pass_kernel(PassParams p) {
+    constexpr int R = 1 << LOG_R;
+    constexpr int TILE = R * BT;
+    extern __shared__ uint4 lds[];
+    uint4* lo = lds;                 // TILE entries: low 16 B of each element
+    uint4* hi = lds + TILE;          // TILE entries: high 16 B
+    uint4* wlo = lds + 2 * TILE;     // R/2 twiddles
+    uint4* whi = wlo + (R / 2 > 0 ? R / 2 : 1);
+
+    const unsigned tid = threadIdx.x;
+    const size_t tile = blockIdx.x;
+    const size_t vblocks = ((size_t)1 << p.log_v) / BT;
+    const size_t u = tile / vblocks, vb = tile % vblocks;
+    const size_t v0 = vb * BT;
+    const size_t col = blockIdx.y;
+    const fe* in = p.in + col * p.in_col_stride + u * p.in_stride_u + v0 * p.in_stride_v;
+    fe* out = p.out + col * p.out_col_stride + u * p.out_stride_u + v0 * p.out_stride_v;
+    const size_t nat0 = u * p.in_nat_u + v0 * p.in_nat_v;
+
+    // stage twiddles w_R^j, j < R/2
+    for (int j = tid; j < R / 2; j += NTHREADS) {
+        const uint4* q = reinterpret_cast<const uint4*>(p.W + (size_t)j * p.wr_step);
+        wlo[j] = q[0];
+        whi[j] = q[1];
+    }
+    // load tile: LDS index = r*BT + b
+    for (int e = tid; e < TILE; e += NTHREADS) {
+        int r, b;
+        if (IN_R_CONTIG) {
+            r = e % R;
+            b = e / R;
+        } else {
+            b = e % BT;
+            r = e / BT;
+        }
+        size_t nat = nat0 + (size_t)r * p.in_nat_r + (size_t)b * p.in_nat_v;
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+        if (nat < p.nonzero) {
+            const uint4* q = reinterpret_cast<const uint4*>(in + (size_t)r * p.in_stride_r + (size_t)b * p.in_stride_v);
+            a0 = q[0];
+            a1 = q[1];
+        }
+        lo[r * BT + b] = a0;
+        hi[r * BT + b] = a1;
+    }
+    __syncthreads();
+
+    // radix-2 DIF stages over r (natural in -> bit-reversed out)
+#pragma unroll 1
+    for (int s = 0; s < LOG_R; s++) {
+        const int half = R >> (s + 1);
+        for (int t = tid; t < (R / 2) * BT; t += NTHREADS) {
+            int b = t % BT, j = t / BT;
+            int pos = j & (half - 1);
+            int i0 = ((j - pos) << 1) + pos;
+            int i1 = i0 + half;
+            int a0i = i0 * BT + b, a1i = i1 * BT + b;
+            fe x0, x1;
+            {
+                uint4 l0 = lo[a0i], h0 = hi[a0i], l1 = lo[a1i], h1 = hi[a1i];
+                x0.v[0] = l0.x; x0.v[1] = l0.y; x0.v[2] = l0.z; x0.v[3] = l0.w;
+                x0.v[4] = h0.x; x0.v[5] = h0.y; x0.v[6] = h0.z; x0.v[7] = h0.w;
+                x1.v[0] = l1.x; x1.v[1] = l1.y; x1.v[2] = l1.z; x1.v[3] = l1.w;
+                x1.v[4] = h1.x; x1.v[5] = h1.y; x1.v[6] = h1.z; x1.v[7] = h1.w;
+            }
+            fe sum = fe_add(x0, x1);
+            fe dif = fe_sub(x0, x1);
+            int widx = pos << s;
+            if (widx != 0) {
+                uint4 wl = wlo[widx], wh = whi[widx];
+                fe w;
+                w.v[0] = wl.x; w.v[1] = wl.y; w.v[2] = wl.z; w.v[3] = wl.w;
+                w.v[4] = wh.x; w.v[5] = wh.y; w.v[6] = wh.z; w.v[7] = wh.w;
+                dif = fe_mul(dif, w);
+            }
+            lo[a0i] = make_uint4(sum.v[0], sum.v[1], sum.v[2], sum.v[3]);
+            hi[a0i] = make_uint4(sum.v[4], sum.v[5], sum.v[6], sum.v[7]);
+            lo[a1i] = make_uint4(dif.v[0], dif.v[1], dif.v[2], dif.v[3]);
+            hi[a1i] = make_uint4(dif.v[4], dif.v[5], dif.v[6], dif.v[7]);
+        }
+        __syncthreads();
+    }
+
+    // store: output index k sits at LDS row bitrev(k); multiply by w_N^(tw_mul*k*v)
+    for (int e = tid; e < TILE; e += NTHREADS) {
+        int b = e % BT, k = e / BT;
+        int r = LOG_R == 0 ? 0 : (int)(__brev((unsigned)k) >> (LOG_R ? 32 - LOG_R : 1));
+        uint4 l0 = lo[r * BT + b], h0 = hi[r * BT + b];
+        fe x;
+        x.v[0] = l0.x; x.v[1] = l0.y; x.v[2] = l0.z; x.v[3] = l0.w;
+        x.v[4] = h0.x; x.v[5] = h0.y; x.v[6] = h0.z; x.v[7] = h0.w;
+        if (p.tw_mul != 0) {
+            size_t ex = (p.tw_mul * (size_t)k * (v0 + b)) & p.n_mask;
+            if (ex != 0) x = fe_mul(x, fe_load(p.W + ex));
+        }
+        fe_store(out + (size_t)k * p.out_stride_r + (size_t)b * p.out_stride_v, x);
+    }
+}
+
+// c[2^k t + j] -> S[j][t]  (t < L): stride-2^k gather done through LDS so both sides coalesce
+template <int FW_MAX>
+__global__ __launch_bounds__(256) void deinterleave_kernel(const fe* __restrict__ c, fe* __restrict__ S, size_t L, unsigned fw,
+                                                           size_t col_stride) {
+    // tile: TT consecutive t x fw columns
+    extern __shared__ uint4 tl[];
+    const unsigned TT = 1024 / fw;  // 1024 elements per tile = 32 KiB
+    size_t t0 = (size_t)blockIdx.x * TT;
+    const fe* src = c + t0 * fw;
+    for (unsigned e = threadIdx.x; e < 1024; e += 256) {
+        size_t t = t0 + e / fw;
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+        if (t < L) {
+            const uint4* q = reinterpret_cast<const uint4*>(src + e);
+            a0 = q[0];
+            a1 = q[1];
+        }
+        tl[2 * e] = a0;
+        tl[2 * e + 1] = a1;
+    }
+    __syncthreads();
+    for (unsigned e = threadIdx.x; e < 1024; e += 256) {
+        unsigned j = e / TT, tt = e % TT;
+        size_t t = t0 + tt;
+        if (t < L) {
+            unsigned src_e = tt * fw + j;
+            uint4* q = reinterpret_cast<uint4*>(S + (size_t)j * col_stride + t);
+            q[0] = tl[2 * src_e];
+            q[1] = tl[2 * src_e + 1];
+        }
+    }
+}
+
+struct TwiddleCache {
+    std::map<unsigned, fe*> tables;  // log_n -> device table of 2^log_n entries
+};
+std::map<pk_ctx*, TwiddleCache> g_tw;
+
+int get_twiddles(pk_ctx* ctx, unsigned log_n, const fe** out) {
+    auto& tc = g_tw[ctx];
+    auto it = tc.tables.find(log_n);
+    if (it != tc.tables.end()) {
+        *out = it->second;
+        return PK_OK;
+    }
+    size_t n = (size_t)1 << log_n;
+    fe* W = nullptr;
+    PK_HIP(ctx, hipMalloc((void**)&W, 32 * (n < 2 ? 2 : n)));
+    twiddle_init_kernel<<<1, 64, 0, ctx->stream>>>(W, log_n);
+    for (size_t h = 2; h < n; h <<= 1) {
+        twiddle_seed_kernel<<<1, 64, 0, ctx->stream>>>(W, h);
+        unsigned grid = (unsigned)((h + 255) / 256);
+        twiddle_double_kernel<<<grid, 256, 0, ctx->stream>>>(W, h);
+    }
+    PK_LAUNCH_CHECK(ctx);
+    tc.tables[log_n] = W;
+    *out = W;
+    return PK_OK;
+}
+
+template <int LOG_R>
+int launch_pass_r(pk_ctx* ctx, const PassParams& p, bool in_r_contig, size_t tiles, unsigned ncols) {
+    constexpr int R = 1 << LOG_R;
+    size_t lds_bytes = (size_t)(2 * R * BT + 2 * (R / 2 > 0 ? R / 2 : 1)) * 16;
+    dim3 grid((unsigned)tiles, ncols);
+    if (in_r_contig) {
+        PK_HIP(ctx, hipFuncSetAttribute((const void*)ntt_pass_kernel<LOG_R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        ntt_pass_kernel<LOG_R, true><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(p);
+    } else {
+        PK_HIP(ctx, hipFuncSetAttribute((const void*)ntt_pass_kernel<LOG_R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        ntt_pass_kernel<LOG_R, false><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(p);
+    }
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+int launch_pass(pk_ctx* ctx, unsigned log_r, const PassParams& p, bool in_r_contig, size_t tiles, unsigned ncols) {
+    switch (log_r) {
+        case 0: return launch_pass_r<0>(ctx, p, in_r_contig, tiles, ncols);
+        case 1: return launch_pass_r<1>(ctx, p, in_r_contig, tiles, ncols);
+        case 2: return launch_pass_r<2>(ctx, p, in_r_contig, tiles, ncols);
+        case 3: return launch_pass_r<3>(ctx, p, in_r_contig, tiles, ncols);
+        case 4: return launch_pass_r<4>(ctx, p, in_r_contig, tiles, ncols);
+        case 5: return launch_pass_r<5>(ctx, p, in_r_contig, tiles, ncols);
+        case 6: return launch_pass_r<6>(ctx, p, in_r_contig, tiles, ncols);
+        case 7: return launch_pass_r<7>(ctx, p, in_r_contig, tiles, ncols);
+        case 8: return launch_pass_r<8>(ctx, p, in_r_contig, tiles, ncols);
+        case 9: return launch_pass_r<9>(ctx, p, in_r_contig, tiles, ncols);
+    }
+    return set_err(ctx, PK_ERR_BAD_ARG, "unsupported radix 2^%u", log_r);
+}
+
+}  // namespace
+
+namespace pk {
+
+void ntt_release_ctx(pk_ctx* ctx) {
+    auto it = g_tw.find(ctx);
+    if (it == g_tw.end()) return;
+    for (auto& kv : it->second.tables) (void)hipFree(kv.second);
+    g_tw.erase(it);
+}
+
+// Column-batched NTT, natural -> natural.  `ncols` vectors of length N = 2^log_n:
+// input column c at in + c*in_col_stride holds `nonzero` leading coefficients (rest is zero
+// and is never read); output column c at out + c*out_col_stride.  `scratch` must hold
+// ncols columns of N elements (column stride N) when log_n > 9, and may alias nothing.
+int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero, fe* out, size_t out_col_stride, fe* scratch,
+                unsigned log_n, unsigned ncols) {
+    PK_REQUIRE(ctx, log_n <= 27, "NTT size above 2^27");
+    const size_t N = (size_t)1 << log_n;
+    const fe* W = nullptr;
+    int rc = get_twiddles(ctx, log_n, &W);
+    if (rc) return rc;
+    PassParams p{};
+    p.W = W;
+    p.n_mask = N - 1;
+    if (log_n <= 9) {
+        // single pass: R = N and the tile's batch axis v runs over BT adjacent *columns*
+        p.in = in;
+        p.out = out;
+        p.in_col_stride = 0;
+        p.out_col_stride = 0;
+        p.in_stride_r = 1;
+        p.in_stride_v = in_col_stride;
+        p.in_stride_u = 0;
+        p.out_stride_r = 1;
+        p.out_stride_v = out_col_stride;
+        p.out_stride_u = 0;
+        p.in_nat_r = 1;
+        p.in_nat_v = 0;
+        p.in_nat_u = 0;
+        p.nonzero = nonzero;
+        p.tw_mul = 0;
+        p.wr_step = 1;
+        unsigned full = ncols / BT, rem = ncols % BT;
+        if (full) {
+            PassParams q = p;
+            q.log_v = 62;  // vblocks = 2^62/BT: u = 0 and vb = blockIdx.x = group of BT columns
+            rc = launch_pass(ctx, log_n, q, true, full, 1);
+            if (rc) return rc;
+        }
+        for (unsigned c = ncols - rem; c < ncols; c++) {
+            // remainder columns: a tile whose 4 lanes-of-batch all read column c; only b == 0 is stored
+            // (handled by pointing the v stride at 0 and letting the 4 copies write the same values)
+            PassParams q = p;
+            q.in = in + (size_t)c * in_col_stride;
+            q.out = out + (size_t)c * out_col_stride;
+            q.in_stride_v = 0;
+            q.out_stride_v = 0;
+            q.log_v = 62;
+            rc = launch_pass(ctx, log_n, q, true, 1, 1);
+            if (rc) return rc;
+        }
+        return PK_OK;
+    }
+    PK_REQUIRE(ctx, scratch != nullptr, "scratch required for N > 512");
+    if (log_n <= 18) {
+        unsigned l1 = (log_n + 1) / 2, l2 = log_n - l1;
+        size_t R1 = (size_t)1 << l1, R2 = (size_t)1 << l2;
+        // pass 1: DFT over n1 (stride R2); v = n2; in -> scratch (same layout); twiddle w_N^(k1*n2)
+        p.in = in;
+        p.out = scratch;
+        p.in_col_stride = in_col_stride;
+        p.out_col_stride = N;
+        p.in_stride_r = R2; p.in_stride_v = 1; p.in_stride_u = 0;
+        p.out_stride_r = R2; p.out_stride_v = 1; p.out_stride_u = 0;
+        p.log_v = l2;
+        p.in_nat_r = R2; p.in_nat_v = 1; p.in_nat_u = 0;
+        p.nonzero = nonzero;
+        p.tw_mul = 1;
+        p.wr_step = N >> l1;
+        rc = launch_pass(ctx, l1, p, false, R2 / BT, ncols);
+        if (rc) return rc;
+        // pass 2: DFT over n2 (contiguous); v = k1 (in stride R2, out stride 1); out k2 stride R1
+        p.in = scratch;
+        p.out = out;
+        p.in_col_stride = N;
+        p.out_col_stride = out_col_stride;
+        p.in_stride_r = 1; p.in_stride_v = R2; p.in_stride_u = 0;
+        p.out_stride_r = R1; p.out_stride_v = 1; p.out_stride_u = 0;
+        p.log_v = l1;
+        p.in_nat_r = 0; p.in_nat_v = 0; p.in_nat_u = 0;
+        p.nonzero = 1;  // nat is always 0 < 1: everything is read
+        p.tw_mul = 0;
+        p.wr_step = N >> l2;
+        return launch_pass(ctx, l2, p, true, R1 / BT, ncols);
+    }
+    // three passes
+    unsigned l1 = (log_n + 2) / 3, l2 = (log_n - l1 + 1) / 2, l3 = log_n - l1 - l2;
+    size_t R1 = (size_t)1 << l1, R2 = (size_t)1 << l2, R3 = (size_t)1 << l3;
+    // pass 1: DFT over n1 (stride R2*R3); v = m = n2*R3+n3; twiddle w_N^(k1*m); in -> scratch
+    p.in = in;
+    p.out = scratch;
+    p.in_col_stride = in_col_stride;
+    p.out_col_stride = N;
+    p.in_stride_r = R2 * R3; p.in_stride_v = 1; p.in_stride_u = 0;
+    p.out_stride_r = R2 * R3; p.out_stride_v = 1; p.out_stride_u = 0;
+    p.log_v = l2 + l3;
+    p.in_nat_r = R2 * R3; p.in_nat_v = 1; p.in_nat_u = 0;
+    p.nonzero = nonzero;
+    p.tw_mul = 1;
+    p.wr_step = N >> l1;
+    rc = launch_pass(ctx, l1, p, false, (R2 * R3) / BT, ncols);
+    if (rc) return rc;
+    // pass 2: DFT over n2 (stride R3); v = n3; u = k1 (stride R2*R3); in place; twiddle w_N^(R1*k2*n3)
+    p.in = scratch;
+    p.out = scratch;
+    p.in_col_stride = N;
+    p.out_col_stride = N;
+    p.in_stride_r = R3; p.in_stride_v = 1; p.in_stride_u = R2 * R3;
+    p.out_stride_r = R3; p.out_stride_v = 1; p.out_stride_u = R2 * R3;
+    p.log_v = l3;
+    p.in_nat_r = 0; p.in_nat_v = 0; p.in_nat_u = 0;
+    p.nonzero = 1;
+    p.tw_mul = R1;
+    p.wr_step = N >> l2;
+    rc = launch_pass(ctx, l2, p, false, R1 * (R3 / BT), ncols);
+    if (rc) return rc;
+    // pass 3: DFT over n3 (contiguous); v = k1 (in stride R2*R3, out stride 1); u = k2 (in stride R3, out stride R1)
+    p.in = scratch;
+    p.out = out;
+    p.in_col_stride = N;
+    p.out_col_stride = out_col_stride;
+    p.in_stride_r = 1; p.in_stride_v = R2 * R3; p.in_stride_u = R3;
+    p.out_stride_r = R1 * R2; p.out_stride_v = 1; p.out_stride_u = R1;
+    p.log_v = l1;
+    p.tw_mul = 0;
+    p.wr_step = N >> l3;
+    return launch_pass(ctx, l3, p, true, R2 * (R1 / BT), ncols);
+}
+
+int deinterleave(pk_ctx* ctx, const fe* coeffs, size_t n_coeffs, unsigned fold, fe* S, size_t col_stride) {
+    size_t fw = (size_t)1 << fold;
+    size_t L = n_coeffs / fw;
+    PK_REQUIRE(ctx, fw <= 1024, "fold too large");
+    size_t TT = 1024 / fw;
+    unsigned grid = (unsigned)((L + TT - 1) / TT);
+    deinterleave_kernel<1024><<<grid, 256, 1024 * 32, ctx->stream>>>(coeffs, S, L, (unsigned)fw, col_stride);
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+}  // namespace pk
+
+extern "C" {
+
+int pk_ntt(pk_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, unsigned log_n, unsigned ncols) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, d_in && d_out, "null pointer");
+    PK_REQUIRE(ctx, ncols >= 1, "ncols must be >= 1");
+    size_t N = (size_t)1 << log_n;
+    fe* scratch = nullptr;
+    if (log_n > 9) PK_HIP(ctx, hipMalloc((void**)&scratch, 32 * N * ncols));
+    int rc = pk::ntt_columns(ctx, (const fe*)d_in, N, N, (fe*)d_out, N, scratch, log_n, ncols);
+    if (scratch) {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(scratch);
+        if (!rc && e != hipSuccess) rc = set_err(ctx, PK_ERR_HIP, "ntt failed: %s", hipGetErrorString(e));
+    }
+    return rc;
+}
+
+int pk_rs_encode(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
+                 unsigned fold, uint64_t* d_leaves, uint64_t* d_scratch) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, d_coeffs && d_leaves && d_scratch, "null pointer");
+    PK_REQUIRE(ctx, batch >= 1 && batch <= 16, "batch out of range");
+    PK_REQUIRE(ctx, fold <= n_vars && fold <= 8, "fold out of range");
+    PK_REQUIRE(ctx, n_vars + log_inv_rate >= fold && n_vars + log_inv_rate - fold <= 27, "domain too large (two-adicity 28)");
+    unsigned log_rows = n_vars + log_inv_rate - fold;
+    size_t rows = (size_t)1 << log_rows, fw = (size_t)1 << fold;
+    size_t L = ((size_t)1 << n_vars) / fw;
+    fe* S = (fe*)d_scratch;                 // first half: de-interleaved coefficients, [batch*fw][rows]
+    fe* S2 = S + (size_t)batch * fw * rows;  // second half: inter-pass buffer
+    for (unsigned b = 0; b < batch; b++) {
+        PK_REQUIRE(ctx, d_coeffs[b], "null polynomial pointer");
+        int rc = pk::deinterleave(ctx, (const fe*)d_coeffs[b], (size_t)1 << n_vars, fold, S + (size_t)b * fw * rows, rows);
+        if (rc) return rc;
+    }
+    return pk::ntt_columns(ctx, S, rows, L, (fe*)d_leaves, rows, S2, log_rows, (unsigned)(batch * fw));
+}
+
+}  // extern "C"

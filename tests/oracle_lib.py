@@ -22,6 +22,7 @@ L.pko_pow_solve.restype = C.c_uint64
 L.pko_pow_solve.argtypes = [C.c_void_p, C.c_double]
 L.pko_pow_verify.argtypes = [C.c_void_p, C.c_double, C.c_uint64]
 L.pko_pow_threshold.argtypes = [C.c_double, C.c_void_p]
+L.pko_fe_pow.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
 L.pko_sbox.restype = C.c_uint8
 L.pko_sbox.argtypes = [C.c_uint8]
 

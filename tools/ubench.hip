@@ -17,13 +17,14 @@
         }                                                                             \
     } while (0)
 
-constexpr int ITERS = 2048;
+constexpr int ITERS = 16384;
 constexpr int UNROLL = 8;  // independent chains per lane
 
 #define BODY8(stmt) stmt(0) stmt(1) stmt(2) stmt(3) stmt(4) stmt(5) stmt(6) stmt(7)
 
 template <int OP>
-__global__ __launch_bounds__(256) void bench(unsigned* out, unsigned seed) {
+__global__ __launch_bounds__(256) void bench(unsigned* out, unsigned seed, unsigned long long* cyc) {
+    unsigned long long t0 = __builtin_readcyclecounter();
     unsigned a = threadIdx.x * 2654435761u + seed, b = a ^ 0x9e3779b9u;
     unsigned long long acc[UNROLL];
     double facc[UNROLL];
@@ -102,21 +103,24 @@ __global__ __launch_bounds__(256) void bench(unsigned* out, unsigned seed) {
     unsigned long long r = 0;
     for (int k = 0; k < UNROLL; k++) r ^= acc[k] ^ (unsigned long long)__double_as_longlong(facc[k]);
     if (r == 0x1234567887654321ull) out[0] = (unsigned)r;  // keep results live
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if (blockIdx.x == 0 && threadIdx.x == 0) cyc[0] = t1 - t0;
 }
 
 template <int OP>
-void run(const char* name, unsigned* d_out, int cus, double ghz) {
-    int waves_per_simd = 4;
+void run(const char* name, unsigned* d_out, int cus, double ghz, int waves_per_simd = 4) {
+    static unsigned long long* d_cyc = nullptr;
+    if (!d_cyc) CHECK(hipMalloc(&d_cyc, 8));
     int blocks = cus * waves_per_simd;  // 256 threads = 4 waves = one per SIMD
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    bench<OP><<<blocks, 256>>>(d_out, 1);
+    bench<OP><<<blocks, 256>>>(d_out, 1, d_cyc);
     CHECK(hipDeviceSynchronize());
     float best = 1e30f;
     for (int rep = 0; rep < 5; rep++) {
         CHECK(hipEventRecord(e0));
-        bench<OP><<<blocks, 256>>>(d_out, rep);
+        bench<OP><<<blocks, 256>>>(d_out, rep, d_cyc);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms;
@@ -126,8 +130,11 @@ void run(const char* name, unsigned* d_out, int cus, double ghz) {
     double wave_instr_per_simd = (double)ITERS * UNROLL * waves_per_simd;
     double cycles = best * 1e-3 * ghz * 1e9 / wave_instr_per_simd;
     double lane_ops_per_s = (double)blocks * 256 * ITERS * UNROLL / (best * 1e-3);
-    printf("%-18s %8.3f ms  %6.2f cyc/wave-instr/SIMD (at %.2f GHz)  %8.2f Tlane-op/s\n", name, best, cycles, ghz,
-           lane_ops_per_s * 1e-12);
+    unsigned long long hc = 0;
+    CHECK(hipMemcpy(&hc, d_cyc, 8, hipMemcpyDeviceToHost));
+    double cyc_ctr = (double)hc / wave_instr_per_simd;
+    printf("%-18s w/SIMD=%d %8.3f ms  %6.2f cyc/instr (wall@%.2fGHz)  %6.2f cyc/instr (s_memtime)  %8.2f Tlane-op/s\n", name,
+           waves_per_simd, best, cycles, ghz, cyc_ctr, lane_ops_per_s * 1e-12);
 }
 
 int main() {
@@ -138,6 +145,9 @@ int main() {
     unsigned* d_out;
     CHECK(hipMalloc(&d_out, 64));
     int cus = prop.multiProcessorCount;
+    run<7>("v_add_u32", d_out, cus, ghz, 1);
+    run<0>("v_mad_u64_u32", d_out, cus, ghz, 1);
+    run<0>("v_mad_u64_u32", d_out, cus, ghz, 2);
     run<7>("v_add_u32", d_out, cus, ghz);
     run<13>("v_mov_b32", d_out, cus, ghz);
     run<5>("v_add_co_u32", d_out, cus, ghz);
