@@ -124,6 +124,115 @@ int pk_rs_encode(pk_ctx *ctx, const uint64_t *const *d_coeffs, unsigned batch, u
  * out[c][k] = sum_i in[c][i] * w_N^(i k)   (helper of pk_rs_encode; exposed for tests/bench) */
 int pk_ntt(pk_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned ncols);
 
+/* ------------------------------------------------------------------ T1: multilinear evals <-> coefficients
+ * EvaluationsList::to_coeffs (whir; call sites provekit/prover/src/whir_r1cs.rs:195,198) and its
+ * inverse, in place over 2^n_vars FEs: for every index bit h, v[i|h] -= v[i] (resp. +=). */
+int pk_to_coeffs(pk_ctx *ctx, uint64_t *d_evals, unsigned n_vars);
+int pk_to_evals(pk_ctx *ctx, uint64_t *d_coeffs, unsigned n_vars);
+
+/* ------------------------------------------------------------------ S2 / W2: equality-polynomial tables
+ * calculate_evaluations_over_boolean_hypercube_for_eq / eval_eq
+ * (provekit/common/src/utils/sumcheck.rs:146-171): d_out[i] = prod_j (bit_j(i) ? r_j : 1-r_j), variable 0
+ * <-> most significant index bit; r = m host FEs; d_out = 2^m device FEs. */
+int pk_eq_table(pk_ctx *ctx, const uint64_t *r, unsigned m, uint64_t *d_out);
+/* d_w[i] (+)= sum_{t<q} scales[t] * eq(points[t], i): whir's add-equality-weights for the OOD and STIR
+ * points of a round.  points = q*n_vars host FEs, scales = q host FEs;
+ * overwrite != 0 starts from zero instead of accumulating. */
+int pk_eq_accumulate(pk_ctx *ctx, uint64_t *d_w, unsigned n_vars, const uint64_t *points, const uint64_t *scales,
+                     unsigned q, int overwrite);
+
+/* ------------------------------------------------------------------ S3: Spartan cubic sumcheck round
+ * sumcheck_fold_map_reduce::<4,3> (provekit/common/src/utils/sumcheck.rs:16-104) with the cubic map of
+ * provekit/prover/src/whir_r1cs.rs:284-291.  len = current length of each of the four arrays.
+ * fold_or_null == NULL: pairs (i, i+len/2).  Otherwise the leading variable is first folded in place
+ * (p0 += fold*(p2-p0), p1 += fold*(p3-p1) on quarters, sumcheck.rs:92-97), pairs are (i, i+len/4), and
+ * the caller continues with len/2 (the reference truncates, whir_r1cs.rs:292-297).
+ * out = [f(0), f(-1), f_inf] as 3 host FEs.  Blocking (synchronises the stream). */
+int pk_sumcheck_cubic_round(pk_ctx *ctx, uint64_t *d_a, uint64_t *d_b, uint64_t *d_c, uint64_t *d_eq, size_t len,
+                            const uint64_t *fold_or_null, uint64_t out[12]);
+
+/* ------------------------------------------------------------------ W3: WHIR quadratic sumcheck sub-round
+ * h(X) = sum_i f(i,X) w(i,X) over adjacent pairs (2i, 2i+1); out = [h(0), h(1), h(2)]
+ * (recursive-verifier/app/circuit/whir_utilities.go:102-125; utilities.go:148-154).
+ * With fold != NULL, f and w (length len) are first folded by it, v'[i] = v[2i] + fold*(v[2i+1]-v[2i]),
+ * into d_f_out / d_w_out (length len/2, must not alias the inputs) and the sums run over the folded
+ * arrays.  Blocking. */
+int pk_sumcheck_quadratic_round(pk_ctx *ctx, const uint64_t *d_f, const uint64_t *d_w, size_t len,
+                                const uint64_t *fold_or_null, uint64_t *d_f_out, uint64_t *d_w_out, uint64_t out[12]);
+/* v'[i] = v[2i] + r*(v[2i+1]-v[2i]); out-of-place, length len -> len/2 */
+int pk_fold_pairs(pk_ctx *ctx, const uint64_t *d_v, size_t len, const uint64_t *r, uint64_t *d_out);
+
+/* ------------------------------------------------------------------ S5 / E1 / W1 / batching
+ * pk_dot: Weights::linear(w).weighted_sum(f) = sum w[i] f[i] (provekit/prover/src/whir_r1cs.rs:401-405).
+ * pk_eval_univariate: sum c[i] z^i = the multilinear coefficient form evaluated at
+ *   (z^(2^(n-1)), ..., z^2, z), i.e. an OOD answer (utilities.go:182-190).
+ * pk_fold_coeffs: out[t] = sum_j c[2^k t + j] prod_b r_b^bit_b(j), r[0] <-> bit 0
+ *   (MultivarPoly, utilities.go:15-22; whir_utilities.go:180-186); 2^n_vars -> 2^(n_vars-k) FEs.
+ * pk_fe_axpy: y += beta*x (batching f + beta*g, mtUtilities.go:98-114). */
+int pk_dot(pk_ctx *ctx, const uint64_t *d_w, const uint64_t *d_f, size_t n, uint64_t out[4]);
+int pk_eval_univariate(pk_ctx *ctx, const uint64_t *d_coeffs, size_t n, const uint64_t z[4], uint64_t out[4]);
+int pk_fold_coeffs(pk_ctx *ctx, const uint64_t *d_coeffs, unsigned n_vars, const uint64_t *r, unsigned k,
+                   uint64_t *d_out);
+int pk_fe_axpy(pk_ctx *ctx, uint64_t *d_y, const uint64_t *beta, const uint64_t *d_x, size_t n);
+
+/* ------------------------------------------------------------------ S1 / S4: R1CS sparse products
+ * pk_sparse_matrix mirrors provekit_common::SparseMatrix (provekit/common/src/sparse_matrix.rs:12-27):
+ * new_row_indices[num_rows] = offset of each row's first entry, col_indices[nnz], values[nnz] =
+ * indices into the Interner's table of distinct field elements (interner.rs).  mats = {A, B, C}. */
+typedef struct pk_sparse_matrix {
+    const uint32_t *new_row_indices;
+    const uint32_t *col_indices;
+    const uint32_t *values;
+    size_t nnz;
+} pk_sparse_matrix;
+int pk_r1cs_create(pk_ctx *ctx, size_t num_constraints, size_t num_witnesses, const pk_sparse_matrix mats[3],
+                   const uint64_t *interner, size_t n_interned, pk_r1cs **out);
+int pk_r1cs_destroy(pk_ctx *ctx, pk_r1cs *r1cs);
+/* calculate_witness_bounds (sumcheck.rs:181-193): a = A z, b = B z, c = a o b, each zero-padded to 2^m0 */
+int pk_r1cs_witness_bounds(pk_ctx *ctx, const pk_r1cs *r1cs, const uint64_t *d_z, unsigned m0, uint64_t *d_a,
+                           uint64_t *d_b, uint64_t *d_c);
+/* HydratedSparseMatrix * v (transpose == 0, sparse_matrix.rs:150-165) or v * HydratedSparseMatrix
+ * (transpose != 0, sparse_matrix.rs:169-184); matrix = 0 (A), 1 (B), 2 (C) */
+int pk_r1cs_matvec(pk_ctx *ctx, const pk_r1cs *r1cs, int matrix, int transpose, const uint64_t *d_x, uint64_t *d_y);
+/* calculate_external_row_of_r1cs_matrices (sumcheck.rs:207-218): d_out = [eq^T A | eq^T B | eq^T C],
+ * 3 * num_witnesses FEs; d_eq_alpha holds at least num_constraints FEs */
+int pk_r1cs_external_row(pk_ctx *ctx, const pk_r1cs *r1cs, const uint64_t *d_eq_alpha, uint64_t *d_out);
+
+/* ------------------------------------------------------------------ P1: proof of work
+ * spongefish_pow::PowStrategy for Skyscraper (provekit/common/src/skyscraper/pow.rs:14-30):
+ * pk_pow_solve = solve() -> skyscraper::pow::solve (skyscraper/core/src/pow.rs:33-41; adds the 0.01
+ * prover bias); returns the SMALLEST nonce with compress(challenge, [nonce,0,0,0]) < threshold (the
+ * reference returns whichever valid nonce its threads find first, generic.rs:42-71).
+ * pk_pow_check = check() -> pow::verify (pow.rs:24-26).  pk_pow_threshold = pow.rs:14-22 (host only). */
+int pk_pow_threshold(double difficulty, uint64_t out[4]);
+int pk_pow_solve(pk_ctx *ctx, const uint8_t challenge[32], double bits, uint64_t *nonce);
+int pk_pow_check(pk_ctx *ctx, const uint8_t challenge[32], double bits, uint64_t nonce, int *ok);
+
+/* ------------------------------------------------------------------ commitment handle + openings (N1+N2+M1+M2, Q1)
+ * pk_commit: the data-parallel body of whir's CommitmentWriter::commit_batch
+ * (provekit/prover/src/whir_r1cs.rs:200-206): RS-encode `batch` coefficient vectors, hash the leaves
+ * (width = batch*2^fold), build the tree; root_out = canonical 32-byte root (what add_digest sends,
+ * provekit/common/src/skyscraper/whir.rs:96-102).  The codeword matrix and all tree levels stay in
+ * HBM behind *out until pk_tree_destroy.
+ * pk_tree_from_leaves: MerkleTree::new over leaves already on the device (borrowed, not copied).
+ * pk_tree_open: MerkleTree::generate_multi_proof + leaf gather for k leaf indices: leaves_out =
+ * k*width FEs leaf-major (Montgomery, or canonical as ark-serialize writes them if canonical_leaves),
+ * sibling_digests = k canonical digests, auth_paths = k*(log2(n_leaves)-1) canonical digests in
+ * root->leaf order.  pk_multipath_serialize (host only): ark MultiPath wire form, prefix-compressed
+ * (types.go:17-22; utilities.go:71-82); out == NULL queries the length. */
+int pk_commit(pk_ctx *ctx, const uint64_t *const *d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
+              unsigned fold, uint8_t root_out[32], pk_tree **out);
+int pk_tree_from_leaves(pk_ctx *ctx, const uint64_t *d_leaves, size_t n_leaves, size_t width, int layout,
+                        uint8_t root_out[32], pk_tree **out);
+int pk_tree_info(const pk_tree *tree, size_t *n_leaves, size_t *width, const uint64_t **d_leaves,
+                 const uint64_t **d_nodes);
+int pk_tree_root(pk_ctx *ctx, const pk_tree *tree, uint8_t root[32]);
+int pk_tree_open(pk_ctx *ctx, const pk_tree *tree, const uint64_t *indices, size_t k, int canonical_leaves,
+                 uint64_t *leaves_out, uint64_t *sibling_digests, uint64_t *auth_paths);
+int pk_tree_destroy(pk_ctx *ctx, pk_tree *tree);
+int pk_multipath_serialize(const uint64_t *indices, size_t k, size_t path_len, const uint64_t *sibling_digests,
+                           const uint64_t *auth_paths, uint8_t *out, size_t out_cap, size_t *out_len);
+
 #ifdef __cplusplus
 }
 #endif

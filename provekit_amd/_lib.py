@@ -71,7 +71,37 @@ SIGNATURES = {
     "pk_merkle_commit": (C.c_int, [vp, vp, sz, sz, C.c_int, vp]),
     "pk_rs_encode": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
     "pk_ntt": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint]),
+    "pk_to_coeffs": (C.c_int, [vp, vp, C.c_uint]),
+    "pk_to_evals": (C.c_int, [vp, vp, C.c_uint]),
+    "pk_eq_table": (C.c_int, [vp, vp, C.c_uint, vp]),
+    "pk_eq_accumulate": (C.c_int, [vp, vp, C.c_uint, vp, vp, C.c_uint, C.c_int]),
+    "pk_sumcheck_cubic_round": (C.c_int, [vp, vp, vp, vp, vp, sz, vp, vp]),
+    "pk_sumcheck_quadratic_round": (C.c_int, [vp, vp, vp, sz, vp, vp, vp, vp]),
+    "pk_fold_pairs": (C.c_int, [vp, vp, sz, vp, vp]),
+    "pk_dot": (C.c_int, [vp, vp, vp, sz, vp]),
+    "pk_eval_univariate": (C.c_int, [vp, vp, sz, vp, vp]),
+    "pk_fold_coeffs": (C.c_int, [vp, vp, C.c_uint, vp, C.c_uint, vp]),
+    "pk_fe_axpy": (C.c_int, [vp, vp, vp, vp, sz]),
+    "pk_r1cs_create": (C.c_int, [vp, sz, sz, vp, vp, sz, C.POINTER(vp)]),
+    "pk_r1cs_destroy": (C.c_int, [vp, vp]),
+    "pk_r1cs_witness_bounds": (C.c_int, [vp, vp, vp, C.c_uint, vp, vp, vp]),
+    "pk_r1cs_matvec": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
+    "pk_r1cs_external_row": (C.c_int, [vp, vp, vp, vp]),
+    "pk_pow_threshold": (C.c_int, [C.c_double, vp]),
+    "pk_pow_solve": (C.c_int, [vp, vp, C.c_double, C.POINTER(C.c_uint64)]),
+    "pk_pow_check": (C.c_int, [vp, vp, C.c_double, C.c_uint64, C.POINTER(C.c_int)]),
+    "pk_commit": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, C.POINTER(vp)]),
+    "pk_tree_from_leaves": (C.c_int, [vp, vp, sz, sz, C.c_int, vp, C.POINTER(vp)]),
+    "pk_tree_info": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(vp), C.POINTER(vp)]),
+    "pk_tree_root": (C.c_int, [vp, vp, vp]),
+    "pk_tree_open": (C.c_int, [vp, vp, vp, sz, C.c_int, vp, vp, vp]),
+    "pk_tree_destroy": (C.c_int, [vp, vp]),
+    "pk_multipath_serialize": (C.c_int, [vp, sz, sz, vp, vp, vp, sz, C.POINTER(sz)]),
 }
+
+
+class SparseMatrixStruct(C.Structure):
+    _fields_ = [("new_row_indices", vp), ("col_indices", vp), ("values", vp), ("nnz", sz)]
 
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here == header/library mismatch: fail loudly

@@ -49,6 +49,7 @@ int pk_ctx_destroy(pk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     pk::ntt_release_ctx(ctx);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
@@ -149,6 +150,18 @@ int ensure_scratch(pk_ctx* ctx, size_t bytes) {
     size_t sz = bytes < (1u << 20) ? (1u << 20) : bytes;
     PK_HIP(ctx, hipMalloc(&ctx->d_scratch, sz));
     ctx->scratch_bytes = sz;
+    return PK_OK;
+}
+int ensure_ws(pk_ctx* ctx, size_t bytes) {
+    if (ctx->ws_bytes >= bytes) return PK_OK;
+    if (ctx->d_ws) {
+        PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PK_HIP(ctx, hipFree(ctx->d_ws));
+        ctx->d_ws = nullptr;
+        ctx->ws_bytes = 0;
+    }
+    PK_HIP(ctx, hipMalloc(&ctx->d_ws, bytes));
+    ctx->ws_bytes = bytes;
     return PK_OK;
 }
 }  // namespace pk

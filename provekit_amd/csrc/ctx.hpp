@@ -22,6 +22,8 @@ struct pk_ctx {
     size_t scratch_bytes = 0;
     void* h_pinned = nullptr;  // pinned host staging for small results
     size_t pinned_bytes = 0;
+    void* d_ws = nullptr;  // large reusable workspace (NTT scratch); grows, never shrinks
+    size_t ws_bytes = 0;
 };
 
 namespace pk {
@@ -71,6 +73,7 @@ inline unsigned grid_for(const pk_ctx* ctx, size_t n, unsigned block, unsigned m
 }
 
 int ensure_scratch(pk_ctx* ctx, size_t bytes);
+int ensure_ws(pk_ctx* ctx, size_t bytes);
 void ntt_release_ctx(pk_ctx* ctx);  // ntt.hip: frees the per-context twiddle tables
 
 }  // namespace pk

@@ -1,0 +1,523 @@
+// mle.hip -- multilinear-extension kernels of the Spartan sumcheck and the WHIR rounds
+// (SURVEY 8a rows T1, S2, S3, S5, E1, W1, W2, W3).
+//
+// All of these stream 32-byte field elements with a handful of modular multiplies per
+// element, so each is laid out for coalesced 32 B/lane access, keeps its arrays resident
+// in HBM across rounds, and returns only the 3-4 field elements the Fiat-Shamir
+// transcript needs per round (grid reduction in reduce.hpp).
+#include "ctx.hpp"
+#include "fe.hpp"
+#include "reduce.hpp"
+
+using namespace pk;
+
+namespace {
+
+struct fe_arg {
+    u32 v[8];
+};
+__device__ __forceinline__ fe from_arg(const fe_arg& a) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = a.v[i];
+    return r;
+}
+inline fe_arg to_arg(const uint64_t* h) {
+    fe_arg a;
+    memcpy(a.v, h, 32);
+    return a;
+}
+
+__device__ __forceinline__ fe lds_get(const uint4* lo, const uint4* hi, int i) {
+    uint4 l = lo[i], h = hi[i];
+    fe x;
+    x.v[0] = l.x; x.v[1] = l.y; x.v[2] = l.z; x.v[3] = l.w;
+    x.v[4] = h.x; x.v[5] = h.y; x.v[6] = h.z; x.v[7] = h.w;
+    return x;
+}
+__device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, int i, const fe& x) {
+    lo[i] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
+    hi[i] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
+}
+
+// ---------------------------------------------------------------- T1: evals <-> coeffs
+// EvaluationsList::to_coeffs (call sites provekit/prover/src/whir_r1cs.rs:195,198): for every
+// variable (index bit) h: v[i | h] -= v[i].  SUB=false gives the inverse (to_evals).
+// low kernel: bits [0, LOGT) on a contiguous tile of 2^LOGT elements held in LDS.
+template <bool SUB>
+__global__ __launch_bounds__(256) void wavelet_low_kernel(fe* __restrict__ data, unsigned logt) {
+    extern __shared__ uint4 lds[];
+    const int T = 1 << logt;
+    uint4* lo = lds;
+    uint4* hi = lds + T;
+    fe* base = data + (size_t)blockIdx.x * T;
+    for (int e = threadIdx.x; e < T; e += 256) {
+        const uint4* q = reinterpret_cast<const uint4*>(base + e);
+        lo[e] = q[0];
+        hi[e] = q[1];
+    }
+    __syncthreads();
+    for (unsigned s = 0; s < logt; s++) {
+        const int h = 1 << s;
+        for (int t = threadIdx.x; t < T / 2; t += 256) {
+            int pos = t & (h - 1);
+            int i0 = ((t - pos) << 1) + pos, i1 = i0 + h;
+            fe a = lds_get(lo, hi, i0), b = lds_get(lo, hi, i1);
+            lds_put(lo, hi, i1, SUB ? fe_sub(b, a) : fe_add(b, a));
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < T; e += 256) {
+        uint4* q = reinterpret_cast<uint4*>(base + e);
+        q[0] = lo[e];
+        q[1] = hi[e];
+    }
+}
+// high kernel: bits [s, s+logr): element index = u*2^(s+logr) + r*2^s + v; tile = [2^logr][4 adjacent v]
+template <bool SUB>
+__global__ __launch_bounds__(256) void wavelet_high_kernel(fe* __restrict__ data, unsigned s, unsigned logr) {
+    extern __shared__ uint4 lds[];
+    constexpr int BT = 4;
+    const int R = 1 << logr;
+    const int TILE = R * BT;
+    uint4* lo = lds;
+    uint4* hi = lds + TILE;
+    const size_t vblocks = ((size_t)1 << s) / BT;
+    const size_t u = blockIdx.x / vblocks, vb = blockIdx.x % vblocks;
+    fe* base = data + (u << (s + logr)) + vb * BT;
+    for (int e = threadIdx.x; e < TILE; e += 256) {
+        int b = e % BT, r = e / BT;
+        const uint4* q = reinterpret_cast<const uint4*>(base + ((size_t)r << s) + b);
+        lo[e] = q[0];
+        hi[e] = q[1];
+    }
+    __syncthreads();
+    for (unsigned st = 0; st < logr; st++) {
+        const int h = 1 << st;
+        for (int t = threadIdx.x; t < (R / 2) * BT; t += 256) {
+            int b = t % BT, j = t / BT;
+            int pos = j & (h - 1);
+            int i0 = ((j - pos) << 1) + pos, i1 = i0 + h;
+            fe a = lds_get(lo, hi, i0 * BT + b), c = lds_get(lo, hi, i1 * BT + b);
+            lds_put(lo, hi, i1 * BT + b, SUB ? fe_sub(c, a) : fe_add(c, a));
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < TILE; e += 256) {
+        int b = e % BT, r = e / BT;
+        uint4* q = reinterpret_cast<uint4*>(base + ((size_t)r << s) + b);
+        q[0] = lo[e];
+        q[1] = hi[e];
+    }
+}
+
+template <bool SUB>
+int wavelet(pk_ctx* ctx, uint64_t* d_data, unsigned n_vars) {
+    PK_REQUIRE(ctx, d_data, "null pointer");
+    PK_REQUIRE(ctx, n_vars <= 30, "too many variables");
+    if (n_vars == 0) return PK_OK;
+    fe* D = (fe*)d_data;
+    unsigned logt = n_vars < 11 ? n_vars : 11;
+    size_t lds = ((size_t)2 << logt) * 16;
+    PK_HIP(ctx, hipFuncSetAttribute((const void*)wavelet_low_kernel<SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 16));
+    wavelet_low_kernel<SUB><<<(unsigned)((size_t)1 << (n_vars - logt)), 256, lds, ctx->stream>>>(D, logt);
+    unsigned s = logt;
+    PK_HIP(ctx, hipFuncSetAttribute((const void*)wavelet_high_kernel<SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 16));
+    while (s < n_vars) {
+        unsigned logr = n_vars - s < 9 ? n_vars - s : 9;
+        size_t tiles = ((size_t)1 << (n_vars - logr)) / 4;
+        size_t l2 = ((size_t)2 << logr) * 4 * 16;
+        wavelet_high_kernel<SUB><<<(unsigned)tiles, 256, l2, ctx->stream>>>(D, s, logr);
+        s += logr;
+    }
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+// ---------------------------------------------------------------- S2 / W2: eq tables
+// eval_eq (provekit/common/src/utils/sumcheck.rs:146-171): out[i] += scalar * prod_j (bit_j(i) ? x_j : 1-x_j),
+// variable 0 <-> most significant index bit.  eq(x, i) = eq_hi(x[0..nhi), i >> nlo) * eq_lo(x[nhi..n), i & mask):
+// one block builds each half table (level by level, in global memory), then one streaming kernel
+// accumulates all q points into w -- one multiply per (point, element).
+// tables layout: [pt][ 2^nhi hi entries | 2^nlo lo entries ]
+__global__ __launch_bounds__(256) void eq_half_tables_kernel(const fe* __restrict__ points, const fe* __restrict__ scales,
+                                                             unsigned n_vars, unsigned nhi, unsigned nlo, fe* __restrict__ tables) {
+    const unsigned pt = blockIdx.x, half = blockIdx.y;
+    const size_t per_pt = ((size_t)1 << nhi) + ((size_t)1 << nlo);
+    fe* T = tables + pt * per_pt + (half ? ((size_t)1 << nhi) : 0);
+    const fe* x = points + (size_t)pt * n_vars + (half ? nhi : 0);
+    const unsigned nv = half ? nlo : nhi;
+    if (threadIdx.x == 0) fe_store(T, half ? fe_one() : fe_load(scales + pt));
+    __threadfence_block();
+    __syncthreads();
+    // Level l appends variable nv-1-l as index bit l, so the last variable is the LSB and variable 0
+    // ends up as the MSB, as eval_eq's recursion orders it: T[h+i] = x*T[i] (s1), T[i] -= that (s0).
+    for (unsigned l = 0; l < nv; l++) {
+        const size_t h = (size_t)1 << l;
+        fe xv = fe_load(x + (nv - 1 - l));
+        for (size_t i = threadIdx.x; i < h; i += 256) {
+            fe t = fe_load(T + i);
+            fe up = fe_mul(t, xv);  // s1 = s * x
+            fe_store(T + h + i, up);
+            fe_store(T + i, fe_sub(t, up));  // s0 = s - s1
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void eq_accumulate_kernel(fe* __restrict__ w, size_t n, unsigned nhi, unsigned nlo, unsigned q,
+                                                            const fe* __restrict__ tables, int overwrite) {
+    const size_t per_pt = ((size_t)1 << nhi) + ((size_t)1 << nlo);
+    const size_t mask = ((size_t)1 << nlo) - 1;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        fe acc = overwrite ? fe_zero() : fe_load(w + i);
+        const fe* T = tables;
+        for (unsigned pt = 0; pt < q; pt++, T += per_pt) {
+            fe h = fe_load(T + (i >> nlo));
+            fe l = fe_load(T + ((size_t)1 << nhi) + (i & mask));
+            acc = fe_add(acc, fe_mul(h, l));
+        }
+        fe_store(w + i, acc);
+    }
+}
+
+// ---------------------------------------------------------------- S3: cubic sumcheck round
+// sumcheck_fold_map_reduce::<4,3> (provekit/common/src/utils/sumcheck.rs:16-104) with the map of
+// provekit/prover/src/whir_r1cs.rs:284-291.
+template <bool FOLD>
+__global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_kernel(fe* __restrict__ a, fe* __restrict__ b, fe* __restrict__ c,
+                                                                     fe* __restrict__ eq, size_t len, fe_arg fold_arg,
+                                                                     fe* __restrict__ partials) {
+    __shared__ uint4 smem[3 * RED_THREADS * 2];
+    const fe alpha = from_arg(fold_arg);
+    const size_t npairs = FOLD ? len / 4 : len / 2;
+    const size_t off = npairs;          // partner of i is i + off (quarter 1 after folding, or the upper half)
+    const size_t foff = len / 2;        // fold partner: p2 = p0 + len/2
+    fe acc[3] = {fe_zero(), fe_zero(), fe_zero()};
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += stride) {
+        fe v[4][2];
+        fe* arr[4] = {a, b, c, eq};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            fe x0 = fe_load(arr[k] + i), x1 = fe_load(arr[k] + i + off);
+            if (FOLD) {  // sumcheck.rs:95-96: p0 += fold*(p2-p0); p1 += fold*(p3-p1)
+                fe x2 = fe_load(arr[k] + i + foff), x3 = fe_load(arr[k] + i + off + foff);
+                x0 = fe_add(x0, fe_mul(alpha, fe_sub(x2, x0)));
+                x1 = fe_add(x1, fe_mul(alpha, fe_sub(x3, x1)));
+                fe_store(arr[k] + i, x0);
+                fe_store(arr[k] + i + off, x1);
+            }
+            v[k][0] = x0;
+            v[k][1] = x1;
+        }
+        const fe &a0 = v[0][0], &a1 = v[0][1], &b0 = v[1][0], &b1 = v[1][1], &c0 = v[2][0], &c1 = v[2][1], &e0 = v[3][0], &e1 = v[3][1];
+        // f0 = eq0 * (a0*b0 - c0)
+        acc[0] = fe_add(acc[0], fe_mul(e0, fe_sub(fe_mul(a0, b0), c0)));
+        // f(-1) = (2eq0-eq1) * ((2a0-a1)(2b0-b1) - (2c0-c1))
+        fe ta = fe_sub(fe_dbl(a0), a1), tb = fe_sub(fe_dbl(b0), b1), tc = fe_sub(fe_dbl(c0), c1), te = fe_sub(fe_dbl(e0), e1);
+        acc[1] = fe_add(acc[1], fe_mul(te, fe_sub(fe_mul(ta, tb), tc)));
+        // f_inf = (eq1-eq0)(a1-a0)(b1-b0)
+        acc[2] = fe_add(acc[2], fe_mul(fe_mul(fe_sub(e1, e0), fe_sub(a1, a0)), fe_sub(b1, b0)));
+    }
+    block_reduce_fe<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        fe_store(partials + (size_t)blockIdx.x * 3 + 0, acc[0]);
+        fe_store(partials + (size_t)blockIdx.x * 3 + 1, acc[1]);
+        fe_store(partials + (size_t)blockIdx.x * 3 + 2, acc[2]);
+    }
+}
+
+// ---------------------------------------------------------------- W3: quadratic sumcheck round
+// adjacent pairs (2i, 2i+1): h(0)=sum f0 w0, h(1)=sum f1 w1, h(2)=sum (2f1-f0)(2w1-w0)
+// (recursive-verifier/app/circuit/whir_utilities.go:102-125; utilities.go:148-154).
+// FOLD: first v'[i] = v[2i] + r (v[2i+1]-v[2i]) written to the *_out arrays (out-of-place).
+template <bool FOLD>
+__global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_kernel(const fe* __restrict__ f, const fe* __restrict__ w,
+                                                                         size_t out_len, fe_arg fold_arg, fe* __restrict__ f_out,
+                                                                         fe* __restrict__ w_out, fe* __restrict__ partials) {
+    __shared__ uint4 smem[3 * RED_THREADS * 2];
+    const fe r = from_arg(fold_arg);
+    fe acc[3] = {fe_zero(), fe_zero(), fe_zero()};
+    const size_t npairs = out_len / 2;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += stride) {
+        fe f0, f1, w0, w1;
+        if (FOLD) {
+            fe x0 = fe_load(f + 4 * i), x1 = fe_load(f + 4 * i + 1), x2 = fe_load(f + 4 * i + 2), x3 = fe_load(f + 4 * i + 3);
+            f0 = fe_add(x0, fe_mul(r, fe_sub(x1, x0)));
+            f1 = fe_add(x2, fe_mul(r, fe_sub(x3, x2)));
+            fe y0 = fe_load(w + 4 * i), y1 = fe_load(w + 4 * i + 1), y2 = fe_load(w + 4 * i + 2), y3 = fe_load(w + 4 * i + 3);
+            w0 = fe_add(y0, fe_mul(r, fe_sub(y1, y0)));
+            w1 = fe_add(y2, fe_mul(r, fe_sub(y3, y2)));
+            fe_store(f_out + 2 * i, f0);
+            fe_store(f_out + 2 * i + 1, f1);
+            fe_store(w_out + 2 * i, w0);
+            fe_store(w_out + 2 * i + 1, w1);
+        } else {
+            f0 = fe_load(f + 2 * i);
+            f1 = fe_load(f + 2 * i + 1);
+            w0 = fe_load(w + 2 * i);
+            w1 = fe_load(w + 2 * i + 1);
+        }
+        acc[0] = fe_add(acc[0], fe_mul(f0, w0));
+        acc[1] = fe_add(acc[1], fe_mul(f1, w1));
+        acc[2] = fe_add(acc[2], fe_mul(fe_sub(fe_dbl(f1), f0), fe_sub(fe_dbl(w1), w0)));
+    }
+    block_reduce_fe<3>(acc, smem);
+    if (threadIdx.x == 0) {
+        fe_store(partials + (size_t)blockIdx.x * 3 + 0, acc[0]);
+        fe_store(partials + (size_t)blockIdx.x * 3 + 1, acc[1]);
+        fe_store(partials + (size_t)blockIdx.x * 3 + 2, acc[2]);
+    }
+}
+// the single-element tail of the fold (out_len == 1): v'[0] = v[0] + r (v[1]-v[0]); no pair to sum
+__global__ void fold_pairs_kernel(const fe* __restrict__ v, fe* __restrict__ out, size_t out_len, fe_arg r_arg) {
+    const fe r = from_arg(r_arg);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < out_len; i += stride) {
+        fe x0 = fe_load(v + 2 * i), x1 = fe_load(v + 2 * i + 1);
+        fe_store(out + i, fe_add(x0, fe_mul(r, fe_sub(x1, x0))));
+    }
+}
+
+// ---------------------------------------------------------------- S5: dot product
+__global__ __launch_bounds__(RED_THREADS) void dot_kernel(const fe* __restrict__ w, const fe* __restrict__ f, size_t n,
+                                                          fe* __restrict__ partials) {
+    __shared__ uint4 smem[RED_THREADS * 2];
+    fe acc[1] = {fe_zero()};
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        acc[0] = fe_add(acc[0], fe_mul(fe_load(w + i), fe_load(f + i)));
+    block_reduce_fe<1>(acc, smem);
+    if (threadIdx.x == 0) fe_store(partials + blockIdx.x, acc[0]);
+}
+
+// ---------------------------------------------------------------- E1: univariate evaluation
+// sum_i c[i] z^i: each thread Horner-evaluates a contiguous chunk, scales by z^(chunk start), block-reduces.
+constexpr int HORNER_CHUNK = 64;
+__device__ __forceinline__ fe fe_pow_u64(fe base, u64 e) {
+    fe acc = fe_one();
+    while (e) {
+        if (e & 1) acc = fe_mul(acc, base);
+        base = fe_sqr(base);
+        e >>= 1;
+    }
+    return acc;
+}
+__global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restrict__ c, size_t n, fe_arg z_arg,
+                                                             fe* __restrict__ partials) {
+    __shared__ uint4 smem[RED_THREADS * 2];
+    const fe z = from_arg(z_arg);
+    fe acc[1] = {fe_zero()};
+    const size_t nchunks = (n + HORNER_CHUNK - 1) / HORNER_CHUNK;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch < nchunks) {
+        fe zs = fe_pow_u64(z, (u64)stride * HORNER_CHUNK);  // z^(stride*chunk): step between this thread's chunks
+        fe zp = fe_pow_u64(z, (u64)ch * HORNER_CHUNK);      // z^(chunk start)
+        for (; ch < nchunks; ch += stride) {
+            size_t lo = ch * HORNER_CHUNK, hi = lo + HORNER_CHUNK < n ? lo + HORNER_CHUNK : n;
+            fe h = fe_zero();
+            for (size_t i = hi; i-- > lo;) h = fe_add(fe_mul(h, z), fe_load(c + i));
+            acc[0] = fe_add(acc[0], fe_mul(h, zp));
+            zp = fe_mul(zp, zs);
+        }
+    }
+    block_reduce_fe<1>(acc, smem);
+    if (threadIdx.x == 0) fe_store(partials + blockIdx.x, acc[0]);
+}
+
+// ---------------------------------------------------------------- W1: coefficient fold
+// out[t] = sum_j c[2^k t + j] * prod_b r_b^bit_b(j)   (MultivarPoly, utilities.go:15-22: r[0] <-> bit 0)
+struct fold_args {
+    fe_arg r[8];
+};
+__global__ __launch_bounds__(256) void fold_coeffs_kernel(const fe* __restrict__ c, size_t n_out, unsigned k, fold_args ra,
+                                                          fe* __restrict__ out) {
+    __shared__ uint4 wts[256 * 2];
+    // weights for j in [0, 2^k): built by doubling
+    if (threadIdx.x == 0) {
+        uint4* lo = wts;
+        uint4* hi = wts + 256;
+        lds_put(lo, hi, 0, fe_one());
+        for (unsigned b = 0; b < k; b++) {
+            fe rb = from_arg(ra.r[b]);
+            for (int j = 0; j < (1 << b); j++) lds_put(lo, hi, (1 << b) + j, fe_mul(lds_get(lo, hi, j), rb));
+        }
+    }
+    __syncthreads();
+    const int fw = 1 << k;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_out; t += stride) {
+        fe acc = fe_load(c + t * fw);
+        for (int j = 1; j < fw; j++) acc = fe_add(acc, fe_mul(fe_load(c + t * fw + j), lds_get(wts, wts + 256, j)));
+        fe_store(out + t, acc);
+    }
+}
+
+// y += beta * x ; y = a o b
+__global__ __launch_bounds__(256) void axpy_kernel(fe* __restrict__ y, const fe* __restrict__ x, size_t n, fe_arg beta_arg) {
+    const fe beta = from_arg(beta_arg);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        fe_store(y + i, fe_add(fe_load(y + i), fe_mul(beta, fe_load(x + i))));
+}
+
+}  // namespace
+
+extern "C" {
+
+int pk_to_coeffs(pk_ctx* ctx, uint64_t* d_evals, unsigned n_vars) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    return wavelet<true>(ctx, d_evals, n_vars);
+}
+int pk_to_evals(pk_ctx* ctx, uint64_t* d_coeffs, unsigned n_vars) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    return wavelet<false>(ctx, d_coeffs, n_vars);
+}
+
+int pk_eq_accumulate(pk_ctx* ctx, uint64_t* d_w, unsigned n_vars, const uint64_t* points, const uint64_t* scales, unsigned q,
+                     int overwrite) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, d_w && (q == 0 || (points && scales)), "null pointer");
+    PK_REQUIRE(ctx, n_vars <= 30, "too many variables");
+    const size_t n = (size_t)1 << n_vars;
+    if (q == 0) {
+        if (overwrite) PK_HIP(ctx, hipMemsetAsync(d_w, 0, 32 * n, ctx->stream));
+        return PK_OK;
+    }
+    const unsigned nlo = (n_vars + 1) / 2, nhi = n_vars - nlo;
+    const size_t per_pt = ((size_t)1 << nhi) + ((size_t)1 << nlo);
+    const size_t bytes = 32 * ((size_t)q * n_vars + q + (size_t)q * per_pt);
+    void* tmp = nullptr;
+    PK_HIP(ctx, hipMalloc(&tmp, bytes ? bytes : 32));
+    fe* d_points = (fe*)tmp;
+    fe* d_scales = d_points + (size_t)q * n_vars;
+    fe* d_tables = d_scales + q;
+    hipError_t e = hipSuccess;
+    if (n_vars) e = hipMemcpyAsync(d_points, points, 32 * (size_t)q * n_vars, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_scales, scales, 32 * (size_t)q, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        eq_half_tables_kernel<<<dim3(q, 2), 256, 0, ctx->stream>>>(d_points, d_scales, n_vars, nhi, nlo, d_tables);
+        eq_accumulate_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_w, n, nhi, nlo, q, d_tables, overwrite);
+        e = hipGetLastError();
+    }
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess || e2 != hipSuccess)
+        return set_err(ctx, PK_ERR_HIP, "eq_accumulate failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    return PK_OK;
+}
+
+int pk_eq_table(pk_ctx* ctx, const uint64_t* r, unsigned m, uint64_t* d_out) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    static const uint64_t one[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};
+    return pk_eq_accumulate(ctx, d_out, m, r, one, 1, 1);
+}
+
+int pk_sumcheck_cubic_round(pk_ctx* ctx, uint64_t* d_a, uint64_t* d_b, uint64_t* d_c, uint64_t* d_eq, size_t len,
+                            const uint64_t* fold_or_null, uint64_t out[12]) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, d_a && d_b && d_c && d_eq && out, "null pointer");
+    PK_REQUIRE(ctx, is_pow2(len) && len >= 2, "size must be a power of two >= 2");  // sumcheck.rs:22-23
+    PK_REQUIRE(ctx, !fold_or_null || len >= 4, "size must be >= 4 when folding");    // sumcheck.rs:27
+    int rc = reduction_scratch(ctx);
+    if (rc) return rc;
+    fe* partials = (fe*)ctx->d_scratch;
+    size_t npairs = fold_or_null ? len / 4 : len / 2;
+    unsigned blocks = reduction_blocks(ctx, npairs);
+    if (fold_or_null)
+        sumcheck_cubic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len,
+                                                                              to_arg(fold_or_null), partials);
+    else
+        sumcheck_cubic_kernel<false><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, fe_arg{},
+                                                                               partials);
+    PK_LAUNCH_CHECK(ctx);
+    return finish_reduction<3>(ctx, blocks, out);
+}
+
+int pk_sumcheck_quadratic_round(pk_ctx* ctx, const uint64_t* d_f, const uint64_t* d_w, size_t len, const uint64_t* fold_or_null,
+                                uint64_t* d_f_out, uint64_t* d_w_out, uint64_t out[12]) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, d_f && d_w && out, "null pointer");
+    PK_REQUIRE(ctx, is_pow2(len), "size must be a power of two");
+    size_t out_len = fold_or_null ? len / 2 : len;
+    PK_REQUIRE(ctx, out_len >= 2, "at least one pair is needed after folding");
+    PK_REQUIRE(ctx, !fold_or_null || (d_f_out && d_w_out && d_f_out != d_f && d_w_out != d_w), "folding is out-of-place");
+    int rc = reduction_scratch(ctx);
+    if (rc) return rc;
+    fe* partials = (fe*)ctx->d_scratch;
+    unsigned blocks = reduction_blocks(ctx, out_len / 2);
+    if (fold_or_null)
+        sumcheck_quadratic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len,
+                                                                                  to_arg(fold_or_null), (fe*)d_f_out, (fe*)d_w_out, partials);
+    else
+        sumcheck_quadratic_kernel<false><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, fe_arg{},
+                                                                                   nullptr, nullptr, partials);
+    PK_LAUNCH_CHECK(ctx);
+    return finish_reduction<3>(ctx, blocks, out);
+}
+
+int pk_fold_pairs(pk_ctx* ctx, const uint64_t* d_v, size_t len, const uint64_t* r, uint64_t* d_out) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, d_v && d_out && r && d_v != d_out, "null or aliased pointer");
+    PK_REQUIRE(ctx, is_pow2(len) && len >= 2, "size must be a power of two >= 2");
+    fold_pairs_kernel<<<grid_for(ctx, len / 2, 256), 256, 0, ctx->stream>>>((const fe*)d_v, (fe*)d_out, len / 2, to_arg(r));
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+int pk_dot(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, size_t n, uint64_t out[4]) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, out && (n == 0 || (d_w && d_f)), "null pointer");
+    if (n == 0) {
+        memset(out, 0, 32);
+        return PK_OK;
+    }
+    int rc = reduction_scratch(ctx);
+    if (rc) return rc;
+    unsigned blocks = reduction_blocks(ctx, n);
+    dot_kernel<<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_w, (const fe*)d_f, n, (fe*)ctx->d_scratch);
+    PK_LAUNCH_CHECK(ctx);
+    return finish_reduction<1>(ctx, blocks, out);
+}
+
+int pk_eval_univariate(pk_ctx* ctx, const uint64_t* d_coeffs, size_t n, const uint64_t z[4], uint64_t out[4]) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, out && z && (n == 0 || d_coeffs), "null pointer");
+    if (n == 0) {
+        memset(out, 0, 32);
+        return PK_OK;
+    }
+    int rc = reduction_scratch(ctx);
+    if (rc) return rc;
+    unsigned blocks = reduction_blocks(ctx, (n + HORNER_CHUNK - 1) / HORNER_CHUNK);
+    horner_kernel<<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_coeffs, n, to_arg(z), (fe*)ctx->d_scratch);
+    PK_LAUNCH_CHECK(ctx);
+    return finish_reduction<1>(ctx, blocks, out);
+}
+
+int pk_fold_coeffs(pk_ctx* ctx, const uint64_t* d_coeffs, unsigned n_vars, const uint64_t* r, unsigned k, uint64_t* d_out) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, d_coeffs && d_out && (k == 0 || r), "null pointer");
+    PK_REQUIRE(ctx, k <= 8 && k <= n_vars, "fold factor out of range");
+    fold_args ra{};
+    for (unsigned b = 0; b < k; b++) ra.r[b] = to_arg(r + 4 * b);
+    size_t n_out = (size_t)1 << (n_vars - k);
+    fold_coeffs_kernel<<<grid_for(ctx, n_out, 256), 256, 0, ctx->stream>>>((const fe*)d_coeffs, n_out, k, ra, (fe*)d_out);
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+int pk_fe_axpy(pk_ctx* ctx, uint64_t* d_y, const uint64_t* beta, const uint64_t* d_x, size_t n) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, beta && (n == 0 || (d_y && d_x)), "null pointer");
+    if (!n) return PK_OK;
+    axpy_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_y, (const fe*)d_x, n, to_arg(beta));
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,148 @@
+// pow.hip -- Skyscraper proof-of-work grinding.
+//
+// Replaces skyscraper::pow::{threshold, verify, solve} (skyscraper/core/src/pow.rs:14-41) and the
+// rayon::broadcast search of generic::solve (skyscraper/core/src/generic.rs:42-71) behind the
+// spongefish_pow::PowStrategy plug-in (provekit/common/src/skyscraper/pow.rs:14-30).
+// The reference returns *a* valid nonce that depends on thread timing; this grinder returns the
+// SMALLEST valid nonce (any valid nonce verifies; the smallest is reproducible): nonces are
+// searched in ascending windows, one compression per lane, device-wide atomicMin.
+#include <cmath>
+
+#include "ctx.hpp"
+#include "skyscraper.hpp"
+
+using namespace pk;
+
+namespace {
+
+struct fe_arg {
+    u32 v[8];
+};
+__device__ __forceinline__ fe from_arg(const fe_arg& a) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = a.v[i];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void pow_search_kernel(fe_arg challenge_arg, fe_arg threshold_arg, unsigned long long base,
+                                                         unsigned long long count, unsigned long long* best) {
+    const fe challenge = fe_reduce_any(from_arg(challenge_arg));  // generic.rs:81 reduce_partial on arbitrary input
+    const fe threshold = from_arg(threshold_arg);
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
+        unsigned long long nonce = base + t;
+        fe r = fe_zero();
+        r.v[0] = (u32)nonce;
+        r.v[1] = (u32)(nonce >> 32);
+        fe h = compress_reduced(challenge, r);
+        if (fe_lt(h, threshold)) atomicMin(best, nonce);
+    }
+}
+
+// skyscraper/core/src/pow.rs:44-82
+void f64_to_u256(double f, uint64_t out[4]) {
+    uint64_t bits;
+    memcpy(&bits, &f, 8);
+    bool sign = bits >> 63;
+    int exp_bits = (int)((bits >> 52) & 0x7ff);
+    uint64_t frac = bits & ((1ull << 52) - 1);
+    int exp = exp_bits == 0 ? -1022 : exp_bits - 1023;
+    uint64_t significand = exp_bits == 0 ? frac : frac + (1ull << 52);
+    memset(out, 0, 32);
+    if (sign) return;
+    if (exp > 256) {
+        memset(out, 0xff, 32);
+        return;
+    }
+    int shift = exp - 52;
+    if (shift < 0) {
+        double r = std::round(f);
+        out[0] = r >= 18446744073709551616.0 ? UINT64_MAX : (r > 0 ? (uint64_t)r : 0);
+    } else {
+        unsigned limb = (unsigned)shift / 64, sh = (unsigned)shift % 64;
+        if (limb > 3) return;
+        out[limb] = significand << sh;
+        if (sh != 0 && limb < 3) out[limb + 1] = significand >> (64 - sh);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// pow.rs:14-22
+int pk_pow_threshold(double difficulty, uint64_t out[4]) {
+    if (!out || !(difficulty >= 0.0 && difficulty < 80.0)) return PK_ERR_BAD_ARG;  // "Difficulty must be in the range [0, 80)"
+    const double modulus = (double)0x30644e72e131a029ull * std::ldexp(1.0, 192);
+    const double prob = std::exp2(-difficulty);
+    f64_to_u256(prob * modulus, out);
+    return PK_OK;
+}
+
+// PowStrategy::solve (provekit/common/src/skyscraper/pow.rs:27-29) -> pow::solve (pow.rs:33-41)
+int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t* nonce) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, challenge && nonce, "null pointer");
+    PK_REQUIRE(ctx, bits >= 0.0 && bits < 60.0, "bits must be smaller than 60");  // skyscraper/pow.rs:16
+    if (bits == 0.0) {  // pow.rs:34-36
+        *nonce = 0;
+        return PK_OK;
+    }
+    uint64_t thr[4];
+    int rc = pk_pow_threshold(bits + 0.01, thr);  // PROVER_BIAS, pow.rs:6,37
+    if (rc) return set_err(ctx, rc, "threshold");
+    rc = ensure_scratch(ctx, 64);
+    if (rc) return rc;
+    unsigned long long* d_best = (unsigned long long*)ctx->d_scratch;
+    fe_arg ch, th;
+    memcpy(ch.v, challenge, 32);
+    memcpy(th.v, thr, 32);
+    unsigned long long best = ~0ull, base = 0;
+    PK_HIP(ctx, hipMemcpyAsync(d_best, &best, 8, hipMemcpyHostToDevice, ctx->stream));
+    // window sized so the expected number of windows is ~1 up to ~24 bits, then grows
+    unsigned long long window = 1ull << 22;
+    const unsigned grid = (unsigned)ctx->num_cus * 16;
+    for (;;) {
+        pow_search_kernel<<<grid, 256, 0, ctx->stream>>>(ch, th, base, window, d_best);
+        PK_LAUNCH_CHECK(ctx);
+        PK_HIP(ctx, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
+        PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (best != ~0ull) break;
+        base += window;
+        if (window < (1ull << 28)) window <<= 1;
+        if (base > (1ull << 62)) return set_err(ctx, PK_ERR_BAD_ARG, "proof of work search exhausted");
+    }
+    *nonce = best;
+    return PK_OK;
+}
+
+// PowStrategy::check (skyscraper/pow.rs:23-25) -> pow::verify (pow.rs:24-26): NO prover bias
+int pk_pow_check(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t nonce, int* ok) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, challenge && ok, "null pointer");
+    PK_REQUIRE(ctx, bits >= 0.0 && bits < 60.0, "bits must be smaller than 60");
+    if (bits == 0.0) {
+        *ok = 1;
+        return PK_OK;
+    }
+    uint64_t thr[4];
+    int rc = pk_pow_threshold(bits, thr);
+    if (rc) return set_err(ctx, rc, "threshold");
+    rc = ensure_scratch(ctx, 64);
+    if (rc) return rc;
+    unsigned long long* d_best = (unsigned long long*)ctx->d_scratch;
+    unsigned long long best = ~0ull;
+    fe_arg ch, th;
+    memcpy(ch.v, challenge, 32);
+    memcpy(th.v, thr, 32);
+    PK_HIP(ctx, hipMemcpyAsync(d_best, &best, 8, hipMemcpyHostToDevice, ctx->stream));
+    pow_search_kernel<<<1, 64, 0, ctx->stream>>>(ch, th, nonce, 1, d_best);
+    PK_LAUNCH_CHECK(ctx);
+    PK_HIP(ctx, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *ok = best == nonce;
+    return PK_OK;
+}
+
+}  // extern "C"

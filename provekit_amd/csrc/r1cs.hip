@@ -1,0 +1,177 @@
+// r1cs.hip -- sparse R1CS matrix x vector products.
+//
+// Replaces HydratedSparseMatrix * &[FieldElement] and &[FieldElement] * HydratedSparseMatrix
+// (provekit/common/src/sparse_matrix.rs:150-184), which the reference runs serially per matrix
+// ("OPT: Paralelize").  The matrices are fixed per proof scheme, so the handle uploads them once
+// -- in the reference's own CSR form (new_row_indices / col_indices / interned value indices,
+// sparse_matrix.rs:12-27) plus a CSC copy built here -- and both products become atomic-free
+// gathers: one lane per output row (A*z) or per output column (eq^T * A).
+#include <vector>
+
+#include "ctx.hpp"
+#include "fe.hpp"
+
+using namespace pk;
+
+struct pk_r1cs {
+    size_t num_constraints = 0, num_witnesses = 0, n_interned = 0;
+    fe* d_interner = nullptr;
+    // per matrix: CSR (ptr has num_constraints+1 entries) and CSC (ptr has num_witnesses+1 entries)
+    uint32_t *csr_ptr[3] = {}, *csr_idx[3] = {}, *csr_val[3] = {};
+    uint32_t *csc_ptr[3] = {}, *csc_idx[3] = {}, *csc_val[3] = {};
+    size_t nnz[3] = {};
+};
+
+namespace {
+
+__device__ __forceinline__ fe sparse_row_dot(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ idx,
+                                             const uint32_t* __restrict__ val, const fe* __restrict__ interner,
+                                             const fe* __restrict__ x, size_t i) {
+    fe acc = fe_zero();
+    for (uint32_t k = ptr[i], e = ptr[i + 1]; k < e; k++) acc = fe_add(acc, fe_mul(fe_load(interner + val[k]), fe_load(x + idx[k])));
+    return acc;
+}
+
+// calculate_witness_bounds (provekit/common/src/utils/sumcheck.rs:181-193): a = A z, b = B z, c = a o b, zero-padded
+__global__ __launch_bounds__(256) void witness_bounds_kernel(const uint32_t* pa, const uint32_t* ia, const uint32_t* va, const uint32_t* pb,
+                                                             const uint32_t* ib, const uint32_t* vb, const fe* __restrict__ interner,
+                                                             const fe* __restrict__ z, size_t num_rows, size_t padded, fe* __restrict__ a,
+                                                             fe* __restrict__ b, fe* __restrict__ c) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= padded) return;
+    fe ra = fe_zero(), rb = fe_zero();
+    if (i < num_rows) {
+        ra = sparse_row_dot(pa, ia, va, interner, z, i);
+        rb = sparse_row_dot(pb, ib, vb, interner, z, i);
+    }
+    fe_store(a + i, ra);
+    fe_store(b + i, rb);
+    fe_store(c + i, fe_mul(ra, rb));
+}
+
+__global__ __launch_bounds__(256) void sparse_gather_kernel(const uint32_t* ptr, const uint32_t* idx, const uint32_t* val,
+                                                            const fe* __restrict__ interner, const fe* __restrict__ x, size_t n_out,
+                                                            fe* __restrict__ y) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    fe_store(y + i, sparse_row_dot(ptr, idx, val, interner, x, i));
+}
+
+int upload_u32(pk_ctx* ctx, const std::vector<uint32_t>& v, uint32_t** out) {
+    PK_HIP(ctx, hipMalloc((void**)out, (v.size() ? v.size() : 1) * 4));
+    if (!v.empty()) PK_HIP(ctx, hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    return PK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pk_r1cs_destroy(pk_ctx* ctx, pk_r1cs* r) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    if (!r) return PK_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(r->d_interner);
+    for (int m = 0; m < 3; m++) {
+        (void)hipFree(r->csr_ptr[m]); (void)hipFree(r->csr_idx[m]); (void)hipFree(r->csr_val[m]);
+        (void)hipFree(r->csc_ptr[m]); (void)hipFree(r->csc_idx[m]); (void)hipFree(r->csc_val[m]);
+    }
+    delete r;
+    return PK_OK;
+}
+
+int pk_r1cs_create(pk_ctx* ctx, size_t num_constraints, size_t num_witnesses, const pk_sparse_matrix mats[3],
+                   const uint64_t* interner, size_t n_interned, pk_r1cs** out) {
+    if (!ctx || !out) return PK_ERR_BAD_ARG;
+    *out = nullptr;
+    PK_REQUIRE(ctx, mats && (interner || n_interned == 0), "null pointer");
+    PK_REQUIRE(ctx, num_constraints < (1ull << 32) && num_witnesses < (1ull << 32), "dimension above u32");
+    pk_r1cs* r = new (std::nothrow) pk_r1cs();
+    if (!r) return PK_ERR_OOM;
+    r->num_constraints = num_constraints;
+    r->num_witnesses = num_witnesses;
+    r->n_interned = n_interned;
+    int rc = PK_OK;
+    auto fail = [&](int code) {
+        pk_r1cs_destroy(ctx, r);
+        return code;
+    };
+    if (hipMalloc((void**)&r->d_interner, (n_interned ? n_interned : 1) * 32) != hipSuccess) return fail(set_err(ctx, PK_ERR_OOM, "hipMalloc interner"));
+    if (n_interned && hipMemcpy(r->d_interner, interner, n_interned * 32, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(set_err(ctx, PK_ERR_HIP, "interner upload"));
+    for (int m = 0; m < 3; m++) {
+        const pk_sparse_matrix& M = mats[m];
+        const size_t nnz = M.nnz;
+        if (nnz >= (1ull << 32)) return fail(set_err(ctx, PK_ERR_BAD_ARG, "nnz above u32"));
+        if (nnz && (!M.col_indices || !M.values)) return fail(set_err(ctx, PK_ERR_BAD_ARG, "null matrix arrays"));
+        if (num_constraints && !M.new_row_indices) return fail(set_err(ctx, PK_ERR_BAD_ARG, "null new_row_indices"));
+        r->nnz[m] = nnz;
+        // CSR pointer array with the closing entry (sparse_matrix.rs:113-123 row_range)
+        std::vector<uint32_t> rp(num_constraints + 1);
+        for (size_t i = 0; i < num_constraints; i++) rp[i] = M.new_row_indices[i];
+        rp[num_constraints] = (uint32_t)nnz;
+        for (size_t i = 0; i < num_constraints; i++)
+            if (rp[i] > rp[i + 1] || rp[i + 1] > nnz) return fail(set_err(ctx, PK_ERR_BAD_ARG, "new_row_indices not monotone"));
+        std::vector<uint32_t> ci(M.col_indices, M.col_indices + nnz), vv(M.values, M.values + nnz);
+        for (size_t k = 0; k < nnz; k++) {
+            if (ci[k] >= num_witnesses) return fail(set_err(ctx, PK_ERR_BAD_ARG, "column index out of bounds"));
+            if (vv[k] >= n_interned) return fail(set_err(ctx, PK_ERR_BAD_ARG, "Value not in interner."));  // sparse_matrix.rs:133
+        }
+        // CSC by counting sort (stable: rows ascending within a column)
+        std::vector<uint32_t> cp(num_witnesses + 1, 0), ri(nnz), cv(nnz);
+        for (size_t k = 0; k < nnz; k++) cp[ci[k] + 1]++;
+        for (size_t j = 0; j < num_witnesses; j++) cp[j + 1] += cp[j];
+        std::vector<uint32_t> cur(cp.begin(), cp.end() - 1);
+        for (size_t i = 0; i < num_constraints; i++)
+            for (uint32_t k = rp[i]; k < rp[i + 1]; k++) {
+                uint32_t pos = cur[ci[k]]++;
+                ri[pos] = (uint32_t)i;
+                cv[pos] = vv[k];
+            }
+        if ((rc = upload_u32(ctx, rp, &r->csr_ptr[m])) || (rc = upload_u32(ctx, ci, &r->csr_idx[m])) || (rc = upload_u32(ctx, vv, &r->csr_val[m])) ||
+            (rc = upload_u32(ctx, cp, &r->csc_ptr[m])) || (rc = upload_u32(ctx, ri, &r->csc_idx[m])) || (rc = upload_u32(ctx, cv, &r->csc_val[m])))
+            return fail(rc);
+    }
+    *out = r;
+    return PK_OK;
+}
+
+int pk_r1cs_witness_bounds(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, unsigned m0, uint64_t* d_a, uint64_t* d_b,
+                           uint64_t* d_c) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, r && d_z && d_a && d_b && d_c, "null pointer");
+    PK_REQUIRE(ctx, m0 <= 30 && r->num_constraints <= ((size_t)1 << m0), "R1CS constraints exceed scheme capacity");  // whir_r1cs.rs:52-54
+    size_t padded = (size_t)1 << m0;
+    witness_bounds_kernel<<<(unsigned)((padded + 255) / 256), 256, 0, ctx->stream>>>(
+        r->csr_ptr[0], r->csr_idx[0], r->csr_val[0], r->csr_ptr[1], r->csr_idx[1], r->csr_val[1], r->d_interner, (const fe*)d_z,
+        r->num_constraints, padded, (fe*)d_a, (fe*)d_b, (fe*)d_c);
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+int pk_r1cs_matvec(pk_ctx* ctx, const pk_r1cs* r, int matrix, int transpose, const uint64_t* d_x, uint64_t* d_y) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, r && d_x && d_y, "null pointer");
+    PK_REQUIRE(ctx, matrix >= 0 && matrix < 3, "matrix must be 0 (A), 1 (B) or 2 (C)");
+    size_t n_out = transpose ? r->num_witnesses : r->num_constraints;
+    if (!n_out) return PK_OK;
+    const uint32_t* ptr = transpose ? r->csc_ptr[matrix] : r->csr_ptr[matrix];
+    const uint32_t* idx = transpose ? r->csc_idx[matrix] : r->csr_idx[matrix];
+    const uint32_t* val = transpose ? r->csc_val[matrix] : r->csr_val[matrix];
+    sparse_gather_kernel<<<(unsigned)((n_out + 255) / 256), 256, 0, ctx->stream>>>(ptr, idx, val, r->d_interner, (const fe*)d_x, n_out, (fe*)d_y);
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+// calculate_external_row_of_r1cs_matrices (sumcheck.rs:207-218): [eq^T A, eq^T B, eq^T C], each num_witnesses long
+int pk_r1cs_external_row(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_eq_alpha, uint64_t* d_out) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, r && d_eq_alpha && d_out, "null pointer");
+    for (int m = 0; m < 3; m++) {
+        int rc = pk_r1cs_matvec(ctx, r, m, 1, d_eq_alpha, d_out + 4 * (size_t)m * r->num_witnesses);
+        if (rc) return rc;
+    }
+    return PK_OK;
+}
+
+}  // extern "C"

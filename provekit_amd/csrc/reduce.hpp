@@ -1,0 +1,81 @@
+// reduce.hpp -- block / grid reduction of field-element sums (used by sumcheck, dot, Horner).
+#pragma once
+#include "ctx.hpp"
+#include "fe.hpp"
+
+namespace pk {
+
+constexpr int RED_THREADS = 256;
+constexpr int RED_MAX_BLOCKS = 1024;
+
+// Sum K field elements per thread across the block; result valid in thread 0.
+// smem must hold K * RED_THREADS fe (as 2 uint4 each).
+template <int K>
+__device__ __forceinline__ void block_reduce_fe(fe (&acc)[K], uint4* smem) {
+    const unsigned tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        smem[(k * RED_THREADS + tid) * 2] = make_uint4(acc[k].v[0], acc[k].v[1], acc[k].v[2], acc[k].v[3]);
+        smem[(k * RED_THREADS + tid) * 2 + 1] = make_uint4(acc[k].v[4], acc[k].v[5], acc[k].v[6], acc[k].v[7]);
+    }
+    __syncthreads();
+    for (unsigned s = RED_THREADS / 2; s >= 1; s >>= 1) {
+        if (tid < s) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                uint4 l = smem[(k * RED_THREADS + tid + s) * 2], h = smem[(k * RED_THREADS + tid + s) * 2 + 1];
+                fe o;
+                o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w;
+                o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w;
+                acc[k] = fe_add(acc[k], o);
+                smem[(k * RED_THREADS + tid) * 2] = make_uint4(acc[k].v[0], acc[k].v[1], acc[k].v[2], acc[k].v[3]);
+                smem[(k * RED_THREADS + tid) * 2 + 1] = make_uint4(acc[k].v[4], acc[k].v[5], acc[k].v[6], acc[k].v[7]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// second stage: sum `nblocks` partial K-vectors (layout partials[block*K + k]) into out[k]
+template <int K>
+__global__ __launch_bounds__(RED_THREADS) void reduce_partials_kernel(const fe* __restrict__ partials, unsigned nblocks,
+                                                                      fe* __restrict__ out) {
+    __shared__ uint4 smem[K * RED_THREADS * 2];
+    fe acc[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) acc[k] = fe_zero();
+    for (unsigned b = threadIdx.x; b < nblocks; b += RED_THREADS) {
+#pragma unroll
+        for (int k = 0; k < K; k++) acc[k] = fe_add(acc[k], fe_load(partials + (size_t)b * K + k));
+    }
+    block_reduce_fe<K>(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) fe_store(out + k, acc[k]);
+    }
+}
+
+// host helper: finish a K-vector reduction whose per-block partials sit at ctx->d_scratch[0 .. nblocks*K)
+// and copy the K results to `host_out` (synchronises the stream).
+template <int K>
+inline int finish_reduction(pk_ctx* ctx, unsigned nblocks, uint64_t* host_out) {
+    fe* partials = (fe*)ctx->d_scratch;
+    fe* result = partials + (size_t)RED_MAX_BLOCKS * 8;
+    reduce_partials_kernel<K><<<1, RED_THREADS, 0, ctx->stream>>>(partials, nblocks, result);
+    PK_LAUNCH_CHECK(ctx);
+    PK_HIP(ctx, hipMemcpyAsync(host_out, result, 32 * K, hipMemcpyDeviceToHost, ctx->stream));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PK_OK;
+}
+
+inline int reduction_scratch(pk_ctx* ctx) { return ensure_scratch(ctx, (size_t)RED_MAX_BLOCKS * 8 * 32 + 8 * 32 + 4096); }
+
+inline unsigned reduction_blocks(const pk_ctx* ctx, size_t work_items) {
+    size_t need = (work_items + RED_THREADS - 1) / RED_THREADS;
+    size_t cap = (size_t)ctx->num_cus * 4;
+    if (cap > RED_MAX_BLOCKS) cap = RED_MAX_BLOCKS;
+    if (need < 1) need = 1;
+    return (unsigned)(need < cap ? need : cap);
+}
+
+}  // namespace pk

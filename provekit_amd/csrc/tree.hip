@@ -1,0 +1,212 @@
+// tree.hip -- commitment handle: RS-encode + Merkle commit, and STIR openings (SURVEY 8a rows N1+N2+M1+M2, Q1).
+//
+// pk_commit replaces the data-parallel body of whir's CommitmentWriter::commit_batch
+// (call site provekit/prover/src/whir_r1cs.rs:200-206): encode the batch, hash the leaves, build the
+// tree, hand back the root.  The codeword matrix (column-major) and every tree level stay resident
+// in HBM behind the pk_tree handle because STIR queries open them later (rows Q1); at P size that is
+// 256 MiB + 16 MiB, at 2^26 it is 8.5 GiB -- far inside 288 GB, so nothing is recomputed or spilled.
+//
+// pk_tree_open replaces MerkleTree::generate_multi_proof + the leaf gather (ark-crypto-primitives
+// 0.5, external); pk_multipath_serialize writes ark's MultiPath wire form (mirrored at
+// recursive-verifier/app/circuit/types.go:17-22, decoded by utilities.go:71-82).
+#include <algorithm>
+#include <vector>
+
+#include "ctx.hpp"
+#include "fe.hpp"
+
+using namespace pk;
+
+struct pk_tree {
+    fe* d_leaves = nullptr;  // column-major [width][n_leaves], Montgomery; owned unless borrowed
+    fe* d_nodes = nullptr;   // heap of 2*n_leaves canonical digests
+    size_t n_leaves = 0, width = 0;
+    bool owns_leaves = true;
+    int layout = PK_COL_MAJOR;
+};
+
+namespace {
+
+// gather k opened leaves to leaf-major order; optionally convert to canonical (ark-serialize form)
+__global__ __launch_bounds__(256) void gather_leaves_kernel(const fe* __restrict__ leaves, size_t n_leaves, unsigned width, int layout,
+                                                            const unsigned long long* __restrict__ idx, size_t k, int canonical,
+                                                            fe* __restrict__ out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k * width) return;
+    size_t q = t / width, j = t % width;
+    size_t i = idx[q];
+    fe x = fe_load(leaves + (layout == PK_COL_MAJOR ? j * n_leaves + i : i * (size_t)width + j));
+    fe_store(out + t, canonical ? fe_from_mont(x) : x);
+}
+// sibling digests: out_sib[q] = nodes[(n+i)^1]; out_path[q][d-1] = sibling of the depth-d ancestor, d = 1..logn-1 (root -> leaf)
+__global__ __launch_bounds__(256) void gather_paths_kernel(const fe* __restrict__ nodes, size_t n_leaves, unsigned logn,
+                                                           const unsigned long long* __restrict__ idx, size_t k, fe* __restrict__ out_sib,
+                                                           fe* __restrict__ out_path) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned plen = logn ? logn - 1 : 0;
+    if (t >= k * (size_t)(plen + 1)) return;
+    size_t q = t / (plen + 1), d = t % (plen + 1);
+    size_t node = n_leaves + idx[q];
+    if (d == plen) {
+        if (logn) fe_store(out_sib + q, fe_load(nodes + (node ^ 1)));
+    } else {
+        size_t anc = node >> (logn - (d + 1));
+        fe_store(out_path + q * plen + d, fe_load(nodes + (anc ^ 1)));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pk_tree_destroy(pk_ctx* ctx, pk_tree* t) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    if (!t) return PK_OK;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (t->owns_leaves) (void)hipFree(t->d_leaves);
+    (void)hipFree(t->d_nodes);
+    delete t;
+    return PK_OK;
+}
+
+int pk_commit(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
+              uint8_t root_out[32], pk_tree** out) {
+    if (!ctx || !out) return PK_ERR_BAD_ARG;
+    *out = nullptr;
+    PK_REQUIRE(ctx, d_coeffs, "null pointer");
+    PK_REQUIRE(ctx, batch >= 1 && batch <= 16, "batch out of range");
+    PK_REQUIRE(ctx, fold <= n_vars && fold <= 8, "fold out of range");
+    PK_REQUIRE(ctx, n_vars + log_inv_rate - fold <= 27, "domain too large (two-adicity 28)");
+    const size_t rows = (size_t)1 << (n_vars + log_inv_rate - fold);
+    const size_t width = (size_t)batch << fold;
+    pk_tree* t = new (std::nothrow) pk_tree();
+    if (!t) return PK_ERR_OOM;
+    t->n_leaves = rows;
+    t->width = width;
+    int rc = PK_OK;
+    if (hipMalloc((void**)&t->d_leaves, rows * width * 32) != hipSuccess || hipMalloc((void**)&t->d_nodes, 2 * rows * 32) != hipSuccess) {
+        pk_tree_destroy(ctx, t);
+        return set_err(ctx, PK_ERR_OOM, "hipMalloc of the codeword matrix failed");
+    }
+    rc = ensure_ws(ctx, 2 * rows * width * 32);
+    if (!rc) rc = pk_rs_encode(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, (uint64_t*)t->d_leaves, (uint64_t*)ctx->d_ws);
+    if (!rc) rc = pk_merkle_commit(ctx, (const uint64_t*)t->d_leaves, rows, width, PK_COL_MAJOR, (uint64_t*)t->d_nodes);
+    if (!rc && root_out) rc = pk_memcpy_d2h(ctx, root_out, t->d_nodes + 1, 32);
+    if (rc) {
+        pk_tree_destroy(ctx, t);
+        return rc;
+    }
+    *out = t;
+    return PK_OK;
+}
+
+// MerkleTree::new over leaves the caller already holds on the device (borrowed, not copied)
+int pk_tree_from_leaves(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, uint8_t root_out[32],
+                        pk_tree** out) {
+    if (!ctx || !out) return PK_ERR_BAD_ARG;
+    *out = nullptr;
+    PK_REQUIRE(ctx, d_leaves, "null pointer");
+    PK_REQUIRE(ctx, is_pow2(n_leaves), "n_leaves must be a power of two");
+    pk_tree* t = new (std::nothrow) pk_tree();
+    if (!t) return PK_ERR_OOM;
+    t->n_leaves = n_leaves;
+    t->width = width;
+    t->owns_leaves = false;
+    t->layout = layout;
+    t->d_leaves = (fe*)d_leaves;
+    if (hipMalloc((void**)&t->d_nodes, 2 * n_leaves * 32) != hipSuccess) {
+        delete t;
+        return set_err(ctx, PK_ERR_OOM, "hipMalloc of the tree failed");
+    }
+    int rc = pk_merkle_commit(ctx, d_leaves, n_leaves, width, layout, (uint64_t*)t->d_nodes);
+    if (!rc && root_out) rc = pk_memcpy_d2h(ctx, root_out, t->d_nodes + 1, 32);
+    if (rc) {
+        pk_tree_destroy(ctx, t);
+        return rc;
+    }
+    *out = t;
+    return PK_OK;
+}
+
+int pk_tree_info(const pk_tree* t, size_t* n_leaves, size_t* width, const uint64_t** d_leaves, const uint64_t** d_nodes) {
+    if (!t) return PK_ERR_BAD_ARG;
+    if (n_leaves) *n_leaves = t->n_leaves;
+    if (width) *width = t->width;
+    if (d_leaves) *d_leaves = (const uint64_t*)t->d_leaves;
+    if (d_nodes) *d_nodes = (const uint64_t*)t->d_nodes;
+    return PK_OK;
+}
+
+int pk_tree_root(pk_ctx* ctx, const pk_tree* t, uint8_t root[32]) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, t && root, "null pointer");
+    return pk_memcpy_d2h(ctx, root, t->d_nodes + 1, 32);
+}
+
+int pk_tree_open(pk_ctx* ctx, const pk_tree* t, const uint64_t* indices, size_t k, int canonical_leaves, uint64_t* leaves_out,
+                 uint64_t* sibling_digests, uint64_t* auth_paths) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, t && (k == 0 || (indices && leaves_out && sibling_digests)), "null pointer");
+    if (!k) return PK_OK;
+    const unsigned logn = ilog2(t->n_leaves);
+    const unsigned plen = logn ? logn - 1 : 0;
+    PK_REQUIRE(ctx, plen == 0 || auth_paths, "null pointer");
+    for (size_t q = 0; q < k; q++) PK_REQUIRE(ctx, indices[q] < t->n_leaves, "leaf index out of range");
+    const size_t idx_bytes = ((k * 8 + 31) / 32) * 32;
+    int rc = ensure_ws(ctx, idx_bytes + 32 * (k * t->width + k + k * plen));
+    if (rc) return rc;
+    unsigned long long* d_idx = (unsigned long long*)ctx->d_ws;
+    fe* d_leaves_out = (fe*)((char*)ctx->d_ws + idx_bytes);
+    fe* d_sib = d_leaves_out + k * t->width;
+    fe* d_path = d_sib + k;
+    PK_HIP(ctx, hipMemcpyAsync(d_idx, indices, k * 8, hipMemcpyHostToDevice, ctx->stream));
+    size_t n1 = k * t->width, n2 = k * (size_t)(plen + 1);
+    gather_leaves_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, ctx->stream>>>(t->d_leaves, t->n_leaves, (unsigned)t->width, t->layout, d_idx, k,
+                                                                              canonical_leaves, d_leaves_out);
+    gather_paths_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, ctx->stream>>>(t->d_nodes, t->n_leaves, logn, d_idx, k, d_sib, d_path);
+    PK_LAUNCH_CHECK(ctx);
+    PK_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves_out, 32 * n1, hipMemcpyDeviceToHost, ctx->stream));
+    if (logn) PK_HIP(ctx, hipMemcpyAsync(sibling_digests, d_sib, 32 * k, hipMemcpyDeviceToHost, ctx->stream));
+    if (plen) PK_HIP(ctx, hipMemcpyAsync(auth_paths, d_path, 32 * k * plen, hipMemcpyDeviceToHost, ctx->stream));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PK_OK;
+}
+
+// ark MultiPath, uncompressed ark-serialize: Vec<T> = u64 length + items; digests = 32 B canonical LE.
+// Fields in order: leaf_siblings_hashes, auth_paths_prefix_lenghts, auth_paths_suffixes, leaf_indexes.
+// `indices` must be sorted ascending and unique (whir sorts+dedups STIR queries); paths are root->leaf.
+int pk_multipath_serialize(const uint64_t* indices, size_t k, size_t path_len, const uint64_t* sibling_digests,
+                           const uint64_t* auth_paths, uint8_t* out, size_t out_cap, size_t* out_len) {
+    if (!out_len || (k && (!indices || !sibling_digests || (path_len && !auth_paths)))) return PK_ERR_BAD_ARG;
+    std::vector<uint8_t> buf;
+    auto put_u64 = [&](uint64_t v) {
+        for (int i = 0; i < 8; i++) buf.push_back((uint8_t)(v >> (8 * i)));
+    };
+    auto put_fe = [&](const uint64_t* p) {
+        const uint8_t* b = (const uint8_t*)p;
+        buf.insert(buf.end(), b, b + 32);
+    };
+    put_u64(k);
+    for (size_t q = 0; q < k; q++) put_fe(sibling_digests + 4 * q);
+    std::vector<size_t> prefix(k, 0);
+    for (size_t q = 1; q < k; q++) {
+        size_t c = 0;
+        while (c < path_len && memcmp(auth_paths + 4 * (q * path_len + c), auth_paths + 4 * ((q - 1) * path_len + c), 32) == 0) c++;
+        prefix[q] = c;
+    }
+    put_u64(k);
+    for (size_t q = 0; q < k; q++) put_u64(prefix[q]);
+    put_u64(k);
+    for (size_t q = 0; q < k; q++) {
+        put_u64(path_len - prefix[q]);
+        for (size_t c = prefix[q]; c < path_len; c++) put_fe(auth_paths + 4 * (q * path_len + c));
+    }
+    put_u64(k);
+    for (size_t q = 0; q < k; q++) put_u64(indices[q]);
+    *out_len = buf.size();
+    if (!out || out_cap < buf.size()) return out ? PK_ERR_BAD_ARG : PK_OK;  // out == NULL: size query
+    memcpy(out, buf.data(), buf.size());
+    return PK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,162 @@
+"""GPU parity: sparse R1CS products (S1, S4), proof of work (P1), commitment handle + openings (N1+N2+M1+M2, Q1)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def synth_r1cs(num_constraints, num_witnesses, seed, nnz_per_row=3, n_interned=17):
+    """R1CS-shaped sparse matrices: ~3 entries per row, sorted unique columns, interned small coefficients,
+    some empty rows."""
+    from provekit_amd.sparse_matrix import SparseMatrix
+
+    rng = np.random.default_rng(seed)
+    mats = []
+    for _ in range(3):
+        nri, ci, vv = [], [], []
+        for i in range(num_constraints):
+            nri.append(len(ci))
+            k = 0 if rng.random() < 0.05 else int(rng.integers(1, 2 * nnz_per_row))
+            cols = np.sort(rng.choice(num_witnesses, size=min(k, num_witnesses), replace=False))
+            ci += cols.tolist()
+            vv += rng.integers(0, n_interned, size=len(cols)).tolist()
+        mats.append(SparseMatrix(num_constraints, num_witnesses, np.array(nri, np.uint32), np.array(ci, np.uint32), np.array(vv, np.uint32)))
+    return mats
+
+
+@pytest.mark.parametrize("nc,nw", [(1, 1), (37, 50), (1000, 777), (5000, 4096)])
+def test_r1cs_products(ctx, oracle, nc, nw):
+    from provekit_amd.field import random_field
+    from provekit_amd.sparse_matrix import R1CS
+
+    a, b, c = synth_r1cs(nc, nw, nc + nw)
+    interner = random_field(17, 5)
+    interner[0] = oracle.to_mont(oracle.ints_to_limbs([1]))[0]
+    r = R1CS(ctx, a, b, c, interner)
+    z = random_field(nw, 9)
+    m0 = max((nc - 1).bit_length(), 1)
+    da, db, dc = r.calculate_witness_bounds(ctx.upload(z), m0)
+    ea = oracle.spmv(nc, nw, a.new_row_indices, a.col_indices, a.values, interner, z)
+    eb = oracle.spmv(nc, nw, b.new_row_indices, b.col_indices, b.values, interner, z)
+    pad = (1 << m0) - nc
+    zpad = np.zeros((pad, 4), np.uint64)
+    assert np.array_equal(ctx.download_fe(da, 1 << m0), np.concatenate([ea, zpad]))
+    assert np.array_equal(ctx.download_fe(db, 1 << m0), np.concatenate([eb, zpad]))
+    assert np.array_equal(ctx.download_fe(dc, 1 << m0), np.concatenate([oracle.hadamard(ea, eb), zpad]))
+    eq = random_field(1 << m0, 10)
+    out = ctx.download_fe(r.calculate_external_row_of_r1cs_matrices(ctx.upload(eq)), 3 * nw).reshape(3, nw, 4)
+    for k, m in enumerate((a, b, c)):
+        exp = oracle.spmv(nc, nw, m.new_row_indices, m.col_indices, m.values, interner, eq[:nc], transpose=True)
+        assert np.array_equal(out[k], exp)
+    r.close()
+
+
+def test_r1cs_rejects_bad_input(ctx):
+    from provekit_amd import ProveKitHipError
+    from provekit_amd.field import random_field
+    from provekit_amd.sparse_matrix import R1CS, SparseMatrix
+
+    good = SparseMatrix(2, 2, np.array([0, 1], np.uint32), np.array([0, 1], np.uint32), np.array([0, 0], np.uint32))
+    bad_col = SparseMatrix(2, 2, np.array([0, 1], np.uint32), np.array([0, 5], np.uint32), np.array([0, 0], np.uint32))
+    bad_val = SparseMatrix(2, 2, np.array([0, 1], np.uint32), np.array([0, 1], np.uint32), np.array([0, 9], np.uint32))
+    it = random_field(2, 1)
+    with pytest.raises(ProveKitHipError):
+        R1CS(ctx, good, bad_col, good, it)
+    with pytest.raises(ProveKitHipError):  # "Value not in interner."
+        R1CS(ctx, good, good, bad_val, it)
+
+
+@pytest.mark.parametrize("bits", [0.0, 3.141592653589793, 10.0, 16.0, 20.0])
+def test_pow_solve_check(ctx, oracle, bits):
+    """pow.rs:105-112 round trip; the GPU returns the smallest valid nonce == the oracle's sequential search"""
+    from provekit_amd.pow import SkyscraperPoW
+
+    for challenge in (b"\xff" * 32, bytes(range(32))):
+        p = SkyscraperPoW(challenge, bits, ctx=ctx)
+        nonce = p.solve()
+        assert p.check(nonce)
+        ch = np.frombuffer(challenge, dtype=np.uint64)
+        assert oracle.pow_verify(ch, bits, nonce)
+        if bits <= 16.0:
+            assert nonce == oracle.pow_solve(ch, bits)
+        if bits > 0:
+            assert not p.check(nonce + 1) or oracle.pow_verify(ch, bits, nonce + 1)
+    with pytest.raises(ValueError):
+        SkyscraperPoW(b"\0" * 32, 60.0, ctx=ctx)
+
+
+@pytest.mark.parametrize("batch,n_vars", [(2, 8), (2, 13), (1, 12), (2, 16)])
+def test_commit_root_and_openings(ctx, oracle, batch, n_vars):
+    from provekit_amd.field import random_field
+    from provekit_amd.whir import commit_batch, multipath_serialize
+
+    polys = [random_field(1 << n_vars, 50 + b + n_vars) for b in range(batch)]
+    c = commit_batch(ctx, [ctx.upload(p) for p in polys], n_vars, 1, 4)
+    leaves = oracle.rs_encode(np.concatenate(polys), batch, n_vars, 1, 4)
+    nodes = oracle.merkle_commit(leaves)
+    n = leaves.shape[0]
+    assert int.from_bytes(c.root, "little") == oracle.limbs_to_ints(nodes[1])[0]
+    rng = np.random.default_rng(n_vars)
+    idx = np.unique(rng.integers(0, n, size=min(40, n)))
+    lv, sib, paths = c.open(idx, canonical_leaves=True)
+    assert np.array_equal(lv, np.stack([oracle.from_mont(leaves[i]) for i in idx]))
+    lv_m, _, _ = c.open(idx, canonical_leaves=False)
+    assert np.array_equal(lv_m, leaves[idx])
+    logn = n.bit_length() - 1
+    for q, i in enumerate(idx):
+        assert np.array_equal(sib[q], nodes[(n + i) ^ 1])
+        for d in range(1, logn):
+            anc = (n + i) >> (logn - d)
+            assert np.array_equal(paths[q, d - 1], nodes[anc ^ 1])
+    # every opening verifies against the root with the verifier's own recurrence (whir_utilities.go:13-46)
+    for q, i in enumerate(idx[:5]):
+        h = oracle.leaf_hash(leaves[i][None])[0]
+        chain = [sib[q]] + [paths[q, d] for d in range(logn - 2, -1, -1)]
+        j = int(i)
+        for s in chain:
+            m = np.concatenate([s, h] if j & 1 else [h, s]).astype("<u8").tobytes()
+            h = np.frombuffer(oracle.compress_many(m), dtype=np.uint64)
+            j >>= 1
+        assert h.tobytes() == c.root
+    blob = multipath_serialize(idx, sib, paths)
+    assert len(blob) > 32 * len(idx)
+    c.close()
+
+
+def test_commit_full_size(ctx, oracle):
+    """BASELINE config 2 commit (batch 2, n=21, rate 1/2, fold 16 -> 2^18 leaves x 32): root is reproducible, the
+    opened leaves are codeword symbols (direct evaluation in the oracle), and the paths chain to the root."""
+    from provekit_amd.field import random_field
+    from provekit_amd.whir import commit_batch
+
+    n_vars = 21
+    polys = [random_field(1 << n_vars, 60 + b) for b in range(2)]
+    bufs = [ctx.upload(p) for p in polys]
+    c = commit_batch(ctx, bufs, n_vars)
+    c2 = commit_batch(ctx, bufs, n_vars)
+    assert c.root == c2.root
+    c2.close()
+    n = c.n_leaves
+    assert n == 1 << 18 and c.width == 32
+    idx = np.array([0, 1, 77777, n - 1], dtype=np.uint64)
+    lv, sib, paths = c.open(idx, canonical_leaves=False)
+    wroot = oracle.root_of_unity(18)
+    for q, i in enumerate(idx):
+        pw = np.empty(4, dtype=np.uint64)
+        oracle.L.pko_fe_pow(oracle._p(wroot), int(i), oracle._p(pw))
+        for b in range(2):
+            for j in (0, 9, 15):
+                assert np.array_equal(lv[q, 16 * b + j], oracle.eval_univariate(np.ascontiguousarray(polys[b][j::16]), pw))
+        h = oracle.leaf_hash(lv[q][None])[0]
+        chain = [sib[q]] + [paths[q, d] for d in range(16, -1, -1)]
+        k = int(i)
+        for s in chain:
+            m = np.concatenate([s, h] if k & 1 else [h, s]).astype("<u8").tobytes()
+            h = np.frombuffer(oracle.compress_many(m), dtype=np.uint64)
+            k >>= 1
+        assert h.tobytes() == c.root
+    c.close()
