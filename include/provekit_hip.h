@@ -76,6 +76,14 @@ int pk_memset_zero(pk_ctx *ctx, void *d_dst, size_t bytes);
 /* hipEvent pair on the ctx stream: elapsed ms between start and stop (stop synchronises) */
 int pk_timer_start(pk_ctx *ctx);
 int pk_timer_stop(pk_ctx *ctx, float *ms);
+/* Per-kernel timing (the CLI's SpanStats layer of the reference, tooling/cli/src/span_stats.rs, scaled to the
+ * device side): when enabled every major kernel launch is bracketed by a hipEvent pair on the work stream.
+ * pk_profile_read sums launches / milliseconds for one kernel name ("leaf_hash", "ntt_pass", "ntt_pass_last",
+ * "merkle_inner", "sumcheck_cubic", ...); pk_profile_names lists the names seen (comma-separated). */
+int pk_profile_enable(pk_ctx *ctx, int on);
+int pk_profile_reset(pk_ctx *ctx);
+int pk_profile_read(pk_ctx *ctx, const char *name, uint64_t *launches, double *total_ms);
+int pk_profile_names(pk_ctx *ctx, char *buf, size_t cap);
 
 /* ------------------------------------------------------------------ A1/A2: field arithmetic
  * ark-ff Fp256 (+,-,*) and block_multiplier::scalar_mul

@@ -59,6 +59,10 @@ SIGNATURES = {
     "pk_memset_zero": (C.c_int, [vp, vp, sz]),
     "pk_timer_start": (C.c_int, [vp]),
     "pk_timer_stop": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "pk_profile_enable": (C.c_int, [vp, C.c_int]),
+    "pk_profile_reset": (C.c_int, [vp]),
+    "pk_profile_read": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+    "pk_profile_names": (C.c_int, [vp, C.c_char_p, sz]),
     "pk_fe_add": (C.c_int, [vp, vp, vp, vp, sz]),
     "pk_fe_sub": (C.c_int, [vp, vp, vp, vp, sz]),
     "pk_fe_mul": (C.c_int, [vp, vp, vp, vp, sz]),

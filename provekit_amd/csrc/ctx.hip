@@ -51,6 +51,11 @@ int pk_ctx_destroy(pk_ctx* ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    for (auto& r : ctx->prof) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -133,6 +138,51 @@ int pk_timer_stop(pk_ctx* ctx, float* ms) {
     PK_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     PK_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
     PK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
+    return PK_OK;
+}
+
+int pk_profile_enable(pk_ctx* ctx, int on) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    ctx->prof_on = on != 0;
+    return PK_OK;
+}
+int pk_profile_reset(pk_ctx* ctx) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& r : ctx->prof) {
+        ctx->ev_pool.push_back(r.e0);
+        ctx->ev_pool.push_back(r.e1);
+    }
+    ctx->prof.clear();
+    return PK_OK;
+}
+int pk_profile_read(pk_ctx* ctx, const char* name, uint64_t* launches, double* total_ms) {
+    if (!ctx || !name || !launches || !total_ms) return PK_ERR_BAD_ARG;
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *launches = 0;
+    *total_ms = 0.0;
+    for (auto& r : ctx->prof) {
+        if (strcmp(r.name, name) != 0) continue;
+        float ms = 0.f;
+        PK_HIP(ctx, hipEventElapsedTime(&ms, r.e0, r.e1));
+        *launches += 1;
+        *total_ms += ms;
+    }
+    return PK_OK;
+}
+int pk_profile_names(pk_ctx* ctx, char* buf, size_t cap) {
+    if (!ctx || !buf || !cap) return PK_ERR_BAD_ARG;
+    std::string s;
+    std::vector<const char*> seen;
+    for (auto& r : ctx->prof) {
+        bool dup = false;
+        for (auto p : seen) dup |= strcmp(p, r.name) == 0;
+        if (dup) continue;
+        seen.push_back(r.name);
+        if (!s.empty()) s += ",";
+        s += r.name;
+    }
+    snprintf(buf, cap, "%s", s.c_str());
     return PK_OK;
 }
 

@@ -6,11 +6,21 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/provekit_hip.h"
 
+struct pk_prof_rec {
+    const char* name;
+    hipEvent_t e0, e1;
+};
+
 struct pk_ctx {
     int device = 0;
+    // optional per-kernel timing (pk_profile_*): hipEvent pairs recorded on the work stream
+    bool prof_on = false;
+    std::vector<pk_prof_rec> prof;
+    std::vector<hipEvent_t> ev_pool;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;  // the stream work is enqueued on (own or borrowed)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -71,6 +81,30 @@ inline unsigned grid_for(const pk_ctx* ctx, size_t n, unsigned block, unsigned m
     if (need < 1) need = 1;
     return (unsigned)(need < cap ? need : cap);
 }
+
+// RAII bracket around a kernel launch (or a group of launches) for pk_profile_*; free when profiling is off
+struct ProfScope {
+    pk_ctx* c;
+    hipEvent_t e1 = nullptr;
+    ProfScope(pk_ctx* ctx, const char* name) : c(ctx) {
+        if (!c->prof_on) return;
+        hipEvent_t ev[2];
+        for (int i = 0; i < 2; i++) {
+            if (!c->ev_pool.empty()) {
+                ev[i] = c->ev_pool.back();
+                c->ev_pool.pop_back();
+            } else if (hipEventCreate(&ev[i]) != hipSuccess) {
+                return;
+            }
+        }
+        (void)hipEventRecord(ev[0], c->stream);
+        e1 = ev[1];
+        c->prof.push_back({name, ev[0], ev[1]});
+    }
+    ~ProfScope() {
+        if (e1) (void)hipEventRecord(e1, c->stream);
+    }
+};
 
 int ensure_scratch(pk_ctx* ctx, size_t bytes);
 int ensure_ws(pk_ctx* ctx, size_t bytes);

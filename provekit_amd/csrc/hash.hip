@@ -68,6 +68,7 @@ __global__ __launch_bounds__(512) void merkle_top_kernel(fe* __restrict__ nodes,
 }
 
 static int leaf_hash_launch(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, uint64_t* d_digests) {
+    ProfScope prof(ctx, "leaf_hash");
     unsigned block = 256;
     unsigned grid = (unsigned)((n_leaves + block - 1) / block);
     const fe* L = (const fe*)d_leaves;
@@ -94,6 +95,7 @@ int pk_compress_many(pk_ctx* ctx, const uint8_t* d_messages, uint8_t* d_hashes, 
     if (!ctx) return PK_ERR_BAD_ARG;
     PK_REQUIRE(ctx, n == 0 || (d_messages && d_hashes), "null pointer");
     if (!n) return PK_OK;
+    ProfScope prof(ctx, "compress_many");
     unsigned grid = grid_for(ctx, n, 256, 16);
     if (ctx->hash_version == 2)
         compress_many_kernel<2><<<grid, 256, 0, ctx->stream>>>((const fe*)d_messages, (fe*)d_hashes, n);
@@ -144,6 +146,7 @@ int pk_merkle_inner(pk_ctx* ctx, uint64_t* d_nodes, size_t n_leaves) {
     PK_REQUIRE(ctx, d_nodes, "null pointer");
     fe* N = (fe*)d_nodes;
     PK_HIP(ctx, hipMemsetAsync(d_nodes, 0, 32, ctx->stream));
+    ProfScope prof(ctx, "merkle_inner");
     size_t lvl = n_leaves / 2;
     for (; lvl > 512; lvl >>= 1) {
         unsigned grid = (unsigned)((lvl + 255) / 256);

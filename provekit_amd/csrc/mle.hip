@@ -116,6 +116,7 @@ int wavelet(pk_ctx* ctx, uint64_t* d_data, unsigned n_vars) {
     PK_REQUIRE(ctx, d_data, "null pointer");
     PK_REQUIRE(ctx, n_vars <= 30, "too many variables");
     if (n_vars == 0) return PK_OK;
+    ProfScope prof(ctx, SUB ? "to_coeffs" : "to_evals");
     fe* D = (fe*)d_data;
     unsigned logt = n_vars < 11 ? n_vars : 11;
     size_t lds = ((size_t)2 << logt) * 16;
@@ -400,6 +401,7 @@ int pk_eq_accumulate(pk_ctx* ctx, uint64_t* d_w, unsigned n_vars, const uint64_t
     if (n_vars) e = hipMemcpyAsync(d_points, points, 32 * (size_t)q * n_vars, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_scales, scales, 32 * (size_t)q, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
+        ProfScope prof(ctx, "eq_accumulate");
         eq_half_tables_kernel<<<dim3(q, 2), 256, 0, ctx->stream>>>(d_points, d_scales, n_vars, nhi, nlo, d_tables);
         eq_accumulate_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_w, n, nhi, nlo, q, d_tables, overwrite);
         e = hipGetLastError();
@@ -428,6 +430,7 @@ int pk_sumcheck_cubic_round(pk_ctx* ctx, uint64_t* d_a, uint64_t* d_b, uint64_t*
     fe* partials = (fe*)ctx->d_scratch;
     size_t npairs = fold_or_null ? len / 4 : len / 2;
     unsigned blocks = reduction_blocks(ctx, npairs);
+    ProfScope prof(ctx, "sumcheck_cubic");
     if (fold_or_null)
         sumcheck_cubic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len,
                                                                               to_arg(fold_or_null), partials);
@@ -450,6 +453,7 @@ int pk_sumcheck_quadratic_round(pk_ctx* ctx, const uint64_t* d_f, const uint64_t
     if (rc) return rc;
     fe* partials = (fe*)ctx->d_scratch;
     unsigned blocks = reduction_blocks(ctx, out_len / 2);
+    ProfScope prof(ctx, "sumcheck_quadratic");
     if (fold_or_null)
         sumcheck_quadratic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len,
                                                                                   to_arg(fold_or_null), (fe*)d_f_out, (fe*)d_w_out, partials);
@@ -479,6 +483,7 @@ int pk_dot(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, size_t n, uint
     int rc = reduction_scratch(ctx);
     if (rc) return rc;
     unsigned blocks = reduction_blocks(ctx, n);
+    ProfScope prof(ctx, "dot");
     dot_kernel<<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_w, (const fe*)d_f, n, (fe*)ctx->d_scratch);
     PK_LAUNCH_CHECK(ctx);
     return finish_reduction<1>(ctx, blocks, out);
@@ -494,6 +499,7 @@ int pk_eval_univariate(pk_ctx* ctx, const uint64_t* d_coeffs, size_t n, const ui
     int rc = reduction_scratch(ctx);
     if (rc) return rc;
     unsigned blocks = reduction_blocks(ctx, (n + HORNER_CHUNK - 1) / HORNER_CHUNK);
+    ProfScope prof(ctx, "eval_univariate");
     horner_kernel<<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_coeffs, n, to_arg(z), (fe*)ctx->d_scratch);
     PK_LAUNCH_CHECK(ctx);
     return finish_reduction<1>(ctx, blocks, out);
@@ -506,6 +512,7 @@ int pk_fold_coeffs(pk_ctx* ctx, const uint64_t* d_coeffs, unsigned n_vars, const
     fold_args ra{};
     for (unsigned b = 0; b < k; b++) ra.r[b] = to_arg(r + 4 * b);
     size_t n_out = (size_t)1 << (n_vars - k);
+    ProfScope prof(ctx, "fold_coeffs");
     fold_coeffs_kernel<<<grid_for(ctx, n_out, 256), 256, 0, ctx->stream>>>((const fe*)d_coeffs, n_out, k, ra, (fe*)d_out);
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;

@@ -241,6 +241,7 @@ int get_twiddles(pk_ctx* ctx, unsigned log_n, const fe** out) {
 
 template <int LOG_R>
 int launch_pass_r(pk_ctx* ctx, const PassParams& p, bool in_r_contig, size_t tiles, unsigned ncols) {
+    ProfScope prof(ctx, in_r_contig ? "ntt_pass_last" : "ntt_pass");
     constexpr int R = 1 << LOG_R;
     size_t lds_bytes = (size_t)(2 * R * BT + 2 * (R / 2 > 0 ? R / 2 : 1)) * 16;
     dim3 grid((unsigned)tiles, ncols);
@@ -416,6 +417,7 @@ int deinterleave(pk_ctx* ctx, const fe* coeffs, size_t n_coeffs, unsigned fold, 
     size_t L = n_coeffs / fw;
     PK_REQUIRE(ctx, fw <= 1024, "fold too large");
     size_t TT = 1024 / fw;
+    ProfScope prof(ctx, "deinterleave");
     unsigned grid = (unsigned)((L + TT - 1) / TT);
     deinterleave_kernel<1024><<<grid, 256, 1024 * 32, ctx->stream>>>(coeffs, S, L, (unsigned)fw, col_stride);
     PK_LAUNCH_CHECK(ctx);

@@ -103,6 +103,7 @@ int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
     // window sized so the expected number of windows is ~1 up to ~24 bits, then grows
     unsigned long long window = 1ull << 22;
     const unsigned grid = (unsigned)ctx->num_cus * 16;
+    ProfScope prof(ctx, "pow_search");
     for (;;) {
         pow_search_kernel<<<grid, 256, 0, ctx->stream>>>(ch, th, base, window, d_best);
         PK_LAUNCH_CHECK(ctx);

@@ -142,6 +142,7 @@ int pk_r1cs_witness_bounds(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, u
     PK_REQUIRE(ctx, r && d_z && d_a && d_b && d_c, "null pointer");
     PK_REQUIRE(ctx, m0 <= 30 && r->num_constraints <= ((size_t)1 << m0), "R1CS constraints exceed scheme capacity");  // whir_r1cs.rs:52-54
     size_t padded = (size_t)1 << m0;
+    ProfScope prof(ctx, "witness_bounds");
     witness_bounds_kernel<<<(unsigned)((padded + 255) / 256), 256, 0, ctx->stream>>>(
         r->csr_ptr[0], r->csr_idx[0], r->csr_val[0], r->csr_ptr[1], r->csr_idx[1], r->csr_val[1], r->d_interner, (const fe*)d_z,
         r->num_constraints, padded, (fe*)d_a, (fe*)d_b, (fe*)d_c);
@@ -158,6 +159,7 @@ int pk_r1cs_matvec(pk_ctx* ctx, const pk_r1cs* r, int matrix, int transpose, con
     const uint32_t* ptr = transpose ? r->csc_ptr[matrix] : r->csr_ptr[matrix];
     const uint32_t* idx = transpose ? r->csc_idx[matrix] : r->csr_idx[matrix];
     const uint32_t* val = transpose ? r->csc_val[matrix] : r->csr_val[matrix];
+    ProfScope prof(ctx, "sparse_matvec");
     sparse_gather_kernel<<<(unsigned)((n_out + 255) / 256), 256, 0, ctx->stream>>>(ptr, idx, val, r->d_interner, (const fe*)d_x, n_out, (fe*)d_y);
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;

@@ -110,6 +110,23 @@ class Context:
     def set_hash_version(self, version: int):
         self._check(lib.pk_ctx_set_hash_version(self.handle, version))
 
+    def profile(self, on=True):
+        self._check(lib.pk_profile_enable(self.handle, int(on)))
+
+    def profile_reset(self):
+        self._check(lib.pk_profile_reset(self.handle))
+
+    def profile_read(self) -> dict:
+        """{kernel name: (launches, total_ms)} since the last reset"""
+        buf = C.create_string_buffer(4096)
+        self._check(lib.pk_profile_names(self.handle, buf, 4096))
+        out = {}
+        for name in filter(None, buf.value.decode().split(",")):
+            n, ms = C.c_uint64(), C.c_double()
+            self._check(lib.pk_profile_read(self.handle, name.encode(), C.byref(n), C.byref(ms)))
+            out[name] = (int(n.value), float(ms.value))
+        return out
+
     def timer_start(self):
         self._check(lib.pk_timer_start(self.handle))
 
