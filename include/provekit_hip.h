@@ -241,6 +241,14 @@ int pk_tree_destroy(pk_ctx *ctx, pk_tree *tree);
 int pk_multipath_serialize(const uint64_t *indices, size_t k, size_t path_len, const uint64_t *sibling_digests,
                            const uint64_t *auth_paths, uint8_t *out, size_t out_cap, size_t *out_len);
 
+/* ------------------------------------------------------------------ self-test (host only, no device)
+ * Runs the library's __host__ __device__ arithmetic (the same source the kernels compile) on the CPU:
+ * op 0: a*b*2^-256 mod p (ark-ff mul)   1: Skyscraper v2 compress   2: v1 compress   3: from Montgomery
+ * 4/5: the lazy 29-bit product / square followed by exact reduction.  n elements of 4 x u64 each. */
+int pk_selftest_arith(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+/* the same ops run by a kernel on device buffers (device-vs-host codegen diff in the GPU suite) */
+int pk_selftest_arith_device(pk_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

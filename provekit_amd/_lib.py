@@ -101,6 +101,8 @@ SIGNATURES = {
     "pk_tree_open": (C.c_int, [vp, vp, vp, sz, C.c_int, vp, vp, vp]),
     "pk_tree_destroy": (C.c_int, [vp, vp]),
     "pk_multipath_serialize": (C.c_int, [vp, sz, sz, vp, vp, vp, sz, C.POINTER(sz)]),
+    "pk_selftest_arith": (C.c_int, [C.c_int, vp, vp, vp, sz]),
+    "pk_selftest_arith_device": (C.c_int, [vp, C.c_int, vp, vp, vp, sz]),
 }
 
 

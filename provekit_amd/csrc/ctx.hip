@@ -1,7 +1,7 @@
 // ctx.hip -- context, memory and timing entry points of the C ABI, plus the
 // elementwise field kernels (rows A1/A2).
 #include "ctx.hpp"
-#include "fe.hpp"
+#include "fe29.hpp"
 
 using namespace pk;
 
@@ -228,9 +228,9 @@ __global__ __launch_bounds__(256) void fe_elementwise_kernel(const fe* __restric
         fe r;
         if (OP == OP_ADD) r = fe_add(x, fe_load(b + i));
         if (OP == OP_SUB) r = fe_sub(x, fe_load(b + i));
-        if (OP == OP_MUL) r = fe_mul(x, fe_load(b + i));
-        if (OP == OP_TO_MONT) r = fe_to_mont(fe_reduce_any(x));
-        if (OP == OP_FROM_MONT) r = fe_from_mont(x);
+        if (OP == OP_MUL) r = fe_mulx(x, fe_load(b + i));
+        if (OP == OP_TO_MONT) r = fe_to_montx(fe_reduce_any(x));
+        if (OP == OP_FROM_MONT) r = fe_from_montx(x);
         fe_store(out + i, r);
     }
 }

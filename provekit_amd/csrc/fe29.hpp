@@ -1,0 +1,270 @@
+// fe29.hpp -- carry-free BN254-Fr arithmetic for gfx950: 9 limbs x 29 bits.
+//
+// Why: on MI355X v_mad_u64_u32 issues at ~4.6 cycles/wave, but every carry instruction
+// (v_add_co/v_addc_co/v_lshl_add_u64) costs ~4 cycles too (profiles/r01_ubench_valu_rates.txt).  A
+// 32-bit-limb Montgomery product spends 3x more issue slots on carries and register-pair moves
+// than on multiplies.  With 29-bit limbs a column sum of up to 18 partial products (< 2^58 each)
+// fits the 64-bit destination of v_mad_u64_u32, so the inner loops are nothing but
+// `acc[k] = a*b + acc[k]` in place, and carries are swept once per product.
+//
+// Same role as block_multiplier::scalar_{mul,sqr} (skyscraper/block-multiplier/src/scalar.rs:12-132)
+// and ark-ff's Fp256 multiplier; same contract style: lazily reduced inputs/outputs.
+//
+// Representation: value = sum v[k] * 2^(29k).  "normalized": every limb < 2^29.
+// All functions are __host__ __device__ so the exact device code is unit-tested on the CPU
+// (tests/test_fe29_host.py through pk_selftest_*).
+#pragma once
+#include "fe.hpp"
+
+#define PK_HD __host__ __device__ __forceinline__
+
+// Hide a value's known bits from the optimizer (device only; no instruction is emitted).
+// Needed for the 24-bit Montgomery step: ROCm 7.2's AMDGPU mul24 combine drops the `& 0xffffff`
+// on the multiplier and then selects a full 32-bit v_mad_u64_u32 on the UNMASKED register for the
+// limbs of p that fit 24 bits (seen in the ISA; caught by tests/test_gpu_selftest.py).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PK_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define PK_OPAQUE(x) (void)(x)
+#endif
+
+namespace pk {
+
+struct fe29 {
+    u32 v[9];
+};
+
+constexpr u32 M29 = (1u << 29) - 1;
+constexpr u32 NP29 = PK_NP0 & M29;  // -p^-1 mod 2^29
+
+// limb k (29-bit) of K*p, K*p < 2^261
+PK_HD constexpr u32 kp29(int K, int k) {
+    constexpr u32 P[8] = {PK_P0, PK_P1, PK_P2, PK_P3, PK_P4, PK_P5, PK_P6, PK_P7};
+    // compute K*p as 9 x 32-bit words then extract bits [29k, 29k+29)
+    u32 w[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    u64 c = 0;
+    for (int i = 0; i < 8; i++) {
+        c += (u64)P[i] * (u32)K;
+        w[i] = (u32)c;
+        c >>= 32;
+    }
+    w[8] = (u32)c;
+    int bit = 29 * k, wi = bit >> 5, sh = bit & 31;
+    u64 window = (u64)w[wi] | ((u64)w[wi + 1] << 32);
+    return (u32)(window >> sh) & M29;
+}
+PK_HD constexpr u32 p29(int k) { return kp29(1, k); }
+
+// ---- packing ---------------------------------------------------------------------------------
+// 8 x u32 (256-bit little-endian) -> 9 x 29-bit limbs, optionally pre-shifted left by SHL bits
+// (SHL = 5 turns x into 32x for free: mont261(a, 32b) = a*b*2^-256).
+template <int SHL>
+PK_HD fe29 unpack29(const fe& x) {
+    fe29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int bit = 29 * k - SHL;  // bit position in x of limb k's lsb (may be negative for k = 0)
+        u32 limb;
+        if (bit < 0) {
+            limb = (x.v[0] << (-bit)) & M29;
+        } else {
+            const int wi = bit >> 5, sh = bit & 31;
+            u32 lo = wi < 8 ? x.v[wi] : 0u;
+            u32 hi = wi + 1 < 8 ? x.v[wi + 1] : 0u;
+            limb = sh == 0 ? lo : ((lo >> sh) | (sh > 3 ? (hi << (32 - sh)) : 0u));
+            limb &= M29;
+        }
+        r.v[k] = limb;
+    }
+    if (SHL > 0) {  // the top limb keeps the bits shifted out beyond 29*9: value < 2^(256+SHL) <= 2^261 fits
+    }
+    return r;
+}
+// normalized limbs, value < 2^256  ->  8 x u32
+PK_HD fe pack29(const fe29& a) {
+    fe r;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        const int bit = 32 * w, k0 = bit / 29, o = bit - 29 * k0;
+        u32 word = a.v[k0] >> o;
+        word |= a.v[k0 + 1] << (29 - o);
+        if (58 - o < 32 && k0 + 2 < 9) word |= a.v[k0 + 2] << (58 - o);
+        r.v[w] = word;
+    }
+    return r;
+}
+
+// ---- carries ---------------------------------------------------------------------------------
+// signed carry sweep: limbs may be "negative" (two's complement) on entry; on exit limbs 0..7 are in
+// [0, 2^29) and limb 8 holds the rest (must be non-negative for a non-negative value).
+PK_HD void normalize29(fe29& a) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int c = (int)a.v[k] >> 29;
+        a.v[k] &= M29;
+        a.v[k + 1] += (u32)c;
+    }
+}
+PK_HD fe29 add29(const fe29& a, const fe29& b) {  // lazy: no carries
+    fe29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.v[k] = a.v[k] + b.v[k];
+    return r;
+}
+// a - q*p, limb-wise (signed limbs; follow with normalize29)
+PK_HD void sub_qp29(fe29& a, u32 q) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) a.v[k] -= q * p29(k);
+}
+// floor-ish estimate of value / p from the (possibly lazy) top limb; never above the true quotient.
+// p >> 232 = 0x30644e; magic = floor(2^32 / (0x30644e + 1))
+PK_HD u32 quot_estimate29(u32 top_limb) { return (u32)(((u64)top_limb * 1354u) >> 32); }
+
+// value (< ~6p, limbs lazy non-negative) -> normalized and "almost reduced": < p*(1 + 2^-18)
+PK_HD void reduce_almost29(fe29& a) {
+    u32 q = quot_estimate29(a.v[8]);
+    sub_qp29(a, q);
+    normalize29(a);
+}
+// exact: normalized value < 2p  ->  canonical [0, p)
+PK_HD fe29 cond_sub_p29(const fe29& a) {
+    fe29 t;
+    int borrow = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        int d = (int)a.v[k] - (int)p29(k) + borrow;
+        borrow = d >> 29;
+        t.v[k] = (u32)d & M29;
+    }
+    // after the sweep `borrow` is -1 iff a < p (limb 8 of both is < 2^29, so the sign is exact)
+    fe29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.v[k] = borrow ? a.v[k] : t.v[k];
+    return r;
+}
+
+// ---- products ---------------------------------------------------------------------------------
+// column sums of a*b.  Requires 9*max(a)*max(b) + 9*2^58 + 2^36 < 2^64 (e.g. limbs < 2^30 each).
+PK_HD void mul_cols29(const fe29& a, const fe29& b, u64 (&acc)[17]) {
+#pragma unroll
+    for (int k = 0; k < 17; k++) acc[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) acc[i + j] += (u64)a.v[i] * b.v[j];
+}
+PK_HD void sqr_cols29(const fe29& a, u64 (&acc)[17]) {
+    u32 a2[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) a2[j] = a.v[j] << 1;
+#pragma unroll
+    for (int k = 0; k < 17; k++) acc[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        acc[2 * i] += (u64)a.v[i] * a.v[i];
+#pragma unroll
+        for (int j = i + 1; j < 9; j++) acc[i + j] += (u64)a.v[i] * a2[j];
+    }
+}
+// Montgomery reduction by exactly 2^256 = 2^(8*29 + 24): returns (T + M p) / 2^256, normalized,
+// value < T / 2^256 + p.   8 steps of 29 bits, one of 24, then the 24-bit realignment.
+PK_HD fe29 reduce256_29(u64 (&acc)[17]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u32 m = ((u32)acc[i] * NP29) & M29;
+#pragma unroll
+        for (int j = 0; j < 9; j++) acc[i + j] += (u64)m * p29(j);
+        acc[i + 1] += acc[i] >> 29;
+    }
+    {
+        u32 m = ((u32)acc[8] * NP29) & 0xffffffu;
+        PK_OPAQUE(m);
+#pragma unroll
+        for (int j = 0; j < 9; j++) acc[8 + j] += (u64)m * p29(j);
+    }
+    u32 d[9];
+#pragma unroll
+    for (int k = 8; k < 16; k++) {
+        acc[k + 1] += acc[k] >> 29;
+        d[k - 8] = (u32)acc[k] & M29;
+    }
+    fe29 r;
+    const u64 top = acc[16];
+    d[8] = (u32)top & M29;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = (d[j] >> 24) | ((d[j + 1] << 5) & M29);
+    r.v[8] = (u32)(top >> 24);
+    return r;
+}
+// Montgomery reduction by 2^261 (9 uniform steps, no realignment): (T + M p) / 2^261
+PK_HD fe29 reduce261_29(u64 (&acc)[17]) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        u32 m = ((u32)acc[i] * NP29) & M29;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            if (i + j < 17) acc[i + j] += (u64)m * p29(j);
+        if (i + 1 < 17) acc[i + 1] += acc[i] >> 29;
+    }
+    fe29 r;
+#pragma unroll
+    for (int k = 9; k < 16; k++) {
+        acc[k + 1] += acc[k] >> 29;
+        r.v[k - 9] = (u32)acc[k] & M29;
+    }
+    r.v[7] = (u32)acc[16] & M29;
+    r.v[8] = (u32)(acc[16] >> 29);
+    return r;
+}
+
+// a*b*2^-256 (lazy): inputs with limbs < 2^30, result normalized, < a*b/2^256 + p
+PK_HD fe29 mont256_29(const fe29& a, const fe29& b) {
+    u64 acc[17];
+    mul_cols29(a, b, acc);
+    return reduce256_29(acc);
+}
+PK_HD fe29 sqr256_29(const fe29& a) {
+    u64 acc[17];
+    sqr_cols29(a, acc);
+    return reduce256_29(acc);
+}
+// a*b*2^-261 (lazy); with b = 32*y (unpack29<5>) this is a*y*2^-256
+PK_HD fe29 mont261_29(const fe29& a, const fe29& b) {
+    u64 acc[17];
+    mul_cols29(a, b, acc);
+    return reduce261_29(acc);
+}
+
+// ---- drop-in for the 8x32 API of fe.hpp ---------------------------------------------------------
+// a, b < p (ark-ff semantics) -> a*b*2^-256 mod p, fully reduced
+PK_HD fe fe_mul29(const fe& a, const fe& b) {
+    fe29 r = mont261_29(unpack29<0>(a), unpack29<5>(b));  // < 32 p^2 / 2^261 + p < 1.2 p
+    return pack29(cond_sub_p29(r));
+}
+
+PK_HD fe fe_mulx(const fe& a, const fe& b) { return fe_mul29(a, b); }
+// a < p -> a^2 * 2^-256 mod p
+PK_HD fe fe_sqrx(const fe& a) {
+    u64 acc[17];
+    sqr_cols29(unpack29<0>(a), acc);
+    return pack29(cond_sub_p29(reduce256_29(acc)));
+}
+// Montgomery -> canonical (x < p)
+PK_HD fe fe_from_montx(const fe& a) {
+    fe29 x = unpack29<0>(a);
+    u64 acc[17];
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] = x.v[k];
+#pragma unroll
+    for (int k = 9; k < 17; k++) acc[k] = 0;
+    return pack29(cond_sub_p29(reduce256_29(acc)));
+}
+// canonical (< p) -> Montgomery: x * R^2 * 2^-256
+PK_HD fe fe_to_montx(const fe& a) {
+    fe r2;
+    r2.v[0] = 0xae216da7u; r2.v[1] = 0x1bb8e645u; r2.v[2] = 0xe35c59e3u; r2.v[3] = 0x53fe3ab1u;
+    r2.v[4] = 0x53bb8085u; r2.v[5] = 0x8c49833du; r2.v[6] = 0x7f4e44a5u; r2.v[7] = 0x0216d0b1u;
+    return fe_mul29(a, r2);
+}
+
+}  // namespace pk

@@ -11,7 +11,7 @@
 //   merkle_level  : lane i owns inner node i of one level; children 2i,2i+1 are
 //                   adjacent in the heap, so a wave reads 4 KiB contiguous.
 #include "ctx.hpp"
-#include "skyscraper.hpp"
+#include "skyscraper29.hpp"
 
 using namespace pk;
 
@@ -19,9 +19,9 @@ template <int VERSION>
 __global__ __launch_bounds__(256) void compress_many_kernel(const fe* __restrict__ msgs, fe* __restrict__ out, size_t n) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        fe l = fe_reduce_any(fe_load(msgs + 2 * i));
-        fe r = fe_reduce_any(fe_load(msgs + 2 * i + 1));
-        fe_store(out + i, compress_v<VERSION>(l, r));
+        fe29 l = unpack_reduce29(fe_load(msgs + 2 * i));
+        fe29 r = unpack_reduce29(fe_load(msgs + 2 * i + 1));
+        fe_store(out + i, pack29(compress29<VERSION>(l, r)));
     }
 }
 
@@ -33,14 +33,14 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const fe* __restrict__ l
     if (i >= n_leaves) return;
     size_t step = LAYOUT == PK_COL_MAJOR ? n_leaves : 1;
     const fe* p = leaves + (LAYOUT == PK_COL_MAJOR ? i : i * (size_t)width);
-    fe h = fe_from_mont(fe_load(p));  // into_bigint(), whir.rs:21
+    fe29 h = from_mont29(fe_load(p));  // into_bigint(), whir.rs:21
     fe nxt = width > 1 ? fe_load(p + step) : fe_zero();
     for (unsigned j = 1; j < width; j++) {
-        fe x = fe_from_mont(nxt);
+        fe29 x = from_mont29(nxt);
         if (j + 1 < width) nxt = fe_load(p + (size_t)(j + 1) * step);  // prefetch next column
-        h = compress_v<VERSION>(h, x);
+        h = compress29<VERSION>(h, x);
     }
-    fe_store(digests + i, h);
+    fe_store(digests + i, pack29(h));
 }
 
 // one level of ark MerkleTree::new: nodes[i] = C(nodes[2i], nodes[2i+1]) for i in [first, first+count)
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void merkle_level_kernel(fe* __restrict__ node
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     size_t i = first + t;
-    fe l = fe_load(nodes + 2 * i), r = fe_load(nodes + 2 * i + 1);
-    fe_store(nodes + i, compress_v<VERSION>(l, r));
+    fe29 l = unpack29<0>(fe_load(nodes + 2 * i)), r = unpack29<0>(fe_load(nodes + 2 * i + 1));  // digests are canonical
+    fe_store(nodes + i, pack29(compress29<VERSION>(l, r)));
 }
 
 // the top of the tree (<= 512 nodes per level) in one workgroup: no launch per level
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(512) void merkle_top_kernel(fe* __restrict__ nodes,
     for (size_t lvl = top_leaves / 2; lvl >= 1; lvl >>= 1) {
         if (threadIdx.x < lvl) {
             size_t i = lvl + threadIdx.x;
-            fe l = fe_load(nodes + 2 * i), r = fe_load(nodes + 2 * i + 1);
-            fe_store(nodes + i, compress_v<VERSION>(l, r));
+            fe29 l = unpack29<0>(fe_load(nodes + 2 * i)), r = unpack29<0>(fe_load(nodes + 2 * i + 1));
+            fe_store(nodes + i, pack29(compress29<VERSION>(l, r)));
         }
         __threadfence_block();
         __syncthreads();

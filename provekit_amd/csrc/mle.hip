@@ -6,7 +6,7 @@
 // in HBM across rounds, and returns only the 3-4 field elements the Fiat-Shamir
 // transcript needs per round (grid reduction in reduce.hpp).
 #include "ctx.hpp"
-#include "fe.hpp"
+#include "fe29.hpp"
 #include "reduce.hpp"
 
 using namespace pk;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void eq_half_tables_kernel(const fe* __restric
         fe xv = fe_load(x + (nv - 1 - l));
         for (size_t i = threadIdx.x; i < h; i += 256) {
             fe t = fe_load(T + i);
-            fe up = fe_mul(t, xv);  // s1 = s * x
+            fe up = fe_mulx(t, xv);  // s1 = s * x
             fe_store(T + h + i, up);
             fe_store(T + i, fe_sub(t, up));  // s0 = s - s1
         }
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void eq_accumulate_kernel(fe* __restrict__ w, 
         for (unsigned pt = 0; pt < q; pt++, T += per_pt) {
             fe h = fe_load(T + (i >> nlo));
             fe l = fe_load(T + ((size_t)1 << nhi) + (i & mask));
-            acc = fe_add(acc, fe_mul(h, l));
+            acc = fe_add(acc, fe_mulx(h, l));
         }
         fe_store(w + i, acc);
     }
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_kernel(fe* __restr
             fe x0 = fe_load(arr[k] + i), x1 = fe_load(arr[k] + i + off);
             if (FOLD) {  // sumcheck.rs:95-96: p0 += fold*(p2-p0); p1 += fold*(p3-p1)
                 fe x2 = fe_load(arr[k] + i + foff), x3 = fe_load(arr[k] + i + off + foff);
-                x0 = fe_add(x0, fe_mul(alpha, fe_sub(x2, x0)));
-                x1 = fe_add(x1, fe_mul(alpha, fe_sub(x3, x1)));
+                x0 = fe_add(x0, fe_mulx(alpha, fe_sub(x2, x0)));
+                x1 = fe_add(x1, fe_mulx(alpha, fe_sub(x3, x1)));
                 fe_store(arr[k] + i, x0);
                 fe_store(arr[k] + i + off, x1);
             }
@@ -215,12 +215,12 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_kernel(fe* __restr
         }
         const fe &a0 = v[0][0], &a1 = v[0][1], &b0 = v[1][0], &b1 = v[1][1], &c0 = v[2][0], &c1 = v[2][1], &e0 = v[3][0], &e1 = v[3][1];
         // f0 = eq0 * (a0*b0 - c0)
-        acc[0] = fe_add(acc[0], fe_mul(e0, fe_sub(fe_mul(a0, b0), c0)));
+        acc[0] = fe_add(acc[0], fe_mulx(e0, fe_sub(fe_mulx(a0, b0), c0)));
         // f(-1) = (2eq0-eq1) * ((2a0-a1)(2b0-b1) - (2c0-c1))
         fe ta = fe_sub(fe_dbl(a0), a1), tb = fe_sub(fe_dbl(b0), b1), tc = fe_sub(fe_dbl(c0), c1), te = fe_sub(fe_dbl(e0), e1);
-        acc[1] = fe_add(acc[1], fe_mul(te, fe_sub(fe_mul(ta, tb), tc)));
+        acc[1] = fe_add(acc[1], fe_mulx(te, fe_sub(fe_mulx(ta, tb), tc)));
         // f_inf = (eq1-eq0)(a1-a0)(b1-b0)
-        acc[2] = fe_add(acc[2], fe_mul(fe_mul(fe_sub(e1, e0), fe_sub(a1, a0)), fe_sub(b1, b0)));
+        acc[2] = fe_add(acc[2], fe_mulx(fe_mulx(fe_sub(e1, e0), fe_sub(a1, a0)), fe_sub(b1, b0)));
     }
     block_reduce_fe<3>(acc, smem);
     if (threadIdx.x == 0) {
@@ -247,11 +247,11 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_kernel(const f
         fe f0, f1, w0, w1;
         if (FOLD) {
             fe x0 = fe_load(f + 4 * i), x1 = fe_load(f + 4 * i + 1), x2 = fe_load(f + 4 * i + 2), x3 = fe_load(f + 4 * i + 3);
-            f0 = fe_add(x0, fe_mul(r, fe_sub(x1, x0)));
-            f1 = fe_add(x2, fe_mul(r, fe_sub(x3, x2)));
+            f0 = fe_add(x0, fe_mulx(r, fe_sub(x1, x0)));
+            f1 = fe_add(x2, fe_mulx(r, fe_sub(x3, x2)));
             fe y0 = fe_load(w + 4 * i), y1 = fe_load(w + 4 * i + 1), y2 = fe_load(w + 4 * i + 2), y3 = fe_load(w + 4 * i + 3);
-            w0 = fe_add(y0, fe_mul(r, fe_sub(y1, y0)));
-            w1 = fe_add(y2, fe_mul(r, fe_sub(y3, y2)));
+            w0 = fe_add(y0, fe_mulx(r, fe_sub(y1, y0)));
+            w1 = fe_add(y2, fe_mulx(r, fe_sub(y3, y2)));
             fe_store(f_out + 2 * i, f0);
             fe_store(f_out + 2 * i + 1, f1);
             fe_store(w_out + 2 * i, w0);
@@ -262,9 +262,9 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_kernel(const f
             w0 = fe_load(w + 2 * i);
             w1 = fe_load(w + 2 * i + 1);
         }
-        acc[0] = fe_add(acc[0], fe_mul(f0, w0));
-        acc[1] = fe_add(acc[1], fe_mul(f1, w1));
-        acc[2] = fe_add(acc[2], fe_mul(fe_sub(fe_dbl(f1), f0), fe_sub(fe_dbl(w1), w0)));
+        acc[0] = fe_add(acc[0], fe_mulx(f0, w0));
+        acc[1] = fe_add(acc[1], fe_mulx(f1, w1));
+        acc[2] = fe_add(acc[2], fe_mulx(fe_sub(fe_dbl(f1), f0), fe_sub(fe_dbl(w1), w0)));
     }
     block_reduce_fe<3>(acc, smem);
     if (threadIdx.x == 0) {
@@ -279,7 +279,7 @@ __global__ void fold_pairs_kernel(const fe* __restrict__ v, fe* __restrict__ out
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < out_len; i += stride) {
         fe x0 = fe_load(v + 2 * i), x1 = fe_load(v + 2 * i + 1);
-        fe_store(out + i, fe_add(x0, fe_mul(r, fe_sub(x1, x0))));
+        fe_store(out + i, fe_add(x0, fe_mulx(r, fe_sub(x1, x0))));
     }
 }
 
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(RED_THREADS) void dot_kernel(const fe* __restrict__
     fe acc[1] = {fe_zero()};
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        acc[0] = fe_add(acc[0], fe_mul(fe_load(w + i), fe_load(f + i)));
+        acc[0] = fe_add(acc[0], fe_mulx(fe_load(w + i), fe_load(f + i)));
     block_reduce_fe<1>(acc, smem);
     if (threadIdx.x == 0) fe_store(partials + blockIdx.x, acc[0]);
 }
@@ -301,8 +301,8 @@ constexpr int HORNER_CHUNK = 64;
 __device__ __forceinline__ fe fe_pow_u64(fe base, u64 e) {
     fe acc = fe_one();
     while (e) {
-        if (e & 1) acc = fe_mul(acc, base);
-        base = fe_sqr(base);
+        if (e & 1) acc = fe_mulx(acc, base);
+        base = fe_sqrx(base);
         e >>= 1;
     }
     return acc;
@@ -321,9 +321,9 @@ __global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restric
         for (; ch < nchunks; ch += stride) {
             size_t lo = ch * HORNER_CHUNK, hi = lo + HORNER_CHUNK < n ? lo + HORNER_CHUNK : n;
             fe h = fe_zero();
-            for (size_t i = hi; i-- > lo;) h = fe_add(fe_mul(h, z), fe_load(c + i));
-            acc[0] = fe_add(acc[0], fe_mul(h, zp));
-            zp = fe_mul(zp, zs);
+            for (size_t i = hi; i-- > lo;) h = fe_add(fe_mulx(h, z), fe_load(c + i));
+            acc[0] = fe_add(acc[0], fe_mulx(h, zp));
+            zp = fe_mulx(zp, zs);
         }
     }
     block_reduce_fe<1>(acc, smem);
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void fold_coeffs_kernel(const fe* __restrict__
         lds_put(lo, hi, 0, fe_one());
         for (unsigned b = 0; b < k; b++) {
             fe rb = from_arg(ra.r[b]);
-            for (int j = 0; j < (1 << b); j++) lds_put(lo, hi, (1 << b) + j, fe_mul(lds_get(lo, hi, j), rb));
+            for (int j = 0; j < (1 << b); j++) lds_put(lo, hi, (1 << b) + j, fe_mulx(lds_get(lo, hi, j), rb));
         }
     }
     __syncthreads();
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void fold_coeffs_kernel(const fe* __restrict__
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_out; t += stride) {
         fe acc = fe_load(c + t * fw);
-        for (int j = 1; j < fw; j++) acc = fe_add(acc, fe_mul(fe_load(c + t * fw + j), lds_get(wts, wts + 256, j)));
+        for (int j = 1; j < fw; j++) acc = fe_add(acc, fe_mulx(fe_load(c + t * fw + j), lds_get(wts, wts + 256, j)));
         fe_store(out + t, acc);
     }
 }
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void axpy_kernel(fe* __restrict__ y, const fe*
     const fe beta = from_arg(beta_arg);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        fe_store(y + i, fe_add(fe_load(y + i), fe_mul(beta, fe_load(x + i))));
+        fe_store(y + i, fe_add(fe_load(y + i), fe_mulx(beta, fe_load(x + i))));
 }
 
 }  // namespace

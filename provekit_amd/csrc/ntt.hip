@@ -24,7 +24,7 @@
 #include <vector>
 
 #include "ctx.hpp"
-#include "fe.hpp"
+#include "fe29.hpp"
 
 using namespace pk;
 
@@ -39,7 +39,7 @@ __device__ __forceinline__ fe root28_mont() {
     fe r;
     r.v[0] = 0x725b19f0u; r.v[1] = 0x9bd61b6eu; r.v[2] = 0x41112ed4u; r.v[3] = 0x402d111eu;
     r.v[4] = 0x8ef62abcu; r.v[5] = 0x00e0a7ebu; r.v[6] = 0xa58a7e85u; r.v[7] = 0x2a3c09f0u;
-    return fe_to_mont(r);
+    return fe_to_montx(r);
 }
 
 // W[e] = w_N^e for e in [0, N): W[0] = 1, then doubling: W[h + j] = W[j] * w^h
@@ -47,7 +47,7 @@ __global__ void twiddle_init_kernel(fe* W, unsigned log_n) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         fe_store(W, fe_one());
         fe w = root28_mont();
-        for (unsigned i = log_n; i < 28; i++) w = fe_sqr(w);
+        for (unsigned i = log_n; i < 28; i++) w = fe_sqrx(w);
         if (log_n > 0) fe_store(W + 1, w);
     }
 }
@@ -57,11 +57,11 @@ __global__ __launch_bounds__(256) void twiddle_double_kernel(fe* W, size_t h) {
     if (j >= h) return;
     fe wh = fe_load(W + h);
     if (j == 0) return;
-    fe_store(W + h + j, fe_mul(fe_load(W + j), wh));
+    fe_store(W + h + j, fe_mulx(fe_load(W + j), wh));
 }
 __global__ void twiddle_seed_kernel(fe* W, size_t h) {
     // W[h] = W[h/2]^2
-    if (threadIdx.x == 0 && blockIdx.x == 0) fe_store(W + h, fe_sqr(fe_load(W + h / 2)));
+    if (threadIdx.x == 0 && blockIdx.x == 0) fe_store(W + h, fe_sqrx(fe_load(W + h / 2)));
 }
 
 struct PassParams {
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(NTHREADS) void ntt_pass_kernel(PassParams p) {
                 fe w;
                 w.v[0] = wl.x; w.v[1] = wl.y; w.v[2] = wl.z; w.v[3] = wl.w;
                 w.v[4] = wh.x; w.v[5] = wh.y; w.v[6] = wh.z; w.v[7] = wh.w;
-                dif = fe_mul(dif, w);
+                dif = fe_mulx(dif, w);
             }
             lo[a0i] = make_uint4(sum.v[0], sum.v[1], sum.v[2], sum.v[3]);
             hi[a0i] = make_uint4(sum.v[4], sum.v[5], sum.v[6], sum.v[7]);
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NTHREADS) void ntt_pass_kernel(PassParams p) {
         x.v[4] = h0.x; x.v[5] = h0.y; x.v[6] = h0.z; x.v[7] = h0.w;
         if (p.tw_mul != 0) {
             size_t ex = (p.tw_mul * (size_t)k * (v0 + b)) & p.n_mask;
-            if (ex != 0) x = fe_mul(x, fe_load(p.W + ex));
+            if (ex != 0) x = fe_mulx(x, fe_load(p.W + ex));
         }
         fe_store(out + (size_t)k * p.out_stride_r + (size_t)b * p.out_stride_v, x);
     }

@@ -9,7 +9,7 @@
 #include <cmath>
 
 #include "ctx.hpp"
-#include "skyscraper.hpp"
+#include "skyscraper29.hpp"
 
 using namespace pk;
 
@@ -27,7 +27,7 @@ __device__ __forceinline__ fe from_arg(const fe_arg& a) {
 
 __global__ __launch_bounds__(256) void pow_search_kernel(fe_arg challenge_arg, fe_arg threshold_arg, unsigned long long base,
                                                          unsigned long long count, unsigned long long* best) {
-    const fe challenge = fe_reduce_any(from_arg(challenge_arg));  // generic.rs:81 reduce_partial on arbitrary input
+    const fe29 challenge = unpack_reduce29(from_arg(challenge_arg));  // generic.rs:81 reduce_partial on arbitrary input
     const fe threshold = from_arg(threshold_arg);
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void pow_search_kernel(fe_arg challenge_arg, f
         fe r = fe_zero();
         r.v[0] = (u32)nonce;
         r.v[1] = (u32)(nonce >> 32);
-        fe h = compress_reduced(challenge, r);
+        fe h = pack29(compress29<2>(challenge, unpack29<0>(r)));
         if (fe_lt(h, threshold)) atomicMin(best, nonce);
     }
 }

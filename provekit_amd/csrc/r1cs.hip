@@ -9,7 +9,7 @@
 #include <vector>
 
 #include "ctx.hpp"
-#include "fe.hpp"
+#include "fe29.hpp"
 
 using namespace pk;
 
@@ -28,7 +28,7 @@ __device__ __forceinline__ fe sparse_row_dot(const uint32_t* __restrict__ ptr, c
                                              const uint32_t* __restrict__ val, const fe* __restrict__ interner,
                                              const fe* __restrict__ x, size_t i) {
     fe acc = fe_zero();
-    for (uint32_t k = ptr[i], e = ptr[i + 1]; k < e; k++) acc = fe_add(acc, fe_mul(fe_load(interner + val[k]), fe_load(x + idx[k])));
+    for (uint32_t k = ptr[i], e = ptr[i + 1]; k < e; k++) acc = fe_add(acc, fe_mulx(fe_load(interner + val[k]), fe_load(x + idx[k])));
     return acc;
 }
 
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void witness_bounds_kernel(const uint32_t* pa,
     }
     fe_store(a + i, ra);
     fe_store(b + i, rb);
-    fe_store(c + i, fe_mul(ra, rb));
+    fe_store(c + i, fe_mulx(ra, rb));
 }
 
 __global__ __launch_bounds__(256) void sparse_gather_kernel(const uint32_t* ptr, const uint32_t* idx, const uint32_t* val,

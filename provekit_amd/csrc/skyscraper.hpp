@@ -39,7 +39,7 @@ __host__ __device__ __forceinline__ constexpr u32 rc_limb(int rc, int i) {
 }
 
 // byte-wise S-box on 4 packed bytes (skyscraper/core/src/bar.rs:40-42,63-67)
-__device__ __forceinline__ u32 sbox4(u32 v) {
+__host__ __device__ __forceinline__ u32 sbox4(u32 v) {
     u32 t1 = ((v & 0x80808080u) >> 7) | ((v & 0x7f7f7f7fu) << 1);
     u32 t2 = ((v & 0xc0c0c0c0u) >> 6) | ((v & 0x3f3f3f3fu) << 2);
     u32 t3 = ((v & 0xe0e0e0e0u) >> 5) | ((v & 0x1f1f1f1fu) << 3);

@@ -13,7 +13,7 @@
 #include <vector>
 
 #include "ctx.hpp"
-#include "fe.hpp"
+#include "fe29.hpp"
 
 using namespace pk;
 
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void gather_leaves_kernel(const fe* __restrict
     size_t q = t / width, j = t % width;
     size_t i = idx[q];
     fe x = fe_load(leaves + (layout == PK_COL_MAJOR ? j * n_leaves + i : i * (size_t)width + j));
-    fe_store(out + t, canonical ? fe_from_mont(x) : x);
+    fe_store(out + t, canonical ? fe_from_montx(x) : x);
 }
 // sibling digests: out_sib[q] = nodes[(n+i)^1]; out_path[q][d-1] = sibling of the depth-d ancestor, d = 1..logn-1 (root -> leaf)
 __global__ __launch_bounds__(256) void gather_paths_kernel(const fe* __restrict__ nodes, size_t n_leaves, unsigned logn,

@@ -1,0 +1,79 @@
+"""CPU: the library's 29-bit-limb arithmetic and Skyscraper (the exact __host__ __device__ source the kernels
+compile) executed on the host through pk_selftest_arith, against the oracle and the golden vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+VEC = json.load(open(os.path.join(G, "vectors.json")))
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+
+
+def run(op, a, b=None):
+    from provekit_amd._lib import lib
+
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    out = np.empty_like(a)
+    bb = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4) if b is not None else None
+    rc = lib.pk_selftest_arith(op, a.ctypes.data, bb.ctypes.data if bb is not None else None, out.ctypes.data, a.shape[0])
+    assert rc == 0
+    return out
+
+
+def rand_fe(n, seed, bound=P):
+    rng = np.random.default_rng(seed)
+    return [int.from_bytes(rng.bytes(32), "little") % bound for _ in range(n)]
+
+
+def test_mul_edge_and_random(oracle):
+    edge = [0, 1, 2, P - 1, P - 2, (1 << 253), (1 << 29) - 1, (1 << 58) - 1, P // 2, P // 3]
+    xs = [a for a in edge for _ in edge] + rand_fe(3000, 1)
+    ys = [b for _ in edge for b in edge] + rand_fe(3000, 2)
+    a, b = oracle.ints_to_limbs(xs), oracle.ints_to_limbs(ys)
+    assert np.array_equal(run(0, a, b), oracle.binop("pko_fe_mul", a, b))
+
+
+def test_lazy_product_and_square_wide_inputs(oracle):
+    """inputs anywhere below 2^256 (the lazy contract), exact result mod p"""
+    xs = rand_fe(2000, 3, 1 << 256) + [(1 << 256) - 1, P, 2 * P, 5 * P]
+    ys = rand_fe(2000, 4, 1 << 256) + [(1 << 256) - 1, P, 2 * P + 1, 5 * P]
+    rinv = pow(1 << 256, -1, P)
+    a, b = oracle.ints_to_limbs(xs), oracle.ints_to_limbs(ys)
+    assert oracle.limbs_to_ints(run(4, a, b)) == [x * y * rinv % P for x, y in zip(xs, ys)]
+    assert oracle.limbs_to_ints(run(5, a)) == [x * x * rinv % P for x in xs]
+
+
+def test_from_mont(oracle):
+    xs = rand_fe(2000, 5) + [0, 1, P - 1]
+    a = oracle.ints_to_limbs(xs)
+    assert np.array_equal(run(3, a), oracle.from_mont(a))
+
+
+@pytest.mark.parametrize("version", [2, 1])
+def test_compress_golden_and_random(oracle, version):
+    vec = VEC["compress_v2" if version == 2 else "compress_v1"]
+    a = oracle.ints_to_limbs(int(x, 16) for x, _, _ in vec)
+    b = oracle.ints_to_limbs(int(y, 16) for _, y, _ in vec)
+    assert oracle.limbs_to_ints(run(1 if version == 2 else 2, a, b)) == [int(e, 16) for _, _, e in vec]
+    n = 20000
+    msgs = np.random.default_rng(9).integers(0, 256, size=64 * n, dtype=np.uint8)
+    m = msgs.view(np.uint64).reshape(n, 8)
+    got = run(1 if version == 2 else 2, np.ascontiguousarray(m[:, :4]), np.ascontiguousarray(m[:, 4:]))
+    assert got.tobytes() == oracle.compress_many(msgs.tobytes(), version)
+
+
+def test_compress_near_modulus_boundaries(oracle):
+    """values that exercise the 'almost reduced' paths: multiples of p plus/minus small offsets"""
+    vals = []
+    for k in range(6):
+        for d in (-3, -1, 0, 1, 2, 1 << 20, 1 << 232):
+            v = k * P + d
+            if 0 <= v < 1 << 256:
+                vals.append(v)
+    xs = [a for a in vals for _ in vals]
+    ys = [b for _ in vals for b in vals]
+    a, b = oracle.ints_to_limbs(xs), oracle.ints_to_limbs(ys)
+    msgs = np.concatenate([a, b], axis=1).astype("<u8").tobytes()
+    assert run(1, a, b).tobytes() == oracle.compress_many(msgs)

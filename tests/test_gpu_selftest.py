@@ -1,0 +1,27 @@
+"""GPU: the library's __host__ __device__ arithmetic must give the same bits when compiled for the device as when
+compiled for the host (which tests/test_fe29_host.py ties to the oracle).  This is the guard against device-codegen
+surprises (it caught an AMDGPU mul24 miscompile of the 24-bit Montgomery step)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("op", range(14))
+def test_device_equals_host(ctx, oracle, op):
+    from provekit_amd._lib import lib
+    from provekit_amd.field import random_field
+
+    n = 4096
+    a, b = random_field(n, 100 + op), random_field(n, 200 + op)
+    a[:6] = oracle.ints_to_limbs([0, 1, oracle.P - 1, oracle.P - 2, (1 << 253) - 1, 1 << 232])
+    b[:6] = oracle.ints_to_limbs([0, oracle.P - 1, oracle.P - 1, 1, 12345, (1 << 200) + 7])
+    if op in (1, 2, 4, 5, 9):  # these accept any 256-bit input
+        rng = np.random.default_rng(op)
+        a[6:600] = rng.integers(0, 2**64, size=(594, 4), dtype=np.uint64)
+        b[6:600] = rng.integers(0, 2**64, size=(594, 4), dtype=np.uint64)
+    host = np.empty_like(a)
+    assert lib.pk_selftest_arith(op, a.ctypes.data, b.ctypes.data, host.ctypes.data, n) == 0
+    da, db, do = ctx.upload(a), ctx.upload(b), ctx.alloc_fe(n)
+    ctx._check(lib.pk_selftest_arith_device(ctx.handle, op, da.ptr, db.ptr, do.ptr, n))
+    assert np.array_equal(ctx.download_fe(do, n), host)
