@@ -6,8 +6,9 @@ m_0 = 20, synthetic R1CS + witness since the .nps is absent from the reference t
 masked witness (to_coeffs, RS-encode NTT, Skyscraper Merkle), the 20-round zk-sumcheck with its blinding
 commitment and small WHIR proof, the external row and weighted sums, and the 4-round WHIR batch opening
 (fold, re-commit, OOD, PoW grind, STIR openings, equality weights, quadratic sumcheck) -- every call through
-the C ABI of libprovekit_hip.so, inputs resident in HBM when the clock starts.  Verifier challenges come from a
-seeded source, not yet from the Skyscraper duplex sponge ("What a bench step is").
+the C ABI of libprovekit_hip.so, inputs resident in HBM when the clock starts.  The host side is the compiled driver
+(pk_prove: Skyscraper duplex-sponge transcript, blinding algebra, challenge bookkeeping); the proof string it returns is
+the same one tests/test_gpu_prove.py feeds to the independent verifier.
 
 Multi-GPU (--gpus N under torch.distributed.run): each rank proves independent statements on its own GPU
 (weak scaling, no data-path collective); value = total proofs / max-over-ranks time.
@@ -163,17 +164,15 @@ def main():
 
     import provekit_amd
     from provekit_amd.field import random_field
-    from provekit_amd.prover import WhirConfig, WhirR1CSProver
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
 
     ctx = provekit_amd.Context(local_rank)
     m, m_0 = args.m, args.m - 1
     n_wit = (1 << (m - 1)) - 5
     r1cs, mats, interner, nc = synth_r1cs(ctx, m_0, n_wit, seed=1234 + rank)
     cfg_w = WhirConfig.poseidon_witness() if m == 21 else WhirConfig.for_size(m)
-    cfg_b = WhirConfig.for_size(max((4 * m_0 - 1).bit_length(), 1) + 1)
-    cfg_b.num_queries = [32] * cfg_b.n_rounds
-    cfg_b.final_queries = 13
-    prover = WhirR1CSProver(ctx, r1cs, m, m_0, cfg_w, cfg_b)
+    cfg_b = blinding_config_for(m_0)
+    prover = WhirR1CSScheme(ctx, r1cs, m, m_0, cfg_w, cfg_b)
     d_z = ctx.upload(random_field(n_wit, 99 + rank))
 
     def barrier():
@@ -183,13 +182,13 @@ def main():
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
-        prover.prove(d_z, seed=1000 + i)
+        prover.prove_nocopy(d_z, seed=1000 + i)
     ctx.profile(True)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        prover.prove(d_z, seed=i + 1)
+        prover.prove_nocopy(d_z, seed=i + 1)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -221,7 +220,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"poseidon-rounds size class: m={m}, m_0={m_0}, batch-2 WHIR commit + zk-sumcheck + {cfg_w.n_rounds}-round WHIR opening, "
-                            f"queries {cfg_w.num_queries}/{cfg_w.final_queries}, pow_bits {cfg_w.pow_bits[0] if cfg_w.pow_bits else 0} (assumed), seeded challenges",
+                            f"queries {cfg_w.num_queries}/{cfg_w.final_queries}, pow_bits {cfg_w.pow_bits[0] if cfg_w.pow_bits else 0} (assumed), Skyscraper-sponge transcript",
                 "parallelism": f"{world} independent provers (1 per GPU)",
             },
             "roofline": {

@@ -51,6 +51,7 @@ extern "C" {
 typedef struct pk_ctx pk_ctx;
 typedef struct pk_tree pk_tree;
 typedef struct pk_r1cs pk_r1cs;
+typedef struct pk_scheme pk_scheme;
 
 /* ------------------------------------------------------------------ context */
 int pk_abi_version(void);
@@ -241,10 +242,45 @@ int pk_tree_destroy(pk_ctx *ctx, pk_tree *tree);
 int pk_multipath_serialize(const uint64_t *indices, size_t k, size_t path_len, const uint64_t *sibling_digests,
                            const uint64_t *auth_paths, uint8_t *out, size_t out_cap, size_t *out_len);
 
+/* ------------------------------------------------------------------ the seam: WhirR1CSProver::prove
+ * pk_whir_config carries the WhirConfig fields the prover consumes (the ones
+ * tooling/provekit-gnark/src/gnark_config.rs:32-57 exports); WhirConfig::new itself lives in the external
+ * `whir` crate, so the caller (Rust side) fills these from its WhirConfig.
+ * pk_scheme = WhirR1CSScheme {m, m_0, whir_witness, whir_for_hiding_spartan} (provekit/common/src/whir_r1cs.rs:17-24)
+ * bound to an uploaded R1CS; it owns a device arena sized for one proof, so pk_prove allocates nothing.
+ * pk_prove = WhirR1CSProver::prove(&self, &R1CS, Vec<FieldElement>) -> WhirR1CSProof{transcript}
+ * (provekit/prover/src/whir_r1cs.rs:36-100): d_witness = n_witness Montgomery FEs on the device; the proof string is
+ * written to transcript_out (capacity cap; *len receives its length).  rng_seed seeds the three random draws the
+ * reference takes from thread_rng (mask, random polynomial, blinding univariates). */
+#define PK_MAX_WHIR_ROUNDS 16
+typedef struct pk_whir_config {
+    unsigned n_vars;
+    unsigned batch_size;
+    unsigned folding_factor;
+    unsigned starting_log_inv_rate;
+    unsigned n_rounds;
+    unsigned num_queries[PK_MAX_WHIR_ROUNDS];
+    unsigned ood_samples[PK_MAX_WHIR_ROUNDS];
+    double pow_bits[PK_MAX_WHIR_ROUNDS];
+    unsigned final_queries;
+    double final_pow_bits;
+    unsigned commitment_ood_samples;
+} pk_whir_config;
+int pk_scheme_create(pk_ctx *ctx, const pk_r1cs *r1cs, size_t num_constraints, size_t num_witnesses, unsigned m, unsigned m_0,
+                     const pk_whir_config *whir_witness, const pk_whir_config *whir_for_hiding_spartan, pk_scheme **out);
+int pk_scheme_destroy(pk_ctx *ctx, pk_scheme *scheme);
+int pk_prove(pk_ctx *ctx, pk_scheme *scheme, const uint64_t *d_witness, size_t n_witness, uint64_t rng_seed,
+             uint8_t *transcript_out, size_t cap, size_t *len);
+/* the spongefish-style domain separator the transcript IV is derived from (labels are this library's) */
+int pk_scheme_domain_separator(const pk_scheme *scheme, char *buf, size_t cap, size_t *len);
+
 /* ------------------------------------------------------------------ self-test (host only, no device)
  * Runs the library's __host__ __device__ arithmetic (the same source the kernels compile) on the CPU:
  * op 0: a*b*2^-256 mod p (ark-ff mul)   1: Skyscraper v2 compress   2: v1 compress   3: from Montgomery
  * 4/5: the lazy 29-bit product / square followed by exact reduction.  n elements of 4 x u64 each. */
+/* host-only pieces of the transcript: domain-separator tag, one sponge permutation on canonical (l, r) */
+int pk_selftest_keccak_tag(const uint8_t *data, size_t len, uint8_t tag[32]);
+int pk_selftest_permute(uint64_t l[4], uint64_t r[4]);
 int pk_selftest_arith(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 /* the same ops run by a kernel on device buffers (device-vs-host codegen diff in the GPU suite) */
 int pk_selftest_arith_device(pk_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n);

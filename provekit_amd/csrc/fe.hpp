@@ -40,7 +40,7 @@ __host__ __device__ __forceinline__ constexpr u32 kPlimb(int i) {
 }
 
 template <int K>
-__device__ __forceinline__ constexpr u32 p_mul_limb(int i) {
+__host__ __device__ __forceinline__ constexpr u32 p_mul_limb(int i) {
     // limb i of K*p, K in 1..4 (4p < 2^256)
     constexpr u32 P[8] = {PK_P0, PK_P1, PK_P2, PK_P3, PK_P4, PK_P5, PK_P6, PK_P7};
     u64 c = 0;
@@ -53,28 +53,28 @@ __device__ __forceinline__ constexpr u32 p_mul_limb(int i) {
     return out;
 }
 
-__device__ __forceinline__ fe fe_zero() {
+__host__ __device__ __forceinline__ fe fe_zero() {
     fe r;
 #pragma unroll
     for (int i = 0; i < 8; i++) r.v[i] = 0;
     return r;
 }
 // R mod p = Montgomery one (constants.rs:17-22)
-__device__ __forceinline__ fe fe_one() {
+__host__ __device__ __forceinline__ fe fe_one() {
     fe r;
     r.v[0] = 0x4ffffffbu; r.v[1] = 0xac96341cu; r.v[2] = 0x9f60cd29u; r.v[3] = 0x36fc7695u;
     r.v[4] = 0x7879462eu; r.v[5] = 0x666ea36fu; r.v[6] = 0x9a07df2fu; r.v[7] = 0x0e0a77c1u;
     return r;
 }
 // R^2 mod p (constants.rs:25-30)
-__device__ __forceinline__ fe fe_r2() {
+__host__ __device__ __forceinline__ fe fe_r2() {
     fe r;
     r.v[0] = 0xae216da7u; r.v[1] = 0x1bb8e645u; r.v[2] = 0xe35c59e3u; r.v[3] = 0x53fe3ab1u;
     r.v[4] = 0x53bb8085u; r.v[5] = 0x8c49833du; r.v[6] = 0x7f4e44a5u; r.v[7] = 0x0216d0b1u;
     return r;
 }
 
-__device__ __forceinline__ fe fe_load(const void* p) {
+__host__ __device__ __forceinline__ fe fe_load(const void* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     uint4 a = q[0], b = q[1];
     fe r;
@@ -82,7 +82,7 @@ __device__ __forceinline__ fe fe_load(const void* p) {
     r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
     return r;
 }
-__device__ __forceinline__ void fe_store(void* p, const fe& x) {
+__host__ __device__ __forceinline__ void fe_store(void* p, const fe& x) {
     uint4* q = reinterpret_cast<uint4*>(p);
     q[0] = make_uint4(x.v[0], x.v[1], x.v[2], x.v[3]);
     q[1] = make_uint4(x.v[4], x.v[5], x.v[6], x.v[7]);
@@ -90,7 +90,7 @@ __device__ __forceinline__ void fe_store(void* p, const fe& x) {
 
 // r = a - K*p if a >= K*p else a      (a any 256-bit value)
 template <int K>
-__device__ __forceinline__ fe cond_sub_kp(const fe& a) {
+__host__ __device__ __forceinline__ fe cond_sub_kp(const fe& a) {
     fe d;
     u32 borrow = 0;
 #pragma unroll
@@ -105,11 +105,11 @@ __device__ __forceinline__ fe cond_sub_kp(const fe& a) {
     return r;
 }
 // any 256-bit value -> [0, p)   (2^256 < 6p)
-__device__ __forceinline__ fe fe_reduce_any(const fe& a) {
+__host__ __device__ __forceinline__ fe fe_reduce_any(const fe& a) {
     return cond_sub_kp<1>(cond_sub_kp<2>(cond_sub_kp<4>(a)));
 }
 
-__device__ __forceinline__ fe fe_add(const fe& a, const fe& b) {  // a,b < p -> < p
+__host__ __device__ __forceinline__ fe fe_add(const fe& a, const fe& b) {  // a,b < p -> < p
     fe s;
     u32 c = 0;
 #pragma unroll
@@ -120,7 +120,7 @@ __device__ __forceinline__ fe fe_add(const fe& a, const fe& b) {  // a,b < p -> 
     }
     return cond_sub_kp<1>(s);  // a+b < 2p < 2^255: no carry out
 }
-__device__ __forceinline__ fe fe_sub(const fe& a, const fe& b) {  // a,b < p -> < p
+__host__ __device__ __forceinline__ fe fe_sub(const fe& a, const fe& b) {  // a,b < p -> < p
     fe d;
     u32 borrow = 0;
 #pragma unroll
@@ -140,10 +140,10 @@ __device__ __forceinline__ fe fe_sub(const fe& a, const fe& b) {  // a,b < p -> 
     }
     return r;
 }
-__device__ __forceinline__ fe fe_dbl(const fe& a) { return fe_add(a, a); }
-__device__ __forceinline__ fe fe_neg(const fe& a) { return fe_sub(fe_zero(), a); }
+__host__ __device__ __forceinline__ fe fe_dbl(const fe& a) { return fe_add(a, a); }
+__host__ __device__ __forceinline__ fe fe_neg(const fe& a) { return fe_sub(fe_zero(), a); }
 
-__device__ __forceinline__ bool fe_lt(const fe& a, const fe& b) {  // a < b as 256-bit integers
+__host__ __device__ __forceinline__ bool fe_lt(const fe& a, const fe& b) {  // a < b as 256-bit integers
     u32 borrow = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -152,7 +152,7 @@ __device__ __forceinline__ bool fe_lt(const fe& a, const fe& b) {  // a < b as 2
     }
     return borrow != 0;
 }
-__device__ __forceinline__ bool fe_eq(const fe& a, const fe& b) {
+__host__ __device__ __forceinline__ bool fe_eq(const fe& a, const fe& b) {
     u32 d = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) d |= a.v[i] ^ b.v[i];
@@ -163,7 +163,7 @@ __device__ __forceinline__ bool fe_eq(const fe& a, const fe& b) {
 // returns a value < 2p (LAZY) -- see SURVEY 8a row A1: the reference's scalar_mul
 // has the same contract ("[0,2P)" in, "< 2^256-2p" out).
 // CIOS on 32-bit limbs: 64 + 64 v_mad_u64_u32 and 8 v_mul_lo_u32.
-__device__ __forceinline__ fe mont_mul_lazy(const fe& a, const fe& b) {
+__host__ __device__ __forceinline__ fe mont_mul_lazy(const fe& a, const fe& b) {
     u32 t[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) t[i] = 0;
@@ -196,11 +196,11 @@ __device__ __forceinline__ fe mont_mul_lazy(const fe& a, const fe& b) {
     for (int i = 0; i < 8; i++) r.v[i] = t[i];
     return r;
 }
-__device__ __forceinline__ fe fe_mul(const fe& a, const fe& b) { return cond_sub_kp<1>(mont_mul_lazy(a, b)); }
-__device__ __forceinline__ fe fe_sqr(const fe& a) { return cond_sub_kp<1>(mont_mul_lazy(a, a)); }
+__host__ __device__ __forceinline__ fe fe_mul(const fe& a, const fe& b) { return cond_sub_kp<1>(mont_mul_lazy(a, b)); }
+__host__ __device__ __forceinline__ fe fe_sqr(const fe& a) { return cond_sub_kp<1>(mont_mul_lazy(a, a)); }
 
 // Montgomery -> canonical: x*2^-256 mod p (reduction half only; into_bigint())
-__device__ __forceinline__ fe fe_from_mont(const fe& a) {
+__host__ __device__ __forceinline__ fe fe_from_mont(const fe& a) {
     u32 t[9];
 #pragma unroll
     for (int i = 0; i < 8; i++) t[i] = a.v[i];
@@ -225,6 +225,6 @@ __device__ __forceinline__ fe fe_from_mont(const fe& a) {
     for (int i = 0; i < 8; i++) r.v[i] = t[i];
     return cond_sub_kp<1>(r);
 }
-__device__ __forceinline__ fe fe_to_mont(const fe& a) { return fe_mul(a, fe_r2()); }
+__host__ __device__ __forceinline__ fe fe_to_mont(const fe& a) { return fe_mul(a, fe_r2()); }
 
 }  // namespace pk

@@ -392,24 +392,21 @@ int pk_eq_accumulate(pk_ctx* ctx, uint64_t* d_w, unsigned n_vars, const uint64_t
     const unsigned nlo = (n_vars + 1) / 2, nhi = n_vars - nlo;
     const size_t per_pt = ((size_t)1 << nhi) + ((size_t)1 << nlo);
     const size_t bytes = 32 * ((size_t)q * n_vars + q + (size_t)q * per_pt);
-    void* tmp = nullptr;
-    PK_HIP(ctx, hipMalloc(&tmp, bytes ? bytes : 32));
-    fe* d_points = (fe*)tmp;
+    // staging + tables use the context workspace; stream order keeps them clear of earlier kernels (NTT scratch)
+    int rc = ensure_ws(ctx, bytes + 64);
+    if (rc) return rc;
+    fe* d_points = (fe*)ctx->d_ws;
     fe* d_scales = d_points + (size_t)q * n_vars;
     fe* d_tables = d_scales + q;
-    hipError_t e = hipSuccess;
-    if (n_vars) e = hipMemcpyAsync(d_points, points, 32 * (size_t)q * n_vars, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_scales, scales, 32 * (size_t)q, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
+    if (n_vars) PK_HIP(ctx, hipMemcpyAsync(d_points, points, 32 * (size_t)q * n_vars, hipMemcpyHostToDevice, ctx->stream));
+    PK_HIP(ctx, hipMemcpyAsync(d_scales, scales, 32 * (size_t)q, hipMemcpyHostToDevice, ctx->stream));
+    {
         ProfScope prof(ctx, "eq_accumulate");
         eq_half_tables_kernel<<<dim3(q, 2), 256, 0, ctx->stream>>>(d_points, d_scales, n_vars, nhi, nlo, d_tables);
         eq_accumulate_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_w, n, nhi, nlo, q, d_tables, overwrite);
-        e = hipGetLastError();
     }
-    hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(tmp);
-    if (e != hipSuccess || e2 != hipSuccess)
-        return set_err(ctx, PK_ERR_HIP, "eq_accumulate failed: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+    PK_LAUNCH_CHECK(ctx);
+    // the host arrays were read by hipMemcpyAsync from pageable memory: that copy is complete on return
     return PK_OK;
 }
 

@@ -2,6 +2,7 @@
 // (fe29.hpp, skyscraper29.hpp), so the CPU test suite can check it against the oracle without a GPU.
 #include "ctx.hpp"
 #include "skyscraper29.hpp"
+#include "transcript.hpp"
 
 using namespace pk;
 
@@ -53,6 +54,21 @@ int pk_selftest_arith_device(pk_ctx* ctx, int op, const uint64_t* d_a, const uin
     if (!n) return PK_OK;
     selftest_kernel<<<(unsigned)((n + 63) / 64), 64, 0, ctx->stream>>>(op, (const fe*)d_a, (const fe*)d_b, (fe*)d_out, n);
     PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+// domain-separator tag (Keccak duplex, overwrite mode) and one Skyscraper sponge permutation, host only
+int pk_selftest_keccak_tag(const uint8_t* data, size_t len, uint8_t tag[32]) {
+    if (!tag || (len && !data)) return PK_ERR_BAD_ARG;
+    keccak_tag(std::string((const char*)data, len), tag);
+    return PK_OK;
+}
+int pk_selftest_permute(uint64_t l[4], uint64_t r[4]) {
+    if (!l || !r) return PK_ERR_BAD_ARG;
+    fe a = load_host(l), b = load_host(r);
+    sky_permute_host(a, b);
+    store_host(l, a);
+    store_host(r, b);
     return PK_OK;
 }
 

@@ -1,0 +1,215 @@
+// transcript.hpp -- host-side Fiat-Shamir transcript: spongefish's DuplexSponge over the Skyscraper
+// permutation.
+//
+// Mirrors provekit/common/src/skyscraper/sponge.rs:42-60 (state = 2 field elements, rate 1, IV in the
+// capacity element, permutation = skyscraper::reference::permute) and the spongefish duplex discipline
+// (overwrite mode: absorbing replaces the rate element; a squeeze after an absorb permutes first).
+// spongefish is an un-pinned, un-vendored git dependency of the reference (Cargo.toml:130-131), so the byte
+// framing below follows what the in-tree Go verifier consumes (recursive-verifier/app/circuit/common.go:30-105,
+// utilities/utilities.go:84-101): scalars = 32-byte canonical little-endian, absorbed as field elements; hints =
+// u32-LE length + payload, not absorbed; PoW nonce = 8 bytes big-endian, absorbed byte-wise; challenge bytes are
+// taken 15 at a time from squeezed elements (spongefish's bytes_uniform_modp for a 254-bit modulus).
+// Parity with the reference transcript is UNPINNED: the domain-separator labels live in the absent
+// `whir`/`spongefish` crates.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "skyscraper29.hpp"
+
+namespace pk {
+
+// ---- host field helpers (fe holds 8 x u32; Montgomery unless named canon) -----------------------
+inline fe h_load(const uint64_t* p) {
+    fe r;
+    memcpy(r.v, p, 32);
+    return r;
+}
+inline void h_store(uint64_t* p, const fe& x) { memcpy(p, x.v, 32); }
+inline fe h_mul(const fe& a, const fe& b) { return fe_mulx(a, b); }
+inline fe h_add(const fe& a, const fe& b) { return fe_add(a, b); }
+inline fe h_sub(const fe& a, const fe& b) { return fe_sub(a, b); }
+inline fe h_to_canon(const fe& mont) { return fe_from_montx(mont); }
+inline fe h_from_canon(const fe& canon) { return fe_to_montx(fe_reduce_any(canon)); }
+inline fe h_from_u64(uint64_t v) {
+    fe c = fe_zero();
+    c.v[0] = (u32)v;
+    c.v[1] = (u32)(v >> 32);
+    return h_from_canon(c);
+}
+inline fe h_pow(fe base, uint64_t e) {
+    fe acc = fe_one();
+    while (e) {
+        if (e & 1) acc = h_mul(acc, base);
+        base = h_mul(base, base);
+        e >>= 1;
+    }
+    return acc;
+}
+// 1/2 (provekit/common/src/utils/mod.rs:24-26)
+inline fe h_half() {
+    // (p+1)/2 canonical
+    fe c;
+    const uint64_t l[4] = {0xa1f0fac9f8000001ULL, 0x9419f4243cdcb848ULL, 0xdc2822db40c0ac2eULL, 0x183227397098d014ULL};
+    memcpy(c.v, l, 32);
+    return h_from_canon(c);
+}
+
+// ---- Keccak-f[1600], only to derive the sponge IV from the domain separator (spongefish tag) ----
+inline void keccak_f1600(uint64_t s[25]) {
+    static const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+                                    0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+                                    0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+                                    0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+                                    0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+                                    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    static const int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+    static const int PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+    for (int round = 0; round < 24; round++) {
+        uint64_t bc[5];
+        for (int i = 0; i < 5; i++) bc[i] = s[i] ^ s[i + 5] ^ s[i + 10] ^ s[i + 15] ^ s[i + 20];
+        for (int i = 0; i < 5; i++) {
+            uint64_t t = bc[(i + 4) % 5] ^ ((bc[(i + 1) % 5] << 1) | (bc[(i + 1) % 5] >> 63));
+            for (int j = 0; j < 25; j += 5) s[j + i] ^= t;
+        }
+        uint64_t t = s[1];
+        for (int i = 0; i < 24; i++) {
+            int j = PIL[i];
+            uint64_t b = s[j];
+            s[j] = (t << ROT[i]) | (t >> (64 - ROT[i]));
+            t = b;
+        }
+        for (int j = 0; j < 25; j += 5) {
+            for (int i = 0; i < 5; i++) bc[i] = s[j + i];
+            for (int i = 0; i < 5; i++) s[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
+        }
+        s[0] ^= RC[round];
+    }
+}
+// duplex sponge over bytes (rate 136), overwrite mode, zero IV: absorb `data`, squeeze 32 bytes
+inline void keccak_tag(const std::string& data, uint8_t tag[32]) {
+    uint64_t st[25];
+    memset(st, 0, sizeof st);
+    uint8_t* b = reinterpret_cast<uint8_t*>(st);
+    const size_t R = 136;
+    size_t pos = 0, i = 0;
+    while (i < data.size()) {
+        if (pos == R) {
+            keccak_f1600(st);
+            pos = 0;
+        } else {
+            size_t chunk = std::min(data.size() - i, R - pos);
+            memcpy(b + pos, data.data() + i, chunk);
+            pos += chunk;
+            i += chunk;
+        }
+    }
+    keccak_f1600(st);
+    memcpy(tag, b, 32);
+}
+
+// Skyscraper v2 permutation on canonical values (skyscraper/core/src/reference.rs:49-60)
+inline void sky_permute_host(fe& l_c, fe& r_c) {
+    fe29 l = unpack_reduce29(l_c), r = unpack_reduce29(r_c);
+    sky_round29<0, false>(l, r);
+    sky_round29<1, false>(l, r);
+    sky_round29<2, false>(l, r);
+    sky_round29<3, false>(l, r);
+    sky_round29<4, false>(l, r);
+    sky_round29<5, false>(l, r);
+    sky_round29<6, true>(l, r);
+    sky_round29<7, true>(l, r);
+    sky_round29<8, false>(l, r);
+    sky_round29<9, false>(l, r);
+    sky_round29<10, true>(l, r);
+    sky_round29<11, true>(l, r);
+    sky_round29<12, false>(l, r);
+    sky_round29<13, false>(l, r);
+    sky_round29<14, false>(l, r);
+    sky_round29<15, false>(l, r);
+    sky_round29<16, false>(l, r);
+    sky_round29<17, false>(l, r);
+    l_c = pack29(cond_sub_p29(l));
+    r_c = pack29(cond_sub_p29(r));
+}
+
+class Transcript {
+  public:
+    std::vector<uint8_t> narg;  // the proof string (WhirR1CSProof::transcript)
+
+    explicit Transcript(const std::string& domain_separator) {
+        uint8_t iv[32];
+        keccak_tag(domain_separator, iv);
+        st_[0] = fe_zero();
+        fe c;
+        memcpy(c.v, iv, 32);
+        st_[1] = fe_reduce_any(c);  // FieldElement::new(bigint_from_bytes_le(iv)), sponge.rs:46-49
+    }
+    // prover -> verifier: field elements (Montgomery in memory), written canonical LE and absorbed
+    void add_scalars(const fe* mont, size_t n) {
+        for (size_t i = 0; i < n; i++) add_canon(h_to_canon(mont[i]));
+    }
+    void add_scalar(const fe& mont) { add_scalars(&mont, 1); }
+    // a digest is already a canonical value (provekit/common/src/skyscraper/whir.rs:96-102)
+    void add_canon(const fe& canon) {
+        append(canon.v, 32);
+        absorb(canon);
+    }
+    // verifier -> prover
+    fe challenge_scalar() { return h_from_canon(squeeze()); }
+    void challenge_scalars(fe* out, size_t n) {
+        for (size_t i = 0; i < n; i++) out[i] = challenge_scalar();
+    }
+    void challenge_bytes(uint8_t* out, size_t n) {
+        while (n) {
+            fe c = squeeze();
+            size_t take = n < 15 ? n : 15;
+            memcpy(out, c.v, take);
+            out += take;
+            n -= take;
+        }
+    }
+    void add_bytes(const uint8_t* b, size_t n) {
+        append(b, n);
+        for (size_t i = 0; i < n; i++) {
+            fe c = fe_zero();
+            c.v[0] = b[i];
+            absorb(c);
+        }
+    }
+    void hint(const void* payload, size_t len) {
+        uint32_t l = (uint32_t)len;
+        append(&l, 4);
+        append(payload, len);
+    }
+
+  private:
+    fe st_[2];
+    int absorb_pos_ = 0, squeeze_pos_ = 1;  // R = 1
+    void append(const void* p, size_t n) {
+        const uint8_t* b = static_cast<const uint8_t*>(p);
+        narg.insert(narg.end(), b, b + n);
+    }
+    void absorb(const fe& canon) {
+        if (absorb_pos_ == 1) {
+            sky_permute_host(st_[0], st_[1]);
+            absorb_pos_ = 0;
+        }
+        st_[0] = canon;
+        absorb_pos_ = 1;
+        squeeze_pos_ = 1;
+    }
+    fe squeeze() {
+        if (squeeze_pos_ == 1) {
+            squeeze_pos_ = 0;
+            absorb_pos_ = 0;
+            sky_permute_host(st_[0], st_[1]);
+        }
+        squeeze_pos_ = 1;
+        return st_[0];
+    }
+};
+
+}  // namespace pk

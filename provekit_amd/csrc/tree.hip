@@ -57,6 +57,31 @@ __global__ __launch_bounds__(256) void gather_paths_kernel(const fe* __restrict_
 
 }  // namespace
 
+namespace pk {
+// RS-encode + Merkle commit into caller-owned device buffers (no allocation): leaves = width*rows FEs
+// (column-major), nodes = 2*rows FEs, scratch = 2*width*rows FEs.
+int commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
+                uint64_t* d_leaves, uint64_t* d_nodes, uint64_t* d_scratch) {
+    const size_t rows = (size_t)1 << (n_vars + log_inv_rate - fold);
+    const size_t width = (size_t)batch << fold;
+    int rc = pk_rs_encode(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, d_leaves, d_scratch);
+    if (!rc) rc = pk_merkle_commit(ctx, d_leaves, rows, width, PK_COL_MAJOR, d_nodes);
+    return rc;
+}
+// open k leaves of a tree described by raw buffers (same outputs as pk_tree_open)
+int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, size_t n_leaves, size_t width, const uint64_t* indices,
+             size_t k, int canonical_leaves, uint64_t* leaves_out, uint64_t* sibling_digests, uint64_t* auth_paths) {
+    pk_tree t;
+    t.d_leaves = (fe*)d_leaves;
+    t.d_nodes = (fe*)d_nodes;
+    t.n_leaves = n_leaves;
+    t.width = width;
+    t.owns_leaves = false;
+    t.layout = PK_COL_MAJOR;
+    return pk_tree_open(ctx, &t, indices, k, canonical_leaves, leaves_out, sibling_digests, auth_paths);
+}
+}  // namespace pk
+
 extern "C" {
 
 int pk_tree_destroy(pk_ctx* ctx, pk_tree* t) {

@@ -1,0 +1,110 @@
+"""WhirR1CSScheme / WhirR1CSProver::prove (provekit/common/src/whir_r1cs.rs:17-39, provekit/prover/src/whir_r1cs.rs:36-100)
+over the compiled host driver (provekit_amd/csrc/prover.hip).  One call = one proof; nothing is allocated per proof."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+from ._lib import WhirConfigStruct, lib
+from .runtime import Context, DeviceBuffer
+from .sparse_matrix import R1CS
+
+
+@dataclass
+class WhirConfig:
+    """The WhirConfig fields the prover consumes (enumerated by tooling/provekit-gnark/src/gnark_config.rs:32-57).
+    Per-round values for n=21 / n=8 are read off the reference's proof fixture; pow_bits is not
+    recoverable from it and is a stated assumption."""
+    n_vars: int
+    batch_size: int = 2
+    folding_factor: int = 4
+    starting_log_inv_rate: int = 1
+    num_queries: list = field(default_factory=list)
+    ood_samples: list = field(default_factory=list)
+    pow_bits: list = field(default_factory=list)
+    final_queries: int = 0
+    final_pow_bits: float = 0.0
+    commitment_ood_samples: int = 1
+
+    @property
+    def n_rounds(self):
+        return len(self.num_queries)
+
+    @staticmethod
+    def poseidon_witness(pow_bits: float = 16.0) -> "WhirConfig":
+        return WhirConfig(21, num_queries=[109, 28, 16, 11], ood_samples=[1, 1, 1, 1], pow_bits=[pow_bits] * 4,
+                          final_queries=9, final_pow_bits=pow_bits)
+
+    @staticmethod
+    def poseidon_blinding(pow_bits: float = 16.0) -> "WhirConfig":
+        return WhirConfig(8, num_queries=[32], ood_samples=[1], pow_bits=[pow_bits], final_queries=13, final_pow_bits=pow_bits)
+
+    @staticmethod
+    def for_size(n_vars: int, pow_bits: float = 16.0) -> "WhirConfig":
+        """size-class configs.  Round count as the fixture and the Go verifier pin it:
+        n_rounds = n/4 - 1 main rounds, final polynomial on n mod 4 variables (whir.go:24-29)."""
+        rounds = max(n_vars // 4 - 1, 0)
+        q = [109, 28, 16, 11, 9, 8, 8][:rounds]
+        return WhirConfig(n_vars, num_queries=q, ood_samples=[1] * rounds, pow_bits=[pow_bits] * rounds, final_queries=9,
+                          final_pow_bits=pow_bits)
+
+
+def _cfg_struct(cfg: WhirConfig) -> WhirConfigStruct:
+    s = WhirConfigStruct()
+    s.n_vars, s.batch_size, s.folding_factor = cfg.n_vars, cfg.batch_size, cfg.folding_factor
+    s.starting_log_inv_rate, s.n_rounds = cfg.starting_log_inv_rate, cfg.n_rounds
+    for i in range(cfg.n_rounds):
+        s.num_queries[i], s.ood_samples[i], s.pow_bits[i] = cfg.num_queries[i], cfg.ood_samples[i], cfg.pow_bits[i]
+    s.final_queries, s.final_pow_bits, s.commitment_ood_samples = cfg.final_queries, cfg.final_pow_bits, cfg.commitment_ood_samples
+    return s
+
+
+def blinding_config_for(m_0: int, pow_bits: float = 16.0) -> WhirConfig:
+    """new_whir_config_for_size(next_power_of_two(4*m_0) + 1, 2) (provekit/r1cs-compiler/src/whir_r1cs.rs:31-34)"""
+    nb = max((4 * m_0 - 1).bit_length(), 0)
+    cfg = WhirConfig.for_size(nb + 1, pow_bits)
+    cfg.num_queries = [32] * cfg.n_rounds
+    cfg.final_queries = 13
+    return cfg
+
+
+class WhirR1CSScheme:
+    def __init__(self, ctx: Context, r1cs: R1CS, m: int, m_0: int, whir_witness: WhirConfig, whir_for_hiding_spartan: WhirConfig):
+        self.ctx, self.r1cs, self.m, self.m_0 = ctx, r1cs, m, m_0
+        self.whir_witness, self.whir_for_hiding_spartan = whir_witness, whir_for_hiding_spartan
+        cw, cb = _cfg_struct(whir_witness), _cfg_struct(whir_for_hiding_spartan)
+        h = C.c_void_p()
+        ctx._check(lib.pk_scheme_create(ctx.handle, r1cs.handle, r1cs.num_constraints, r1cs.num_witnesses, m, m_0, C.byref(cw), C.byref(cb),
+                                        C.byref(h)))
+        self.handle = h.value
+        self._buf = (C.c_uint8 * (8 << 20))()
+        n = C.c_size_t()
+        lib.pk_scheme_domain_separator(self.handle, None, 0, C.byref(n))
+        ds = C.create_string_buffer(n.value)
+        lib.pk_scheme_domain_separator(self.handle, ds, n.value, C.byref(n))
+        self.domain_separator = ds.raw[: n.value]
+
+    def close(self):
+        if self.handle is not None and self.ctx.handle is not None:
+            lib.pk_scheme_destroy(self.ctx.handle, self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def prove(self, d_witness, seed: int = 1) -> bytes:
+        """-> WhirR1CSProof.transcript"""
+        n = C.c_size_t()
+        ptr = d_witness.ptr if isinstance(d_witness, DeviceBuffer) else d_witness
+        self.ctx._check(lib.pk_prove(self.ctx.handle, self.handle, ptr, self.r1cs.num_witnesses, seed, self._buf, len(self._buf), C.byref(n)))
+        return bytes(self._buf[: n.value])
+
+    def prove_nocopy(self, d_witness, seed: int = 1) -> int:
+        """prove and return only the transcript length (bench loop: no Python-side copy)"""
+        n = C.c_size_t()
+        ptr = d_witness.ptr if isinstance(d_witness, DeviceBuffer) else d_witness
+        self.ctx._check(lib.pk_prove(self.ctx.handle, self.handle, ptr, self.r1cs.num_witnesses, seed, self._buf, len(self._buf), C.byref(n)))
+        return n.value
