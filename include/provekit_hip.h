@@ -179,6 +179,8 @@ int pk_fold_pairs(pk_ctx *ctx, const uint64_t *d_v, size_t len, const uint64_t *
  *   (MultivarPoly, utilities.go:15-22; whir_utilities.go:180-186); 2^n_vars -> 2^(n_vars-k) FEs.
  * pk_fe_axpy: y += beta*x (batching f + beta*g, mtUtilities.go:98-114). */
 int pk_dot(pk_ctx *ctx, const uint64_t *d_w, const uint64_t *d_f, size_t n, uint64_t out[4]);
+/* <w,f> and <w,g> in one pass over w: out = [ <w,f>, <w,g> ] */
+int pk_dot2(pk_ctx *ctx, const uint64_t *d_w, const uint64_t *d_f, const uint64_t *d_g, size_t n, uint64_t out[8]);
 int pk_eval_univariate(pk_ctx *ctx, const uint64_t *d_coeffs, size_t n, const uint64_t z[4], uint64_t out[4]);
 int pk_fold_coeffs(pk_ctx *ctx, const uint64_t *d_coeffs, unsigned n_vars, const uint64_t *r, unsigned k,
                    uint64_t *d_out);

@@ -83,6 +83,7 @@ SIGNATURES = {
     "pk_sumcheck_quadratic_round": (C.c_int, [vp, vp, vp, sz, vp, vp, vp, vp]),
     "pk_fold_pairs": (C.c_int, [vp, vp, sz, vp, vp]),
     "pk_dot": (C.c_int, [vp, vp, vp, sz, vp]),
+    "pk_dot2": (C.c_int, [vp, vp, vp, vp, sz, vp]),
     "pk_eval_univariate": (C.c_int, [vp, vp, sz, vp, vp]),
     "pk_fold_coeffs": (C.c_int, [vp, vp, C.c_uint, vp, C.c_uint, vp]),
     "pk_fe_axpy": (C.c_int, [vp, vp, vp, vp, sz]),

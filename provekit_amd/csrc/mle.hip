@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void eq_accumulate_kernel(fe* __restrict__ w, 
 template <bool FOLD>
 __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_kernel(fe* __restrict__ a, fe* __restrict__ b, fe* __restrict__ c,
                                                                      fe* __restrict__ eq, size_t len, fe_arg fold_arg,
-                                                                     fe* __restrict__ partials) {
+                                                                     fe* __restrict__ partials, unsigned* __restrict__ ticket,
+                                                                     fe* __restrict__ result) {
     __shared__ uint4 smem[3 * RED_THREADS * 2];
     const fe alpha = from_arg(fold_arg);
     const size_t npairs = FOLD ? len / 4 : len / 2;
@@ -222,12 +223,7 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_kernel(fe* __restr
         // f_inf = (eq1-eq0)(a1-a0)(b1-b0)
         acc[2] = fe_add(acc[2], fe_mulx(fe_mulx(fe_sub(e1, e0), fe_sub(a1, a0)), fe_sub(b1, b0)));
     }
-    block_reduce_fe<3>(acc, smem);
-    if (threadIdx.x == 0) {
-        fe_store(partials + (size_t)blockIdx.x * 3 + 0, acc[0]);
-        fe_store(partials + (size_t)blockIdx.x * 3 + 1, acc[1]);
-        fe_store(partials + (size_t)blockIdx.x * 3 + 2, acc[2]);
-    }
+    grid_finish_fe<3>(acc, smem, partials, ticket, result);
 }
 
 // ---------------------------------------------------------------- W3: quadratic sumcheck round
@@ -237,7 +233,8 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_kernel(fe* __restr
 template <bool FOLD>
 __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_kernel(const fe* __restrict__ f, const fe* __restrict__ w,
                                                                          size_t out_len, fe_arg fold_arg, fe* __restrict__ f_out,
-                                                                         fe* __restrict__ w_out, fe* __restrict__ partials) {
+                                                                         fe* __restrict__ w_out, fe* __restrict__ partials,
+                                                                         unsigned* __restrict__ ticket, fe* __restrict__ result) {
     __shared__ uint4 smem[3 * RED_THREADS * 2];
     const fe r = from_arg(fold_arg);
     fe acc[3] = {fe_zero(), fe_zero(), fe_zero()};
@@ -266,12 +263,7 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_kernel(const f
         acc[1] = fe_add(acc[1], fe_mulx(f1, w1));
         acc[2] = fe_add(acc[2], fe_mulx(fe_sub(fe_dbl(f1), f0), fe_sub(fe_dbl(w1), w0)));
     }
-    block_reduce_fe<3>(acc, smem);
-    if (threadIdx.x == 0) {
-        fe_store(partials + (size_t)blockIdx.x * 3 + 0, acc[0]);
-        fe_store(partials + (size_t)blockIdx.x * 3 + 1, acc[1]);
-        fe_store(partials + (size_t)blockIdx.x * 3 + 2, acc[2]);
-    }
+    grid_finish_fe<3>(acc, smem, partials, ticket, result);
 }
 // the single-element tail of the fold (out_len == 1): v'[0] = v[0] + r (v[1]-v[0]); no pair to sum
 __global__ void fold_pairs_kernel(const fe* __restrict__ v, fe* __restrict__ out, size_t out_len, fe_arg r_arg) {
@@ -283,21 +275,28 @@ __global__ void fold_pairs_kernel(const fe* __restrict__ v, fe* __restrict__ out
     }
 }
 
-// ---------------------------------------------------------------- S5: dot product
-__global__ __launch_bounds__(RED_THREADS) void dot_kernel(const fe* __restrict__ w, const fe* __restrict__ f, size_t n,
-                                                          fe* __restrict__ partials) {
-    __shared__ uint4 smem[RED_THREADS * 2];
-    fe acc[1] = {fe_zero()};
+// ---------------------------------------------------------------- S5: dot product(s)
+// <w,f> and optionally <w,g> in one pass over w (the statement needs both sums, whir_r1cs.rs:401-405)
+template <int NV>
+__global__ __launch_bounds__(RED_THREADS) void dot_kernel(const fe* __restrict__ w, const fe* __restrict__ f, const fe* __restrict__ g,
+                                                          size_t n, fe* __restrict__ partials, unsigned* __restrict__ ticket,
+                                                          fe* __restrict__ result) {
+    __shared__ uint4 smem[NV * RED_THREADS * 2];
+    fe acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) acc[k] = fe_zero();
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        acc[0] = fe_add(acc[0], fe_mulx(fe_load(w + i), fe_load(f + i)));
-    block_reduce_fe<1>(acc, smem);
-    if (threadIdx.x == 0) fe_store(partials + blockIdx.x, acc[0]);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        fe wi = fe_load(w + i);
+        acc[0] = fe_add(acc[0], fe_mulx(wi, fe_load(f + i)));
+        if (NV == 2) acc[NV - 1] = fe_add(acc[NV - 1], fe_mulx(wi, fe_load(g + i)));
+    }
+    grid_finish_fe<NV>(acc, smem, partials, ticket, result);
 }
 
 // ---------------------------------------------------------------- E1: univariate evaluation
-// sum_i c[i] z^i: each thread Horner-evaluates a contiguous chunk, scales by z^(chunk start), block-reduces.
-constexpr int HORNER_CHUNK = 64;
+// sum_i c[i] z^i with T = gridDim*blockDim lanes: lane g Horner-evaluates the stride-T subsequence c[g], c[g+T], ...
+// in z^T (so every load is coalesced across the wave), scales by z^g and the grid reduces.
 __device__ __forceinline__ fe fe_pow_u64(fe base, u64 e) {
     fe acc = fe_one();
     while (e) {
@@ -307,27 +306,21 @@ __device__ __forceinline__ fe fe_pow_u64(fe base, u64 e) {
     }
     return acc;
 }
-__global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restrict__ c, size_t n, fe_arg z_arg,
-                                                             fe* __restrict__ partials) {
+__global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restrict__ c, size_t n, fe_arg z_arg, fe_arg zT_arg,
+                                                             fe* __restrict__ partials, unsigned* __restrict__ ticket,
+                                                             fe* __restrict__ result) {
     __shared__ uint4 smem[RED_THREADS * 2];
-    const fe z = from_arg(z_arg);
+    const fe z = from_arg(z_arg), zT = from_arg(zT_arg);
+    const size_t T = (size_t)gridDim.x * blockDim.x;
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     fe acc[1] = {fe_zero()};
-    const size_t nchunks = (n + HORNER_CHUNK - 1) / HORNER_CHUNK;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t ch = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch < nchunks) {
-        fe zs = fe_pow_u64(z, (u64)stride * HORNER_CHUNK);  // z^(stride*chunk): step between this thread's chunks
-        fe zp = fe_pow_u64(z, (u64)ch * HORNER_CHUNK);      // z^(chunk start)
-        for (; ch < nchunks; ch += stride) {
-            size_t lo = ch * HORNER_CHUNK, hi = lo + HORNER_CHUNK < n ? lo + HORNER_CHUNK : n;
-            fe h = fe_zero();
-            for (size_t i = hi; i-- > lo;) h = fe_add(fe_mulx(h, z), fe_load(c + i));
-            acc[0] = fe_add(acc[0], fe_mulx(h, zp));
-            zp = fe_mulx(zp, zs);
-        }
+    if (g < n) {
+        size_t cnt = (n - g + T - 1) / T;  // elements g, g+T, ..., g+(cnt-1)T
+        fe h = fe_load(c + g + (cnt - 1) * T);
+        for (size_t j = cnt - 1; j-- > 0;) h = fe_add(fe_mulx(h, zT), fe_load(c + g + j * T));
+        acc[0] = fe_mulx(h, fe_pow_u64(z, (u64)g));
     }
-    block_reduce_fe<1>(acc, smem);
-    if (threadIdx.x == 0) fe_store(partials + blockIdx.x, acc[0]);
+    grid_finish_fe<1>(acc, smem, partials, ticket, result);
 }
 
 // ---------------------------------------------------------------- W1: coefficient fold
@@ -424,18 +417,19 @@ int pk_sumcheck_cubic_round(pk_ctx* ctx, uint64_t* d_a, uint64_t* d_b, uint64_t*
     PK_REQUIRE(ctx, !fold_or_null || len >= 4, "size must be >= 4 when folding");    // sumcheck.rs:27
     int rc = reduction_scratch(ctx);
     if (rc) return rc;
-    fe* partials = (fe*)ctx->d_scratch;
     size_t npairs = fold_or_null ? len / 4 : len / 2;
     unsigned blocks = reduction_blocks(ctx, npairs);
-    ProfScope prof(ctx, "sumcheck_cubic");
-    if (fold_or_null)
-        sumcheck_cubic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len,
-                                                                              to_arg(fold_or_null), partials);
-    else
-        sumcheck_cubic_kernel<false><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, fe_arg{},
-                                                                               partials);
+    {
+        ProfScope prof(ctx, "sumcheck_cubic");
+        if (fold_or_null)
+            sumcheck_cubic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, to_arg(fold_or_null),
+                                                                                  red_partials(ctx), red_ticket(ctx), red_result(ctx));
+        else
+            sumcheck_cubic_kernel<false><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, fe_arg{},
+                                                                                   red_partials(ctx), red_ticket(ctx), red_result(ctx));
+    }
     PK_LAUNCH_CHECK(ctx);
-    return finish_reduction<3>(ctx, blocks, out);
+    return collect_reduction<3>(ctx, out);
 }
 
 int pk_sumcheck_quadratic_round(pk_ctx* ctx, const uint64_t* d_f, const uint64_t* d_w, size_t len, const uint64_t* fold_or_null,
@@ -448,17 +442,19 @@ int pk_sumcheck_quadratic_round(pk_ctx* ctx, const uint64_t* d_f, const uint64_t
     PK_REQUIRE(ctx, !fold_or_null || (d_f_out && d_w_out && d_f_out != d_f && d_w_out != d_w), "folding is out-of-place");
     int rc = reduction_scratch(ctx);
     if (rc) return rc;
-    fe* partials = (fe*)ctx->d_scratch;
     unsigned blocks = reduction_blocks(ctx, out_len / 2);
-    ProfScope prof(ctx, "sumcheck_quadratic");
-    if (fold_or_null)
-        sumcheck_quadratic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len,
-                                                                                  to_arg(fold_or_null), (fe*)d_f_out, (fe*)d_w_out, partials);
-    else
-        sumcheck_quadratic_kernel<false><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, fe_arg{},
-                                                                                   nullptr, nullptr, partials);
+    {
+        ProfScope prof(ctx, "sumcheck_quadratic");
+        if (fold_or_null)
+            sumcheck_quadratic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, to_arg(fold_or_null),
+                                                                                      (fe*)d_f_out, (fe*)d_w_out, red_partials(ctx), red_ticket(ctx),
+                                                                                      red_result(ctx));
+        else
+            sumcheck_quadratic_kernel<false><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, fe_arg{}, nullptr, nullptr,
+                                                                                       red_partials(ctx), red_ticket(ctx), red_result(ctx));
+    }
     PK_LAUNCH_CHECK(ctx);
-    return finish_reduction<3>(ctx, blocks, out);
+    return collect_reduction<3>(ctx, out);
 }
 
 int pk_fold_pairs(pk_ctx* ctx, const uint64_t* d_v, size_t len, const uint64_t* r, uint64_t* d_out) {
@@ -480,10 +476,32 @@ int pk_dot(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, size_t n, uint
     int rc = reduction_scratch(ctx);
     if (rc) return rc;
     unsigned blocks = reduction_blocks(ctx, n);
-    ProfScope prof(ctx, "dot");
-    dot_kernel<<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_w, (const fe*)d_f, n, (fe*)ctx->d_scratch);
+    {
+        ProfScope prof(ctx, "dot");
+        dot_kernel<1><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_w, (const fe*)d_f, nullptr, n, red_partials(ctx), red_ticket(ctx),
+                                                               red_result(ctx));
+    }
     PK_LAUNCH_CHECK(ctx);
-    return finish_reduction<1>(ctx, blocks, out);
+    return collect_reduction<1>(ctx, out);
+}
+
+int pk_dot2(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, const uint64_t* d_g, size_t n, uint64_t out[8]) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, out && (n == 0 || (d_w && d_f && d_g)), "null pointer");
+    if (n == 0) {
+        memset(out, 0, 64);
+        return PK_OK;
+    }
+    int rc = reduction_scratch(ctx);
+    if (rc) return rc;
+    unsigned blocks = reduction_blocks(ctx, n);
+    {
+        ProfScope prof(ctx, "dot");
+        dot_kernel<2><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_w, (const fe*)d_f, (const fe*)d_g, n, red_partials(ctx), red_ticket(ctx),
+                                                               red_result(ctx));
+    }
+    PK_LAUNCH_CHECK(ctx);
+    return collect_reduction<2>(ctx, out);
 }
 
 int pk_eval_univariate(pk_ctx* ctx, const uint64_t* d_coeffs, size_t n, const uint64_t z[4], uint64_t out[4]) {
@@ -495,11 +513,29 @@ int pk_eval_univariate(pk_ctx* ctx, const uint64_t* d_coeffs, size_t n, const ui
     }
     int rc = reduction_scratch(ctx);
     if (rc) return rc;
-    unsigned blocks = reduction_blocks(ctx, (n + HORNER_CHUNK - 1) / HORNER_CHUNK);
-    ProfScope prof(ctx, "eval_univariate");
-    horner_kernel<<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_coeffs, n, to_arg(z), (fe*)ctx->d_scratch);
+    // ~32 coefficients per lane, at most 256 blocks
+    size_t want = (n / 32 + RED_THREADS - 1) / RED_THREADS;
+    unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want));
+    const u64 T = (u64)blocks * RED_THREADS;
+    // z^T on the host (square-and-multiply, ~16 products)
+    fe zf, zT = fe_one();
+    memcpy(zf.v, z, 32);
+    {
+        fe b = zf;
+        for (u64 e = T; e; e >>= 1) {
+            if (e & 1) zT = fe_mulx(zT, b);
+            b = fe_mulx(b, b);
+        }
+    }
+    fe_arg za, zTa;
+    memcpy(za.v, zf.v, 32);
+    memcpy(zTa.v, zT.v, 32);
+    {
+        ProfScope prof(ctx, "eval_univariate");
+        horner_kernel<<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_coeffs, n, za, zTa, red_partials(ctx), red_ticket(ctx), red_result(ctx));
+    }
     PK_LAUNCH_CHECK(ctx);
-    return finish_reduction<1>(ctx, blocks, out);
+    return collect_reduction<1>(ctx, out);
 }
 
 int pk_fold_coeffs(pk_ctx* ctx, const uint64_t* d_coeffs, unsigned n_vars, const uint64_t* r, unsigned k, uint64_t* d_out) {

@@ -100,11 +100,15 @@ int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
     memcpy(th.v, thr, 32);
     unsigned long long best = ~0ull, base = 0;
     PK_HIP(ctx, hipMemcpyAsync(d_best, &best, 8, hipMemcpyHostToDevice, ctx->stream));
-    // window sized so the expected number of windows is ~1 up to ~24 bits, then grows
-    unsigned long long window = 1ull << 22;
-    const unsigned grid = (unsigned)ctx->num_cus * 16;
+    // first window = 8x the expected work (miss probability e^-8), then doubling; never more lanes than nonces
+    unsigned wbits = (unsigned)bits + 3;
+    if (wbits < 12) wbits = 12;
+    if (wbits > 26) wbits = 26;
+    unsigned long long window = 1ull << wbits;
     ProfScope prof(ctx, "pow_search");
     for (;;) {
+        unsigned long long want = (window + 255) / 256;
+        const unsigned grid = (unsigned)(want < (unsigned long long)ctx->num_cus * 16 ? want : (unsigned long long)ctx->num_cus * 16);
         pow_search_kernel<<<grid, 256, 0, ctx->stream>>>(ch, th, base, window, d_best);
         PK_LAUNCH_CHECK(ctx);
         PK_HIP(ctx, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));

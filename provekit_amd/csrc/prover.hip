@@ -628,10 +628,9 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
         }
         ALLOC(d_bw, NB2);
         CK(pk_memcpy_h2d(ctx, d_bw, wv.data(), 32 * NB2));
-        uint64_t fs[4], gs[4];
-        CK(pk_dot(ctx, U(d_bw), U(B.f_evals), NB2, fs));
-        CK(pk_dot(ctx, U(d_bw), U(B.g_evals), NB2, gs));
-        fe sums[2] = {h_load(fs), h_load(gs)};
+        uint64_t fg[8];
+        CK(pk_dot2(ctx, U(d_bw), U(B.f_evals), U(B.g_evals), NB2, fg));
+        fe sums[2] = {h_load(fg), h_load(fg + 4)};
         T.add_scalars(sums, 2);
         fe* wts[1] = {d_bw};
         CK(whir_prove(ctx, A, s->whir_hiding, B.com, wts, 1, T));
@@ -650,11 +649,10 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
             CK(pk_memset_zero(ctx, d_w, 32 * N));
             CK(pk_memcpy_d2d(ctx, d_w, d_rows + (size_t)k * n_witness, 32 * n_witness));
             wts[k] = d_w;
-            uint64_t o[4];
-            CK(pk_dot(ctx, U(d_w), U(W.f_evals), N, o));  // S5
+            uint64_t o[8];
+            CK(pk_dot2(ctx, U(d_w), U(W.f_evals), U(W.g_evals), N, o));  // S5
             fsum[k] = h_load(o);
-            CK(pk_dot(ctx, U(d_w), U(W.g_evals), N, o));
-            gsum[k] = h_load(o);
+            gsum[k] = h_load(o + 4);
         }
         // hint::<(Vec<F>, Vec<F>)>: two ark-serialize vectors (u64 length + canonical elements)
         for (const std::vector<fe>* v : {&fsum, &gsum}) {

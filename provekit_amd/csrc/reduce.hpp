@@ -36,6 +36,48 @@ __device__ __forceinline__ void block_reduce_fe(fe (&acc)[K], uint4* smem) {
     }
 }
 
+// Single-launch grid reduction: every block stores its K partial sums, takes a ticket, and the block that
+// draws the last ticket sums all partials and writes the K results (agent-scope release/acquire around the
+// ticket, MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility").  `result` may point to
+// device-visible pinned host memory, so the host needs no copy after the stream sync.
+template <int K>
+__device__ __forceinline__ void grid_finish_fe(fe (&acc)[K], uint4* smem, fe* __restrict__ partials, unsigned* __restrict__ ticket,
+                                               fe* __restrict__ result) {
+    __shared__ unsigned s_last;
+    block_reduce_fe<K>(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) fe_store(partials + (size_t)blockIdx.x * K + k, acc[k]);
+        __threadfence();  // release the partials before the ticket
+        unsigned t = atomicAdd(ticket, 1u);
+        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();  // acquire: other blocks' partials
+#pragma unroll
+    for (int k = 0; k < K; k++) acc[k] = fe_zero();
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += RED_THREADS) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const fe* p = partials + (size_t)b * K + k;
+            fe v;  // bypass L1: the data was written by other CUs
+            const unsigned* q = reinterpret_cast<const unsigned*>(p);
+#pragma unroll
+            for (int i = 0; i < 8; i++) v.v[i] = __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc[k] = fe_add(acc[k], v);
+        }
+    }
+    __syncthreads();
+    block_reduce_fe<K>(acc, smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) fe_store(result + k, acc[k]);
+        __threadfence_system();
+        *ticket = 0;  // re-arm for the next launch (stream order makes this safe)
+    }
+}
+
 // second stage: sum `nblocks` partial K-vectors (layout partials[block*K + k]) into out[k]
 template <int K>
 __global__ __launch_bounds__(RED_THREADS) void reduce_partials_kernel(const fe* __restrict__ partials, unsigned nblocks,
@@ -68,7 +110,26 @@ inline int finish_reduction(pk_ctx* ctx, unsigned nblocks, uint64_t* host_out) {
     return PK_OK;
 }
 
-inline int reduction_scratch(pk_ctx* ctx) { return ensure_scratch(ctx, (size_t)RED_MAX_BLOCKS * 8 * 32 + 8 * 32 + 4096); }
+inline int reduction_scratch(pk_ctx* ctx) {
+    int rc = ensure_scratch(ctx, (size_t)RED_MAX_BLOCKS * 8 * 32 + 8 * 32 + 4096);
+    if (rc) return rc;
+    if (!ctx->h_pinned) {  // device-visible host memory for the few field elements each round returns
+        PK_HIP(ctx, hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocMapped));
+        ctx->pinned_bytes = 4096;
+        PK_HIP(ctx, hipMemsetAsync((char*)ctx->d_scratch + (size_t)RED_MAX_BLOCKS * 8 * 32 + 8 * 32, 0, 64, ctx->stream));
+    }
+    return PK_OK;
+}
+inline fe* red_partials(pk_ctx* ctx) { return (fe*)ctx->d_scratch; }
+inline unsigned* red_ticket(pk_ctx* ctx) { return (unsigned*)((char*)ctx->d_scratch + (size_t)RED_MAX_BLOCKS * 8 * 32 + 8 * 32); }
+inline fe* red_result(pk_ctx* ctx) { return (fe*)ctx->h_pinned; }
+// wait for the kernel and hand the K results (already in pinned host memory) to the caller
+template <int K>
+inline int collect_reduction(pk_ctx* ctx, uint64_t* host_out) {
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(host_out, ctx->h_pinned, 32 * K);
+    return PK_OK;
+}
 
 inline unsigned reduction_blocks(const pk_ctx* ctx, size_t work_items) {
     size_t need = (work_items + RED_THREADS - 1) / RED_THREADS;
