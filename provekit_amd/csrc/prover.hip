@@ -11,6 +11,8 @@
 //    +- external rows, weighted sums, claimed_evaluations hint (whir_r1cs.rs:81-91)
 //    +- whir_prove (whir::Prover::prove; structure pinned by recursive-verifier/app/circuit/whir.go:51-220)
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -547,6 +549,17 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     PK_REQUIRE(ctx, n_witness == s->num_witnesses, "Unexpected witness length for R1CS instance");  // whir_r1cs.rs:43-46
     Arena A{s->arena, s->arena_bytes};
     Transcript T(s->domain_separator);
+    const bool timing = getenv("PK_PROVE_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t_start = now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(ctx->stream);
+        auto t = now();
+        fprintf(stderr, "[pk_prove] %-28s %8.3f ms (sponge: %u permutes, %.3f ms)\n", what,
+                1e3 * std::chrono::duration<double>(t - t_start).count(), T.permutes, 1e3 * T.permute_seconds);
+        t_start = t;
+    };
     const unsigned m = s->m, m_0 = s->m_0;
     const size_t N = (size_t)1 << m;
 
@@ -554,6 +567,7 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     BatchCommit W;
     CK(batch_commit(ctx, A, m, s->whir_witness, (const fe*)d_witness, n_witness, rng_seed * 0x9e3779b97f4a7c15ULL + 1, T, W));
 
+    lap("witness commit");
     // --- run_zk_sumcheck_prover (whir_r1cs.rs:228-369)
     std::vector<fe> r(m_0);
     T.challenge_scalars(r.data(), m_0);
@@ -576,6 +590,7 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     CK(pk_memcpy_d2h(ctx, g_univ.data(), d_blind, 32 * g_univ.size()));
     BatchCommit B;
     CK(batch_commit(ctx, A, nb + 1, s->whir_hiding, d_blind, NB, rng_seed * 0x9e3779b97f4a7c15ULL + 11, T, B));
+    lap("bounds+eq+blinding commit");
     // sum_over_hypercube (whir_r1cs.rs:172-180)
     fe sum_g;
     {
@@ -616,6 +631,7 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
             saved = eval_cubic(c, a_i);
         }
     }
+    lap("zk sumcheck rounds");
     // statement over the blinding commitment: weight = expand_powers(alpha) zero-extended (whir_r1cs.rs:347-366,371-380)
     {
         const size_t NB2 = 2 * NB;
@@ -635,6 +651,7 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
         fe* wts[1] = {d_bw};
         CK(whir_prove(ctx, A, s->whir_hiding, B.com, wts, 1, T));
     }
+    lap("blinding WHIR proof");
     // --- external rows and the statement over the witness commitment (whir_r1cs.rs:81-91, 382-412)
     ALLOC(d_eq_alpha, M0);
     CK(pk_eq_table(ctx, (const uint64_t*)alpha.data(), m_0, U(d_eq_alpha)));
@@ -666,9 +683,11 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
         }
     }
     T.hint(claimed.data(), claimed.size());
+    lap("external rows + sums");
     // --- WHIR weighted batch opening (whir_r1cs.rs:94-95)
     CK(whir_prove(ctx, A, s->whir_witness, W.com, wts, 3, T));
     CK(pk_ctx_sync(ctx));
+    lap("witness WHIR proof");
 
     *len = T.narg.size();
     if (!transcript_out) return PK_OK;  // size query

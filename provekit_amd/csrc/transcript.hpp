@@ -12,6 +12,7 @@
 // Parity with the reference transcript is UNPINNED: the domain-separator labels live in the absent
 // `whir`/`spongefish` crates.
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -110,34 +111,112 @@ inline void keccak_tag(const std::string& data, uint8_t tag[32]) {
     memcpy(tag, b, 32);
 }
 
-// Skyscraper v2 permutation on canonical values (skyscraper/core/src/reference.rs:49-60)
+// Skyscraper v2 permutation on canonical values (skyscraper/core/src/reference.rs:49-60), host flavour:
+// 4 x 64-bit limbs with unsigned __int128 (the CPU has a 64x64->128 multiplier; the 29-bit layout above is
+// shaped for the GPU's 32x32+64 mad).  Checked against the Python restatement by tests/test_fe29_host.py.
+namespace host64 {
+typedef unsigned __int128 u128;
+static const uint64_t P64[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+static const uint64_t NP64 = 0xc2e1f593efffffffULL;  // -p^-1 mod 2^64
+inline bool geq_p(const uint64_t a[4]) {
+    for (int i = 3; i >= 0; i--) {
+        if (a[i] > P64[i]) return true;
+        if (a[i] < P64[i]) return false;
+    }
+    return true;
+}
+inline void sub_p(uint64_t a[4]) {
+    uint64_t borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a[i] - P64[i] - borrow;
+        a[i] = (uint64_t)d;
+        borrow = (uint64_t)(d >> 64) & 1;
+    }
+}
+// a*b*2^-256 mod p, inputs < p
+inline void mont_mul(const uint64_t a[4], const uint64_t b[4], uint64_t r[4]) {
+    uint64_t t[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)a[j] * b[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        uint64_t t4 = t[4] + (uint64_t)c;  // p < 2^254 keeps the running value below 2^320
+        uint64_t m = t[0] * NP64;
+        c = (u128)m * P64[0] + t[0];
+        c >>= 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)m * P64[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t4;
+        t[3] = (uint64_t)c;
+        t[4] = (uint64_t)(c >> 64);
+    }
+    for (int i = 0; i < 4; i++) r[i] = t[i];
+    if (t[4] || geq_p(r)) sub_p(r);
+}
+inline void add_mod(uint64_t a[4], const uint64_t b[4]) {  // a = a + b mod p, both < p
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) {
+        c += (u128)a[i] + b[i];
+        a[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    if (geq_p(a)) sub_p(a);
+}
+inline uint64_t sbox8(uint64_t v) {  // bar.rs:63-67
+    uint64_t t1 = ((v & 0x8080808080808080ULL) >> 7) | ((v & 0x7f7f7f7f7f7f7f7fULL) << 1);
+    uint64_t t2 = ((v & 0xc0c0c0c0c0c0c0c0ULL) >> 6) | ((v & 0x3f3f3f3f3f3f3f3fULL) << 2);
+    uint64_t t3 = ((v & 0xe0e0e0e0e0e0e0e0ULL) >> 5) | ((v & 0x1f1f1f1f1f1f1f1fULL) << 3);
+    uint64_t x = (~t1 & t2 & t3) ^ v;
+    return ((x & 0x8080808080808080ULL) >> 7) | ((x & 0x7f7f7f7f7f7f7f7fULL) << 1);
+}
+inline void bar(const uint64_t x[4], uint64_t out[4]) {  // reference.rs:80-94
+    out[0] = sbox8(x[2]);
+    out[1] = sbox8(x[3]);
+    out[2] = sbox8(x[0]);
+    out[3] = sbox8(x[1]);
+    while (geq_p(out)) sub_p(out);
+}
+inline void permute(uint64_t l[4], uint64_t r[4]) {
+    while (geq_p(l)) sub_p(l);
+    while (geq_p(r)) sub_p(r);
+    for (int i = 0; i < 18; i++) {
+        uint64_t f[4];
+        if (i == 6 || i == 7 || i == 10 || i == 11)
+            bar(l, f);
+        else
+            mont_mul(l, l, f);
+        add_mod(f, r);
+        uint64_t rc[4];
+        for (int k = 0; k < 4; k++) rc[k] = (uint64_t)rc_limb(i, 2 * k) | ((uint64_t)rc_limb(i, 2 * k + 1) << 32);
+        add_mod(f, rc);
+        for (int k = 0; k < 4; k++) {
+            r[k] = l[k];
+            l[k] = f[k];
+        }
+    }
+}
+}  // namespace host64
+
 inline void sky_permute_host(fe& l_c, fe& r_c) {
-    fe29 l = unpack_reduce29(l_c), r = unpack_reduce29(r_c);
-    sky_round29<0, false>(l, r);
-    sky_round29<1, false>(l, r);
-    sky_round29<2, false>(l, r);
-    sky_round29<3, false>(l, r);
-    sky_round29<4, false>(l, r);
-    sky_round29<5, false>(l, r);
-    sky_round29<6, true>(l, r);
-    sky_round29<7, true>(l, r);
-    sky_round29<8, false>(l, r);
-    sky_round29<9, false>(l, r);
-    sky_round29<10, true>(l, r);
-    sky_round29<11, true>(l, r);
-    sky_round29<12, false>(l, r);
-    sky_round29<13, false>(l, r);
-    sky_round29<14, false>(l, r);
-    sky_round29<15, false>(l, r);
-    sky_round29<16, false>(l, r);
-    sky_round29<17, false>(l, r);
-    l_c = pack29(cond_sub_p29(l));
-    r_c = pack29(cond_sub_p29(r));
+    uint64_t l[4], r[4];
+    memcpy(l, l_c.v, 32);
+    memcpy(r, r_c.v, 32);
+    host64::permute(l, r);
+    memcpy(l_c.v, l, 32);
+    memcpy(r_c.v, r, 32);
 }
 
 class Transcript {
   public:
     std::vector<uint8_t> narg;  // the proof string (WhirR1CSProof::transcript)
+    double permute_seconds = 0.0;  // host time spent in the sponge permutation (PK_PROVE_TIMING)
+    unsigned permutes = 0;
 
     explicit Transcript(const std::string& domain_separator) {
         uint8_t iv[32];
@@ -186,6 +265,12 @@ class Transcript {
     }
 
   private:
+    void permute() {
+        auto t0 = std::chrono::steady_clock::now();
+        sky_permute_host(st_[0], st_[1]);
+        permute_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        permutes++;
+    }
     fe st_[2];
     int absorb_pos_ = 0, squeeze_pos_ = 1;  // R = 1
     void append(const void* p, size_t n) {
@@ -194,7 +279,7 @@ class Transcript {
     }
     void absorb(const fe& canon) {
         if (absorb_pos_ == 1) {
-            sky_permute_host(st_[0], st_[1]);
+            permute();
             absorb_pos_ = 0;
         }
         st_[0] = canon;
@@ -205,7 +290,7 @@ class Transcript {
         if (squeeze_pos_ == 1) {
             squeeze_pos_ = 0;
             absorb_pos_ = 0;
-            sky_permute_host(st_[0], st_[1]);
+            permute();
         }
         squeeze_pos_ = 1;
         return st_[0];

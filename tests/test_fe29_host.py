@@ -77,3 +77,29 @@ def test_compress_near_modulus_boundaries(oracle):
     a, b = oracle.ints_to_limbs(xs), oracle.ints_to_limbs(ys)
     msgs = np.concatenate([a, b], axis=1).astype("<u8").tobytes()
     assert run(1, a, b).tobytes() == oracle.compress_many(msgs)
+
+
+def test_host_sponge_permutation_and_tag(oracle):
+    """the transcript's host pieces: 64-bit Skyscraper permutation == the Python restatement (which passes the
+    reference KATs), Keccak duplex tag == hashlib's SHA3 on a padded single block"""
+    import ctypes as C
+    import hashlib
+    import random
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(G), "..", "oracle"))
+    import pyref as pr
+    from provekit_amd._lib import lib
+
+    random.seed(7)
+    cases = [(0, 0), (P - 1, P - 1), (P, (1 << 256) - 1)] + [(random.getrandbits(256), random.getrandbits(256)) for _ in range(300)]
+    for a, b in cases:
+        l = np.array(pr.int_to_limbs(a), dtype=np.uint64)
+        r = np.array(pr.int_to_limbs(b), dtype=np.uint64)
+        assert lib.pk_selftest_permute(l.ctypes.data, r.ctypes.data) == 0
+        assert (pr.limbs_to_int(l), pr.limbs_to_int(r)) == pr.permute(a, b)
+    for m in (b"", b"abc", b"x" * 100):
+        data = m + b"\x06" + bytes(136 - len(m) - 2) + b"\x80"
+        out = (C.c_uint8 * 32)()
+        assert lib.pk_selftest_keccak_tag(data, len(data), out) == 0
+        assert bytes(out) == hashlib.sha3_256(m).digest()
