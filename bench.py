@@ -142,8 +142,8 @@ def cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--m", type=int, default=21, help="log2 of the committed polynomial size (poseidon-rounds: 21)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--concurrency", type=int, default=3,

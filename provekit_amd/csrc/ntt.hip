@@ -179,6 +179,168 @@ __global__ __launch_bounds__(NTHREADS) void ntt_pass_kernel(PassParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Fast path: the same pass (same PassParams, same index maps) with the butterflies kept in REGISTERS.
+// A 256-lane workgroup owns a 2048-element tile = [R = 2^LOG_R rows] x [BT = 2048/R adjacent elements]; each lane
+// holds 8 elements in the 9x29-bit lazy form (fe29.hpp) and runs a radix-2^d DIF butterfly network on them
+// (d = 3 except possibly the first round), so LDS is touched only BETWEEN rounds: ceil(LOG_R/3)-1 exchanges instead
+// of LOG_R read-modify-write sweeps.  Twiddles come from the same w_N^e table (an entry is turned into the
+// pre-shifted 29-bit form on the fly: mont261(a, 32*w) = a*w*2^-256).
+//
+// Tile index I (11 bits) = r * BT + b.  Round j transforms digit D_j of r (digits are taken from the top of r: DIF),
+// leaving the frequency digit a_j in the same bit positions; the output frequency is the digit reversal
+// k = a_0 + 2^d0 a_1 + 2^(d0+d1) a_2.  In round j a lane's 8 registers are indexed by (digit bits | low 3-d_j bits of b).
+__device__ __forceinline__ fe29 red29(fe29 x) {  // lazy non-negative limbs, value < 4p -> normalized, < p(1+2^-18)
+    reduce_almost29(x);
+    return x;
+}
+// a - b + 2p with borrow-proof limbs (b normalized, value < 2p): result limbs < 2^30.6, value < a + 2p
+__host__ __device__ __forceinline__ constexpr u32 c2p29(int k) {
+    return k == 0 ? kp29(2, 0) + (1u << 29) : (k < 8 ? kp29(2, k) + (1u << 29) - 1u : kp29(2, 8) - 1u);
+}
+__device__ __forceinline__ fe29 sub2p29(const fe29& a, const fe29& b) {
+    fe29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.v[k] = a.v[k] + c2p29(k) - b.v[k];
+    return r;
+}
+__device__ __forceinline__ fe29 tw29(const fe* W, size_t idx) { return unpack29<5>(fe_load(W + idx)); }
+
+template <int D>  // radix-2^D DIF over the top D bits of the register index; low 3-D bits are independent batches
+__device__ __forceinline__ void dft_regs(fe29 (&x)[8], const fe29& w8_1, const fe29& w8_2, const fe29& w8_3) {
+    constexpr int E = 3 - D;
+#pragma unroll
+    for (int s = 0; s < D; s++) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {  // the 4 butterflies of this stage over 8 registers
+            const int bp = E + (D - 1 - s);  // register-index bit paired in this stage
+            const int i0 = ((t >> bp) << (bp + 1)) | (t & ((1 << bp) - 1)), i1 = i0 | (1 << bp);
+            const int half = 1 << (D - 1 - s);
+            const int pos = (i0 >> E) & (half - 1);
+            const int wexp = (pos << s) << (3 - D);  // exponent of w_8
+            const bool last = (s == D - 1);
+            fe29 a = x[i0], b = x[i1];
+            fe29 sum = add29(a, b);
+            fe29 dif = sub2p29(a, b);
+            x[i0] = last ? sum : red29(sum);  // the last stage's outputs go straight into the twiddle multiply
+            if (wexp == 0)
+                x[i1] = last ? dif : red29(dif);
+            else
+                x[i1] = mont261_29(dif, wexp == 1 ? w8_1 : (wexp == 2 ? w8_2 : w8_3));
+        }
+    }
+}
+__host__ __device__ __forceinline__ constexpr int bitrev_c(int v, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+
+struct Ntt8Ctx {
+    const fe* in;
+    fe* out;
+    size_t nat0, v0;
+    unsigned tid;
+};
+
+// one round (digit J) of the register NTT; everything about the digit layout is a compile-time constant
+template <int LOG_R, int J>
+__device__ __forceinline__ void ntt8_round(fe29 (&x)[8], const PassParams& p, const Ntt8Ctx& c, u32* planes, const fe29& w8_1,
+                                           const fe29& w8_2, const fe29& w8_3) {
+    constexpr int LOGB = 11 - LOG_R, BTT = 1 << LOGB;
+    constexpr int NR = (LOG_R + 2) / 3;
+    constexpr int D0 = LOG_R - 3 * (NR - 1);
+    constexpr int D = J == 0 ? D0 : 3;
+    constexpr int DONE = J == 0 ? 0 : D0 + 3 * (J - 1);  // r bits consumed before this round
+    constexpr int POS = LOGB + LOG_R - DONE - D;          // bit offset of digit J inside the tile index
+    constexpr int E = 3 - D;
+    constexpr int REST = POS - LOGB;                      // r bits below this digit
+    constexpr int LO = POS - E;
+    const unsigned tid = c.tid;
+    // tile index of (tid, reg): [tid hi][digit][tid lo][extra]
+    const int base_idx = (int)((tid & ((1u << LO) - 1)) << E) | (int)((tid >> LO) << (POS + D));
+#define PK_TILE_INDEX(reg) (base_idx | ((reg) & ((1 << E) - 1)) | (((reg) >> E) << POS))
+    if (J == 0) {
+#pragma unroll
+        for (int reg = 0; reg < 8; reg++) {
+            const int I = PK_TILE_INDEX(reg);
+            const int r = I >> LOGB, b = I & (BTT - 1);
+            size_t nat = c.nat0 + (size_t)r * p.in_nat_r + (size_t)b * p.in_nat_v;
+            fe t = fe_zero();
+            if (nat < p.nonzero) t = fe_load(c.in + (size_t)r * p.in_stride_r + (size_t)b * p.in_stride_v);
+            x[reg] = unpack29<0>(t);
+        }
+    } else {
+        __syncthreads();
+#pragma unroll
+        for (int reg = 0; reg < 8; reg++) {
+            const int I = PK_TILE_INDEX(reg);
+#pragma unroll
+            for (int l = 0; l < 9; l++) x[reg].v[l] = planes[l * 2048 + I];
+        }
+        __syncthreads();
+    }
+    dft_regs<D>(x, w8_1, w8_2, w8_3);
+    const int m = (base_idx >> LOGB) & ((1 << REST) - 1);  // r bits below the digit: index inside the sub-transform
+    if (J + 1 < NR) {
+        const size_t unit = p.wr_step << (LOG_R - D - REST);  // w_{2^(D+REST)} in units of w_N
+#pragma unroll
+        for (int reg = 0; reg < 8; reg++) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int a = bitrev_c(reg >> E, D);
+            fe29 y = a == 0 ? red29(x[reg]) : mont261_29(x[reg], tw29(p.W, (size_t)(a * m) * unit));
+            const int I = (PK_TILE_INDEX(reg) & ~(((1 << D) - 1) << POS)) | (a << POS);  // keep the true frequency digit
+#pragma unroll
+            for (int l = 0; l < 9; l++) planes[l * 2048 + I] = y.v[l];
+        }
+    } else {
+        // frequency digits of the earlier rounds sit above this digit in the index (already true frequencies)
+        const int rr = base_idx >> LOGB;
+        int k_hi = 0;
+        if (J >= 1) k_hi |= (rr >> (LOG_R - D0)) & ((1 << D0) - 1);
+        if (J >= 2) k_hi |= ((rr >> (LOG_R - D0 - 3)) & 7) << D0;
+        constexpr int KLO = DONE;
+#pragma unroll
+        for (int reg = 0; reg < 8; reg++) {
+            const int a = bitrev_c(reg >> E, D);
+            const int b = PK_TILE_INDEX(reg) & (BTT - 1);
+            const int k = k_hi | (a << KLO);
+            fe29 y;
+            if (p.tw_mul) {
+                size_t ex = (p.tw_mul * (size_t)k * (c.v0 + b)) & p.n_mask;
+                y = mont261_29(x[reg], tw29(p.W, ex));
+            } else {
+                y = red29(x[reg]);
+            }
+            fe_store(c.out + (size_t)k * p.out_stride_r + (size_t)b * p.out_stride_v, pack29(cond_sub_p29(y)));
+        }
+    }
+#undef PK_TILE_INDEX
+}
+
+template <int LOG_R, bool IN_R_CONTIG>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ntt8_pass_kernel(PassParams p) {
+    constexpr int LOGB = 11 - LOG_R;
+    constexpr int NR = (LOG_R + 2) / 3;
+    extern __shared__ u32 planes[];  // [9][2048]
+    const size_t vblocks = ((size_t)1 << p.log_v) >> LOGB;
+    const size_t u = blockIdx.x / vblocks, vb = blockIdx.x % vblocks;
+    const size_t col = blockIdx.y;
+    Ntt8Ctx c;
+    c.v0 = vb << LOGB;
+    c.in = p.in + col * p.in_col_stride + u * p.in_stride_u + c.v0 * p.in_stride_v;
+    c.out = p.out + col * p.out_col_stride + u * p.out_stride_u + c.v0 * p.out_stride_v;
+    c.nat0 = u * p.in_nat_u + c.v0 * p.in_nat_v;
+    c.tid = threadIdx.x;
+    const size_t N8 = (p.n_mask + 1) >> 3;
+    const fe29 w8_1 = tw29(p.W, N8), w8_2 = tw29(p.W, 2 * N8), w8_3 = tw29(p.W, 3 * N8);
+    fe29 x[8];
+    ntt8_round<LOG_R, 0>(x, p, c, planes, w8_1, w8_2, w8_3);
+    if (NR > 1) ntt8_round<LOG_R, (NR > 1 ? 1 : 0)>(x, p, c, planes, w8_1, w8_2, w8_3);
+    if (NR > 2) ntt8_round<LOG_R, (NR > 2 ? 2 : 0)>(x, p, c, planes, w8_1, w8_2, w8_3);
+}
+
 // c[2^k t + j] -> S[j][t]  (t < L): stride-2^k gather done through LDS so both sides coalesce
 template <int FW_MAX>
 __global__ __launch_bounds__(256) void deinterleave_kernel(const fe* __restrict__ c, fe* __restrict__ S, size_t L, unsigned fw,
@@ -241,8 +403,26 @@ int get_twiddles(pk_ctx* ctx, unsigned log_n, const fe** out) {
 
 template <int LOG_R>
 int launch_pass_r(pk_ctx* ctx, const PassParams& p, bool in_r_contig, size_t tiles, unsigned ncols) {
-    ProfScope prof(ctx, in_r_contig ? "ntt_pass_last" : "ntt_pass");
     constexpr int R = 1 << LOG_R;
+    // register-radix fast path: needs at least BT8 = 2048/R elements along v per tile and a real twiddle table
+    if (LOG_R >= 3 && p.log_v < 62 && p.log_v >= (unsigned)(11 - LOG_R) && p.n_mask + 1 >= 8) {
+        ProfScope prof(ctx, in_r_contig ? "ntt_pass_last" : "ntt_pass");
+        const size_t tiles8 = (tiles * BT) >> (11 - LOG_R);
+        const size_t lds_bytes = 9 * 2048 * 4;
+        dim3 grid((unsigned)tiles8, ncols);
+        if (in_r_contig) {
+            PK_HIP(ctx, hipFuncSetAttribute((const void*)ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), true><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(p);
+        } else {
+            PK_HIP(ctx, hipFuncSetAttribute((const void*)ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), false>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), false><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(p);
+        }
+        PK_LAUNCH_CHECK(ctx);
+        return PK_OK;
+    }
+    ProfScope prof(ctx, in_r_contig ? "ntt_pass_last" : "ntt_pass");
     size_t lds_bytes = (size_t)(2 * R * BT + 2 * (R / 2 > 0 ? R / 2 : 1)) * 16;
     dim3 grid((unsigned)tiles, ncols);
     if (in_r_contig) {
