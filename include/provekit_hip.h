@@ -129,6 +129,13 @@ int pk_merkle_commit(pk_ctx *ctx, const uint64_t *d_leaves, size_t n_leaves, siz
  * [batch*2^fold][rows].  d_scratch: 2 * batch * 2^fold * rows FEs of device scratch. */
 int pk_rs_encode(pk_ctx *ctx, const uint64_t *const *d_coeffs, unsigned batch, unsigned n_vars,
                  unsigned log_inv_rate, unsigned fold, uint64_t *d_leaves, uint64_t *d_scratch);
+/* One shard of the same encode for a commit spread over n_shards GPUs: shard g keeps the codeword rows
+ * (leaves) i = g + n_shards*t, t < rows/n_shards.  Every rank holds the full coefficient vectors; the shard is a
+ * log2(n_shards)-stage decimation-in-frequency pre-step restricted to residue g followed by NTTs of size rows/n_shards,
+ * so ranks run independently until the digest all-gather.  d_leaves_local: column-major [batch*2^fold][rows/n_shards];
+ * d_scratch: batch*2^fold*(rows + 2*rows/n_shards) FEs. */
+int pk_rs_encode_shard(pk_ctx *ctx, const uint64_t *const *d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
+                       unsigned fold, unsigned shard, unsigned n_shards, uint64_t *d_leaves_local, uint64_t *d_scratch);
 /* plain NTT of `ncols` contiguous vectors of 2^log_n FEs, natural order in and out:
  * out[c][k] = sum_i in[c][i] * w_N^(i k)   (helper of pk_rs_encode; exposed for tests/bench) */
 int pk_ntt(pk_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, unsigned ncols);

@@ -74,6 +74,7 @@ SIGNATURES = {
     "pk_merkle_inner": (C.c_int, [vp, vp, sz]),
     "pk_merkle_commit": (C.c_int, [vp, vp, sz, sz, C.c_int, vp]),
     "pk_rs_encode": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
+    "pk_rs_encode_shard": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp]),
     "pk_ntt": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint]),
     "pk_to_coeffs": (C.c_int, [vp, vp, C.c_uint]),
     "pk_to_evals": (C.c_int, [vp, vp, C.c_uint]),

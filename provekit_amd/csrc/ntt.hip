@@ -20,6 +20,7 @@
 // from a per-size table.  The index maps are Cooley-Tukey so that natural-order input
 // gives natural-order output with no bit-reversal pass over HBM:
 //   n = n1*R2*R3 + n2*R3 + n3,   k = k1 + R1*k2 + R1*R2*k3.
+#include <algorithm>
 #include <map>
 #include <vector>
 
@@ -374,6 +375,32 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const fe* __restrict_
     }
 }
 
+// Sharded encode: rank g of G keeps the codeword rows i = g + G t.  For one column x (L nonzero
+// coefficients of N):  X[g + G t] = sum_{n'} y[n'] (w_N^G)^(n' t),   y[n'] = w_N^(n' g) * sum_s x[n' + s N/G] * w_G^(s g),
+// i.e. a log2(G)-stage decimation-in-frequency pre-step restricted to residue g, then one NTT of size N/G.
+__global__ __launch_bounds__(256) void ntt_shard_prestep_kernel(const fe* __restrict__ S, size_t s_col_stride, size_t L, fe* __restrict__ Y,
+                                                                size_t y_col_stride, size_t Ng /* N/G */, unsigned g, unsigned G,
+                                                                const fe* __restrict__ W /* w_N^e */, size_t n_mask) {
+    const size_t col = blockIdx.y;
+    const fe* x = S + col * s_col_stride;
+    fe* y = Y + col * y_col_stride;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t n = (size_t)blockIdx.x * blockDim.x + threadIdx.x; n < Ng; n += stride) {
+        fe acc = fe_zero();
+        for (unsigned s = 0; s < G; s++) {
+            size_t idx = n + (size_t)s * Ng;
+            if (idx >= L) break;
+            fe v = fe_load(x + idx);
+            size_t e = ((size_t)((s * g) % G) * Ng) & n_mask;  // w_G^(s g) = w_N^((s g mod G) N/G)
+            if (e) v = fe_mulx(v, fe_load(W + e));
+            acc = fe_add(acc, v);
+        }
+        size_t e = (n * (size_t)g) & n_mask;
+        if (e) acc = fe_mulx(acc, fe_load(W + e));
+        fe_store(y + n, acc);
+    }
+}
+
 struct TwiddleCache {
     std::map<unsigned, fe*> tables;  // log_n -> device table of 2^log_n entries
 };
@@ -642,6 +669,42 @@ int pk_rs_encode(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, u
         if (rc) return rc;
     }
     return pk::ntt_columns(ctx, S, rows, L, (fe*)d_leaves, rows, S2, log_rows, (unsigned)(batch * fw));
+}
+
+// rows of shard g only: d_leaves_local = column-major [batch*2^fold][rows/G]; local row t is global leaf g + G t.
+// d_scratch: (batch*2^fold) * (rows + 2*rows/G) FEs.
+int pk_rs_encode_shard(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
+                       unsigned fold, unsigned shard, unsigned n_shards, uint64_t* d_leaves_local, uint64_t* d_scratch) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, d_coeffs && d_leaves_local && d_scratch, "null pointer");
+    PK_REQUIRE(ctx, batch >= 1 && batch <= 16, "batch out of range");
+    PK_REQUIRE(ctx, fold <= n_vars && fold <= 8, "fold out of range");
+    PK_REQUIRE(ctx, n_vars + log_inv_rate >= fold && n_vars + log_inv_rate - fold <= 27, "domain too large (two-adicity 28)");
+    PK_REQUIRE(ctx, is_pow2(n_shards) && shard < n_shards, "n_shards must be a power of two and shard < n_shards");
+    const unsigned log_rows = n_vars + log_inv_rate - fold, log_g = ilog2(n_shards);
+    PK_REQUIRE(ctx, log_g <= log_rows, "more shards than leaves");
+    if (n_shards == 1) return pk_rs_encode(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, d_leaves_local, d_scratch);
+    const size_t rows = (size_t)1 << log_rows, fw = (size_t)1 << fold, Ng = rows >> log_g;
+    const size_t L = ((size_t)1 << n_vars) / fw;
+    const unsigned ncols = (unsigned)(batch * fw);
+    fe* S = (fe*)d_scratch;               // [ncols][rows]: de-interleaved coefficients (first L of each column)
+    fe* Y = S + (size_t)ncols * rows;     // [ncols][Ng]: pre-stepped input of the local NTT
+    fe* S2 = Y + (size_t)ncols * Ng;      // [ncols][Ng]: inter-pass buffer
+    for (unsigned b = 0; b < batch; b++) {
+        PK_REQUIRE(ctx, d_coeffs[b], "null polynomial pointer");
+        int rc = pk::deinterleave(ctx, (const fe*)d_coeffs[b], (size_t)1 << n_vars, fold, S + (size_t)b * fw * rows, rows);
+        if (rc) return rc;
+    }
+    const fe* W = nullptr;
+    int rc = get_twiddles(ctx, log_rows, &W);
+    if (rc) return rc;
+    {
+        ProfScope prof(ctx, "ntt_shard_prestep");
+        dim3 grid((unsigned)std::min<size_t>((Ng + 255) / 256, 1024), ncols);
+        ntt_shard_prestep_kernel<<<grid, 256, 0, ctx->stream>>>(S, rows, L, Y, Ng, Ng, shard, n_shards, W, rows - 1);
+    }
+    PK_LAUNCH_CHECK(ctx);
+    return pk::ntt_columns(ctx, Y, Ng, Ng, (fe*)d_leaves_local, Ng, S2, log_rows - log_g, ncols);
 }
 
 }  // extern "C"

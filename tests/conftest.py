@@ -22,6 +22,10 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def ctx():
+    # torch bundles its own HIP runtime: when a test uses both, torch must initialise it first (see provekit_amd/distributed.py)
+    import torch
+
+    torch.cuda.is_available()
     import provekit_amd
 
     c = provekit_amd.Context(0)
