@@ -304,6 +304,16 @@ def main():
         avg_ms = ms_l / max(n_l, 1)
         achieved = (bytes_step / launches_step) / (avg_ms * 1e-3) / 1e9 if n_l else 0.0
         steps_w0 = max(len(range(0, args.steps, conc)), 1)  # the profiled context (worker 0) ran this many proofs
+        # HBM bytes per launch from the rocprofv3 PMC passes (tools/pmc.sh; FETCH_SIZE doubled as the microarch guide
+        # prescribes for gfx950).  Counters cannot be read from inside this process, so the committed summary of the same
+        # command is used; null when it is missing or was taken on another workload size.
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01b_pmc_leaf_hash.json")))
+            if m == 21:
+                traffic = pmc["traffic_bytes_per_launch"]
+        except Exception:
+            pass
         stage_ms = {k: round(v[1] / steps_w0, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         line = {
             "metric": "proofs/sec (noir-r1cs prove hot path, WHIR commit + sumcheck + folding rounds)",
@@ -330,7 +340,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_step / launches_step,
                 "launches_per_step": launches_step,
                 "avg_launch_ms": avg_ms,
                 "note": "integer-ALU bound (14 Montgomery squarings per compression, DESIGN.md 4); launch time measured with hipEvents over "
