@@ -224,7 +224,8 @@ def main():
     import torch
 
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("PK_BENCH_FORCE_DIST"):
+        # launched by torch.distributed.run: one rank per GPU over RCCL ("nccl" is RCCL on ROCm)
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
