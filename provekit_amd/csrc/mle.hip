@@ -190,7 +190,7 @@ template <bool FOLD>
 __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_kernel(fe* __restrict__ a, fe* __restrict__ b, fe* __restrict__ c,
                                                                      fe* __restrict__ eq, size_t len, fe_arg fold_arg,
                                                                      fe* __restrict__ partials, unsigned* __restrict__ ticket,
-                                                                     fe* __restrict__ result) {
+                                                                     fe* __restrict__ result, unsigned seq) {
     __shared__ uint4 smem[3 * RED_THREADS * 2];
     const fe alpha = from_arg(fold_arg);
     const size_t npairs = FOLD ? len / 4 : len / 2;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_kernel(fe* __restr
         // f_inf = (eq1-eq0)(a1-a0)(b1-b0)
         acc[2] = fe_add(acc[2], fe_mulx(fe_mulx(fe_sub(e1, e0), fe_sub(a1, a0)), fe_sub(b1, b0)));
     }
-    grid_finish_fe<3>(acc, smem, partials, ticket, result);
+    grid_finish_fe<3>(acc, smem, partials, ticket, result, seq);
 }
 
 // ---------------------------------------------------------------- W3: quadratic sumcheck round
@@ -234,7 +234,7 @@ template <bool FOLD>
 __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_kernel(const fe* __restrict__ f, const fe* __restrict__ w,
                                                                          size_t out_len, fe_arg fold_arg, fe* __restrict__ f_out,
                                                                          fe* __restrict__ w_out, fe* __restrict__ partials,
-                                                                         unsigned* __restrict__ ticket, fe* __restrict__ result) {
+                                                                         unsigned* __restrict__ ticket, fe* __restrict__ result, unsigned seq) {
     __shared__ uint4 smem[3 * RED_THREADS * 2];
     const fe r = from_arg(fold_arg);
     fe acc[3] = {fe_zero(), fe_zero(), fe_zero()};
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_kernel(const f
         acc[1] = fe_add(acc[1], fe_mulx(f1, w1));
         acc[2] = fe_add(acc[2], fe_mulx(fe_sub(fe_dbl(f1), f0), fe_sub(fe_dbl(w1), w0)));
     }
-    grid_finish_fe<3>(acc, smem, partials, ticket, result);
+    grid_finish_fe<3>(acc, smem, partials, ticket, result, seq);
 }
 // the single-element tail of the fold (out_len == 1): v'[0] = v[0] + r (v[1]-v[0]); no pair to sum
 __global__ void fold_pairs_kernel(const fe* __restrict__ v, fe* __restrict__ out, size_t out_len, fe_arg r_arg) {
@@ -280,7 +280,7 @@ __global__ void fold_pairs_kernel(const fe* __restrict__ v, fe* __restrict__ out
 template <int NV>
 __global__ __launch_bounds__(RED_THREADS) void dot_kernel(const fe* __restrict__ w, const fe* __restrict__ f, const fe* __restrict__ g,
                                                           size_t n, fe* __restrict__ partials, unsigned* __restrict__ ticket,
-                                                          fe* __restrict__ result) {
+                                                          fe* __restrict__ result, unsigned seq) {
     __shared__ uint4 smem[NV * RED_THREADS * 2];
     fe acc[NV];
 #pragma unroll
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(RED_THREADS) void dot_kernel(const fe* __restrict__
         acc[0] = fe_add(acc[0], fe_mulx(wi, fe_load(f + i)));
         if (NV == 2) acc[NV - 1] = fe_add(acc[NV - 1], fe_mulx(wi, fe_load(g + i)));
     }
-    grid_finish_fe<NV>(acc, smem, partials, ticket, result);
+    grid_finish_fe<NV>(acc, smem, partials, ticket, result, seq);
 }
 
 // ---------------------------------------------------------------- E1: univariate evaluation
@@ -308,7 +308,7 @@ __device__ __forceinline__ fe fe_pow_u64(fe base, u64 e) {
 }
 __global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restrict__ c, size_t n, fe_arg z_arg, fe_arg zT_arg,
                                                              fe* __restrict__ partials, unsigned* __restrict__ ticket,
-                                                             fe* __restrict__ result) {
+                                                             fe* __restrict__ result, unsigned seq) {
     __shared__ uint4 smem[RED_THREADS * 2];
     const fe z = from_arg(z_arg), zT = from_arg(zT_arg);
     const size_t T = (size_t)gridDim.x * blockDim.x;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restric
         for (size_t j = cnt - 1; j-- > 0;) h = fe_add(fe_mulx(h, zT), fe_load(c + g + j * T));
         acc[0] = fe_mulx(h, fe_pow_u64(z, (u64)g));
     }
-    grid_finish_fe<1>(acc, smem, partials, ticket, result);
+    grid_finish_fe<1>(acc, smem, partials, ticket, result, seq);
 }
 
 // ---------------------------------------------------------------- W1: coefficient fold
@@ -423,10 +423,10 @@ int pk_sumcheck_cubic_round(pk_ctx* ctx, uint64_t* d_a, uint64_t* d_b, uint64_t*
         ProfScope prof(ctx, "sumcheck_cubic");
         if (fold_or_null)
             sumcheck_cubic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, to_arg(fold_or_null),
-                                                                                  red_partials(ctx), red_ticket(ctx), red_result(ctx));
+                                                                                  red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
         else
             sumcheck_cubic_kernel<false><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, fe_arg{},
-                                                                                   red_partials(ctx), red_ticket(ctx), red_result(ctx));
+                                                                                   red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
     }
     PK_LAUNCH_CHECK(ctx);
     return collect_reduction<3>(ctx, out);
@@ -448,10 +448,10 @@ int pk_sumcheck_quadratic_round(pk_ctx* ctx, const uint64_t* d_f, const uint64_t
         if (fold_or_null)
             sumcheck_quadratic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, to_arg(fold_or_null),
                                                                                       (fe*)d_f_out, (fe*)d_w_out, red_partials(ctx), red_ticket(ctx),
-                                                                                      red_result(ctx));
+                                                                                      red_result(ctx), next_seq(ctx));
         else
             sumcheck_quadratic_kernel<false><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, fe_arg{}, nullptr, nullptr,
-                                                                                       red_partials(ctx), red_ticket(ctx), red_result(ctx));
+                                                                                       red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
     }
     PK_LAUNCH_CHECK(ctx);
     return collect_reduction<3>(ctx, out);
@@ -479,7 +479,7 @@ int pk_dot(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, size_t n, uint
     {
         ProfScope prof(ctx, "dot");
         dot_kernel<1><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_w, (const fe*)d_f, nullptr, n, red_partials(ctx), red_ticket(ctx),
-                                                               red_result(ctx));
+                                                               red_result(ctx), next_seq(ctx));
     }
     PK_LAUNCH_CHECK(ctx);
     return collect_reduction<1>(ctx, out);
@@ -498,7 +498,7 @@ int pk_dot2(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, const uint64_
     {
         ProfScope prof(ctx, "dot");
         dot_kernel<2><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_w, (const fe*)d_f, (const fe*)d_g, n, red_partials(ctx), red_ticket(ctx),
-                                                               red_result(ctx));
+                                                               red_result(ctx), next_seq(ctx));
     }
     PK_LAUNCH_CHECK(ctx);
     return collect_reduction<2>(ctx, out);
@@ -532,7 +532,7 @@ int pk_eval_univariate(pk_ctx* ctx, const uint64_t* d_coeffs, size_t n, const ui
     memcpy(zTa.v, zT.v, 32);
     {
         ProfScope prof(ctx, "eval_univariate");
-        horner_kernel<<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_coeffs, n, za, zTa, red_partials(ctx), red_ticket(ctx), red_result(ctx));
+        horner_kernel<<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_coeffs, n, za, zTa, red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
     }
     PK_LAUNCH_CHECK(ctx);
     return collect_reduction<1>(ctx, out);

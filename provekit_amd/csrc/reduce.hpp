@@ -1,11 +1,14 @@
 // reduce.hpp -- block / grid reduction of field-element sums (used by sumcheck, dot, Horner).
 #pragma once
+#include <atomic>
+
 #include "ctx.hpp"
 #include "fe.hpp"
 
 namespace pk {
 
 constexpr int RED_THREADS = 256;
+constexpr int PK_FLAG_WORD = 256;  // u32 index of the completion flag inside the pinned result page (byte 1024)
 constexpr int RED_MAX_BLOCKS = 1024;
 
 // Sum K field elements per thread across the block; result valid in thread 0.
@@ -40,41 +43,53 @@ __device__ __forceinline__ void block_reduce_fe(fe (&acc)[K], uint4* smem) {
 // draws the last ticket sums all partials and writes the K results (agent-scope release/acquire around the
 // ticket, MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility").  `result` may point to
 // device-visible pinned host memory, so the host needs no copy after the stream sync.
+// write-through (sc1) store / L1-bypassing load of one field element: the cross-workgroup hand-off uses these plus
+// `s_waitcnt vmcnt(0)` before the ticket, i.e. the microarch guide's "sc1 payload -> drained -> flag" form.  No
+// agent/system release fence: those write back the whole L2, which holds megabytes of freshly folded sumcheck data.
+__device__ __forceinline__ void fe_store_sc1(fe* p, const fe& x) {
+    unsigned* q = reinterpret_cast<unsigned*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; i++) __hip_atomic_store(q + i, x.v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ fe fe_load_sc1(const fe* p) {
+    fe v;
+    const unsigned* q = reinterpret_cast<const unsigned*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; i++) v.v[i] = __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+}
 template <int K>
 __device__ __forceinline__ void grid_finish_fe(fe (&acc)[K], uint4* smem, fe* __restrict__ partials, unsigned* __restrict__ ticket,
-                                               fe* __restrict__ result) {
+                                               fe* __restrict__ result, unsigned seq = 0) {
     __shared__ unsigned s_last;
     block_reduce_fe<K>(acc, smem);
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < K; k++) fe_store(partials + (size_t)blockIdx.x * K + k, acc[k]);
-        __threadfence();  // release the partials before the ticket
+        for (int k = 0; k < K; k++) fe_store_sc1(partials + (size_t)blockIdx.x * K + k, acc[k]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partials are out before the ticket is drawn
         unsigned t = atomicAdd(ticket, 1u);
         s_last = (t == gridDim.x - 1) ? 1u : 0u;
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();  // acquire: other blocks' partials
 #pragma unroll
     for (int k = 0; k < K; k++) acc[k] = fe_zero();
     for (unsigned b = threadIdx.x; b < gridDim.x; b += RED_THREADS) {
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            const fe* p = partials + (size_t)b * K + k;
-            fe v;  // bypass L1: the data was written by other CUs
-            const unsigned* q = reinterpret_cast<const unsigned*>(p);
-#pragma unroll
-            for (int i = 0; i < 8; i++) v.v[i] = __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            acc[k] = fe_add(acc[k], v);
-        }
+        for (int k = 0; k < K; k++) acc[k] = fe_add(acc[k], fe_load_sc1(partials + (size_t)b * K + k));
     }
     __syncthreads();
     block_reduce_fe<K>(acc, smem);
     if (threadIdx.x == 0) {
+        unsigned* out = reinterpret_cast<unsigned*>(result);  // pinned, fine-grained host memory
 #pragma unroll
-        for (int k = 0; k < K; k++) fe_store(result + k, acc[k]);
-        __threadfence_system();
-        *ticket = 0;  // re-arm for the next launch (stream order makes this safe)
+        for (int k = 0; k < K; k++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) __hip_atomic_store(out + 8 * k + i, acc[k].v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // publish: the host may spin on this word instead of paying a stream synchronisation
+        __hip_atomic_store(out + PK_FLAG_WORD, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -123,7 +138,15 @@ inline int reduction_scratch(pk_ctx* ctx) {
 inline fe* red_partials(pk_ctx* ctx) { return (fe*)ctx->d_scratch; }
 inline unsigned* red_ticket(pk_ctx* ctx) { return (unsigned*)((char*)ctx->d_scratch + (size_t)RED_MAX_BLOCKS * 8 * 32 + 8 * 32); }
 inline fe* red_result(pk_ctx* ctx) { return (fe*)ctx->h_pinned; }
-// wait for the kernel and hand the K results (already in pinned host memory) to the caller
+// next sequence number for a reduction launch on this context (never 0)
+inline unsigned next_seq(pk_ctx* ctx) {
+    ctx->red_seq++;
+    if (ctx->red_seq == 0) ctx->red_seq = 1;
+    return ctx->red_seq;
+}
+// Wait for the kernel and hand the K results -- already in pinned host memory -- to the caller.  (Spinning on the
+// completion word the finishing block publishes was measured: no gain over hipStreamSynchronize single-stream and a
+// loss with several provers per GPU, so the plain synchronisation is kept; the word stays for diagnostics.)
 template <int K>
 inline int collect_reduction(pk_ctx* ctx, uint64_t* host_out) {
     PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
