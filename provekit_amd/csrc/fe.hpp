@@ -1,11 +1,7 @@
 // fe.hpp -- BN254-Fr arithmetic for gfx950 device code.
 //
-// Replaces, on the GPU, the two multipliers the reference uses on the CPU:
-//   * ark-ff Fp256<MontBackend<.., 4>> (+,-,*)            -- SURVEY 8a row A2
-//   * block_multiplier::scalar_{mul,sqr}                   -- row A1
-//       (skyscraper/block-multiplier/src/scalar.rs:12-132)
-// Both compute a*b*2^-256 mod p; here it is one routine on 8 x 32-bit limbs so
-// that every partial product is a single v_mad_u64_u32 (32x32+64 -> 64).
+// The 256-bit element container, exact add/sub and conditional subtraction (ark-ff Fp256 + and -).
+// The multipliers (rows A1/A2: ark-ff mul, block_multiplier::scalar_{mul,sqr}) are in fe29.hpp.
 //
 // In-memory format is the reference's: 4 x u64 little-endian limbs, Montgomery
 // form, 32 B per element (== 8 x u32 little-endian).  Values held in registers
@@ -159,72 +155,7 @@ __host__ __device__ __forceinline__ bool fe_eq(const fe& a, const fe& b) {
     return d == 0;
 }
 
-// Montgomery product a*b*2^-256 mod p.  Requires a < 2^255, b < 2^255 (e.g. < 2p);
-// returns a value < 2p (LAZY) -- see SURVEY 8a row A1: the reference's scalar_mul
-// has the same contract ("[0,2P)" in, "< 2^256-2p" out).
-// CIOS on 32-bit limbs: 64 + 64 v_mad_u64_u32 and 8 v_mul_lo_u32.
-__host__ __device__ __forceinline__ fe mont_mul_lazy(const fe& a, const fe& b) {
-    u32 t[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            c += (u64)a.v[j] * b.v[i] + t[j];
-            t[j] = (u32)c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[8] = (u32)c;  // < 2^288 overall for a,b < 2^255: no further carry
-        u32 m = t[0] * PK_NP0;
-        c = (u64)m * PK_P0 + t[0];
-        c >>= 32;
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            c += (u64)m * kPlimb(j) + t[j];
-            t[j - 1] = (u32)c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[7] = (u32)c;
-        t[8] = (u32)(c >> 32);
-    }
-    fe r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = t[i];
-    return r;
-}
-__host__ __device__ __forceinline__ fe fe_mul(const fe& a, const fe& b) { return cond_sub_kp<1>(mont_mul_lazy(a, b)); }
-__host__ __device__ __forceinline__ fe fe_sqr(const fe& a) { return cond_sub_kp<1>(mont_mul_lazy(a, a)); }
-
-// Montgomery -> canonical: x*2^-256 mod p (reduction half only; into_bigint())
-__host__ __device__ __forceinline__ fe fe_from_mont(const fe& a) {
-    u32 t[9];
-#pragma unroll
-    for (int i = 0; i < 8; i++) t[i] = a.v[i];
-    t[8] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u32 m = t[0] * PK_NP0;
-        u64 c = (u64)m * PK_P0 + t[0];
-        c >>= 32;
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            c += (u64)m * kPlimb(j) + t[j];
-            t[j - 1] = (u32)c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[7] = (u32)c;
-        t[8] = (u32)(c >> 32);
-    }
-    fe r;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = t[i];
-    return cond_sub_kp<1>(r);
-}
-__host__ __device__ __forceinline__ fe fe_to_mont(const fe& a) { return fe_mul(a, fe_r2()); }
+// Multiplication lives in fe29.hpp (9 x 29-bit carry-free limbs); this header keeps the 256-bit container,
+// loads/stores and the carry-chain add/sub used where a value must be an exact canonical 8 x u32 integer.
 
 }  // namespace pk

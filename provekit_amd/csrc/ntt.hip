@@ -401,16 +401,11 @@ __global__ __launch_bounds__(256) void ntt_shard_prestep_kernel(const fe* __rest
     }
 }
 
-struct TwiddleCache {
-    std::map<unsigned, fe*> tables;  // log_n -> device table of 2^log_n entries
-};
-std::map<pk_ctx*, TwiddleCache> g_tw;
-
 int get_twiddles(pk_ctx* ctx, unsigned log_n, const fe** out) {
-    auto& tc = g_tw[ctx];
-    auto it = tc.tables.find(log_n);
-    if (it != tc.tables.end()) {
-        *out = it->second;
+    // per-context cache (a pk_ctx is single-caller, so no locking; distinct contexts never share tables)
+    auto it = ctx->twiddles.find(log_n);
+    if (it != ctx->twiddles.end()) {
+        *out = (const fe*)it->second;
         return PK_OK;
     }
     size_t n = (size_t)1 << log_n;
@@ -423,7 +418,7 @@ int get_twiddles(pk_ctx* ctx, unsigned log_n, const fe** out) {
         twiddle_double_kernel<<<grid, 256, 0, ctx->stream>>>(W, h);
     }
     PK_LAUNCH_CHECK(ctx);
-    tc.tables[log_n] = W;
+    ctx->twiddles[log_n] = W;
     *out = W;
     return PK_OK;
 }
@@ -484,10 +479,8 @@ int launch_pass(pk_ctx* ctx, unsigned log_r, const PassParams& p, bool in_r_cont
 namespace pk {
 
 void ntt_release_ctx(pk_ctx* ctx) {
-    auto it = g_tw.find(ctx);
-    if (it == g_tw.end()) return;
-    for (auto& kv : it->second.tables) (void)hipFree(kv.second);
-    g_tw.erase(it);
+    for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
+    ctx->twiddles.clear();
 }
 
 // Column-batched NTT, natural -> natural.  `ncols` vectors of length N = 2^log_n:

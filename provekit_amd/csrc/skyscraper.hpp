@@ -1,13 +1,8 @@
-// skyscraper.hpp -- Skyscraper two-to-one compression on gfx950.
-//
-// Semantics: skyscraper/core/src/reference.rs:41-98 (v2) and v1.rs:19-32 (v1; only
-// needed to replay the reference's stale proof fixture).  Structure follows
-// skyscraper/core/src/generic.rs:77-102: one lane computes one compression; the
-// 18 Feistel rounds are fully unrolled so every round constant is an immediate.
-//
-// Values are canonical integers (NOT Montgomery): the hash squares with a
-// Montgomery product, which is exactly sq(x) = x^2 * 2^-256 mod p
-// (reference.rs:22-26: SIGMA_INV == 2^-256).
+// skyscraper.hpp -- Skyscraper constants shared by host and device code: the round
+// constants (skyscraper/core/src/constants.rs:30-49) and the byte S-box (bar.rs:40-67).  The compression itself
+// (reference.rs:41-98 v2, v1.rs:19-32 v1; structure of generic.rs:77-102) is in skyscraper29.hpp.
+// Values are canonical integers (NOT Montgomery): the hash squares with a Montgomery product, which is exactly
+// sq(x) = x^2 * 2^-256 mod p (reference.rs:22-26: SIGMA_INV == 2^-256).
 #pragma once
 #include "fe.hpp"
 
@@ -45,94 +40,6 @@ __host__ __device__ __forceinline__ u32 sbox4(u32 v) {
     u32 t3 = ((v & 0xe0e0e0e0u) >> 5) | ((v & 0x1f1f1f1fu) << 3);
     u32 x = (~t1 & t2 & t3) ^ v;
     return ((x & 0x80808080u) >> 7) | ((x & 0x7f7f7f7fu) << 1);
-}
-
-// bar: canonical x in [0,p) -> canonical [0,p)   (reference.rs:80-94, bar.rs:15-31)
-__device__ __forceinline__ fe bar(const fe& x) {
-    fe y;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        y.v[i] = sbox4(x.v[i + 4]);
-        y.v[i + 4] = sbox4(x.v[i]);
-    }
-    return fe_reduce_any(y);
-}
-
-// (l, r) <- (r + F(l) + RC, l), all values kept canonical in [0,p)
-template <int RCI, bool BAR>
-__device__ __forceinline__ void sky_round(fe& l, fe& r) {
-    fe f = BAR ? bar(l) : fe_sqr(l);
-    // s = r + f + rc < 3p < 2^256
-    fe s;
-    u32 c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        u64 t = (u64)r.v[i] + f.v[i] + c;
-        s.v[i] = (u32)t;
-        c = (u32)(t >> 32);
-    }
-    if (RCI != 0 && RCI != 17) {
-        c = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            u64 t = (u64)s.v[i] + rc_limb(RCI, i) + c;
-            s.v[i] = (u32)t;
-            c = (u32)(t >> 32);
-        }
-        s = cond_sub_kp<2>(s);
-    }
-    r = l;
-    l = cond_sub_kp<1>(s);
-}
-
-// Skyscraper v2 compress on canonical inputs < p (generic.rs:77-102)
-__device__ __forceinline__ fe compress_reduced(const fe& l_in, const fe& r_in) {
-    fe l = l_in, r = r_in;
-    sky_round<0, false>(l, r);
-    sky_round<1, false>(l, r);
-    sky_round<2, false>(l, r);
-    sky_round<3, false>(l, r);
-    sky_round<4, false>(l, r);
-    sky_round<5, false>(l, r);
-    sky_round<6, true>(l, r);
-    sky_round<7, true>(l, r);
-    sky_round<8, false>(l, r);
-    sky_round<9, false>(l, r);
-    sky_round<10, true>(l, r);
-    sky_round<11, true>(l, r);
-    sky_round<12, false>(l, r);
-    sky_round<13, false>(l, r);
-    sky_round<14, false>(l, r);
-    sky_round<15, false>(l, r);
-    sky_round<16, false>(l, r);
-    sky_round<17, false>(l, r);
-    return fe_add(l, l_in);
-}
-// any 256-bit inputs (the reference accepts them: generic.rs:81-82 reduce_partial)
-__device__ __forceinline__ fe compress_any(const fe& l, const fe& r) {
-    return compress_reduced(fe_reduce_any(l), fe_reduce_any(r));
-}
-
-// Skyscraper v1 (v1.rs:19-32): 10 rounds [sq,sq,bar,bar,sq,sq,bar,bar,sq,sq], RC[1..8]
-__device__ __forceinline__ fe compress_v1_reduced(const fe& l_in, const fe& r_in) {
-    fe l = l_in, r = r_in;
-    sky_round<0, false>(l, r);
-    sky_round<1, false>(l, r);
-    sky_round<2, true>(l, r);
-    sky_round<3, true>(l, r);
-    sky_round<4, false>(l, r);
-    sky_round<5, false>(l, r);
-    sky_round<6, true>(l, r);
-    sky_round<7, true>(l, r);
-    sky_round<8, false>(l, r);
-    sky_round<0, false>(l, r);
-    return fe_add(l, l_in);
-}
-
-template <int VERSION>
-__device__ __forceinline__ fe compress_v(const fe& l, const fe& r) {
-    if (VERSION == 1) return compress_v1_reduced(l, r);
-    return compress_reduced(l, r);
 }
 
 }  // namespace pk
