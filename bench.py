@@ -363,8 +363,8 @@ def main():
                 "unit": "proofs/s",
                 "cores": threads,
                 "kind": "port",
-                "sample": f"1 step of the same workload (m={m}) through oracle/pk_oracle.c with OpenMP on {threads} threads; "
-                          "serial stages (sumcheck, SpMV, eq) run on one core as in the reference; 2^8 blinding WHIR omitted",
+                "sample": f"1 step of the same workload (m={m}) through oracle/pk_oracle.c, OpenMP on {threads} threads wherever the reference "
+                          "uses rayon (commit, sumcheck, eq, sums); SpMV serial as in the reference; 2^8 blinding WHIR omitted",
             }
         print(json.dumps(line))
     if dist is not None:

@@ -1,8 +1,10 @@
 /*
  * pk_oracle.c -- CPU restatement of the ProveKit WHIR hot path.
  * TEST INFRASTRUCTURE ONLY (see pk_oracle.h header comment for the rules and
- * the pinning status). Plain C11 + unsigned __int128; OpenMP only for the
- * cpu_baseline timing leg.
+ * the pinning status). Plain C11 + unsigned __int128.  OpenMP marks the loops the
+ * reference parallelises with rayon (par_iter / rayon::join: sumcheck.rs:53,83,163,185;
+ * ark MerkleTree's `parallel` feature) so the cpu_baseline leg is a fair all-cores run;
+ * the sparse mat-vecs stay serial as in sparse_matrix.rs:148,167 ("OPT: Paralelize").
  */
 #include "pk_oracle.h"
 
@@ -441,19 +443,26 @@ void pko_eval_univariate(const u64 *c, size_t n, const u64 z[4], u64 out[4]) {
 static void eq_accumulate(const u64 *point, unsigned m, const u64 scalar[4], u64 *out) {
     /* recursion of eval_eq unrolled level by level into a scratch table */
     size_t n = (size_t)1 << m;
-    u64 *t = (u64 *)malloc(32 * n);
+    u64 *t = (u64 *)malloc(32);
     memcpy(t, scalar, 32);
     for (unsigned j = 0; j < m; j++) {
         size_t cur = (size_t)1 << j;
-        for (size_t i = cur; i-- > 0;) {
+        /* the recursion's halves are independent (rayon::join in the reference): write level j+1 into a second buffer */
+        u64 *t2 = (u64 *)malloc(64 * cur);
+#pragma omp parallel for schedule(static) if (cur >= 1024)
+        for (long ii = 0; ii < (long)cur; ii++) {
+            size_t i = (size_t)ii;
             u64 s1[4], s0[4];
             pko_fe_mul(t + 4 * i, point + 4 * j, s1); /* s1 = scalar * x   */
             pko_fe_sub(t + 4 * i, s1, s0);             /* s0 = scalar - s1  */
-            memcpy(t + 4 * (2 * i), s0, 32);
-            memcpy(t + 4 * (2 * i + 1), s1, 32);
+            memcpy(t2 + 4 * (2 * i), s0, 32);
+            memcpy(t2 + 4 * (2 * i + 1), s1, 32);
         }
+        free(t);
+        t = t2;
     }
-    for (size_t i = 0; i < n; i++) pko_fe_add(out + 4 * i, t + 4 * i, out + 4 * i); /* out[0] += scalar */
+#pragma omp parallel for schedule(static) if (n >= 1024)
+    for (long ii = 0; ii < (long)n; ii++) pko_fe_add(out + 4 * ii, t + 4 * ii, out + 4 * ii); /* out[0] += scalar */
     free(t);
 }
 void pko_eq_table(const u64 *r, unsigned m, u64 *out) {
@@ -491,7 +500,9 @@ int pko_sumcheck_cubic_round(u64 *a, u64 *b, u64 *c, u64 *eq, size_t len, const 
     if (fold) { /* sumcheck.rs:92-97 */
         size_t q = len / 4;
         for (int k = 0; k < 4; k++)
-            for (size_t i = 0; i < q; i++) {
+#pragma omp parallel for schedule(static) if (q >= 1024)
+            for (long ii = 0; ii < (long)q; ii++) {
+                size_t i = (size_t)ii;
                 u64 d[4];
                 pko_fe_sub(m[k] + 4 * (2 * q + i), m[k] + 4 * i, d);
                 pko_fe_mul(fold, d, d);
@@ -508,33 +519,39 @@ int pko_sumcheck_cubic_round(u64 *a, u64 *b, u64 *c, u64 *eq, size_t len, const 
     }
     u64 acc[3][4];
     memset(acc, 0, sizeof acc);
-    for (size_t i = 0; i < npairs; i++) { /* prover/src/whir_r1cs.rs:284-291 */
-        const u64 *a0 = a + 4 * i, *a1 = a + 4 * (i + off);
-        const u64 *b0 = b + 4 * i, *b1 = b + 4 * (i + off);
-        const u64 *c0 = c + 4 * i, *c1 = c + 4 * (i + off);
-        const u64 *e0 = eq + 4 * i, *e1 = eq + 4 * (i + off);
-        u64 t[4], u[4], v[4], w[4];
-        /* f0 = eq0 * (a0*b0 - c0) */
-        pko_fe_mul(a0, b0, t);
-        pko_fe_sub(t, c0, t);
-        pko_fe_mul(e0, t, t);
-        pko_fe_add(acc[0], t, acc[0]);
-        /* f_em1 = (2eq0-eq1) * ((2a0-a1)(2b0-b1) - (2c0-c1)) */
-        dbl_sub(a0, a1, u);
-        dbl_sub(b0, b1, v);
-        pko_fe_mul(u, v, t);
-        dbl_sub(c0, c1, w);
-        pko_fe_sub(t, w, t);
-        dbl_sub(e0, e1, u);
-        pko_fe_mul(u, t, t);
-        pko_fe_add(acc[1], t, acc[1]);
-        /* f_inf = (eq1-eq0)(a1-a0)(b1-b0) */
-        pko_fe_sub(e1, e0, u);
-        pko_fe_sub(a1, a0, v);
-        pko_fe_mul(u, v, t);
-        pko_fe_sub(b1, b0, v);
-        pko_fe_mul(t, v, t);
-        pko_fe_add(acc[2], t, acc[2]);
+#pragma omp parallel
+    {
+        u64 loc[3][4];
+        memset(loc, 0, sizeof loc);
+#pragma omp for schedule(static) nowait
+        for (long ii = 0; ii < (long)npairs; ii++) { /* prover/src/whir_r1cs.rs:284-291 */
+            size_t i = (size_t)ii;
+            const u64 *a0 = a + 4 * i, *a1 = a + 4 * (i + off);
+            const u64 *b0 = b + 4 * i, *b1 = b + 4 * (i + off);
+            const u64 *c0 = c + 4 * i, *c1 = c + 4 * (i + off);
+            const u64 *e0 = eq + 4 * i, *e1 = eq + 4 * (i + off);
+            u64 t[4], u[4], v[4], w[4];
+            pko_fe_mul(a0, b0, t);
+            pko_fe_sub(t, c0, t);
+            pko_fe_mul(e0, t, t);
+            pko_fe_add(loc[0], t, loc[0]);
+            dbl_sub(a0, a1, u);
+            dbl_sub(b0, b1, v);
+            pko_fe_mul(u, v, t);
+            dbl_sub(c0, c1, w);
+            pko_fe_sub(t, w, t);
+            dbl_sub(e0, e1, u);
+            pko_fe_mul(u, t, t);
+            pko_fe_add(loc[1], t, loc[1]);
+            pko_fe_sub(e1, e0, u);
+            pko_fe_sub(a1, a0, v);
+            pko_fe_mul(u, v, t);
+            pko_fe_sub(b1, b0, v);
+            pko_fe_mul(t, v, t);
+            pko_fe_add(loc[2], t, loc[2]);
+        }
+#pragma omp critical
+        for (int k = 0; k < 3; k++) pko_fe_add(acc[k], loc[k], acc[k]);
     }
     memcpy(out, acc, 96);
     return 0;
@@ -581,14 +598,22 @@ int pko_spmv_t(size_t num_rows, size_t num_cols, const uint32_t *nri, const uint
     return 0;
 }
 void pko_hadamard(const u64 *a, const u64 *b, u64 *c, size_t n) {
-    for (size_t i = 0; i < n; i++) pko_fe_mul(a + 4 * i, b + 4 * i, c + 4 * i);
+#pragma omp parallel for schedule(static) if (n >= 1024)
+    for (long i = 0; i < (long)n; i++) pko_fe_mul(a + 4 * i, b + 4 * i, c + 4 * i);
 }
 void pko_dot(const u64 *w, const u64 *f, size_t n, u64 out[4]) {
     u64 acc[4] = {0, 0, 0, 0};
-    for (size_t i = 0; i < n; i++) {
-        u64 t[4];
-        pko_fe_mul(w + 4 * i, f + 4 * i, t);
-        pko_fe_add(acc, t, acc);
+#pragma omp parallel
+    {
+        u64 loc[4] = {0, 0, 0, 0};
+#pragma omp for schedule(static) nowait
+        for (long i = 0; i < (long)n; i++) {
+            u64 t[4];
+            pko_fe_mul(w + 4 * i, f + 4 * i, t);
+            pko_fe_add(loc, t, loc);
+        }
+#pragma omp critical
+        pko_fe_add(acc, loc, acc);
     }
     memcpy(out, acc, 32);
 }
@@ -602,22 +627,33 @@ void pko_fold_coeffs(const u64 *coeffs, unsigned n_vars, const u64 *r, unsigned 
     memcpy(tmp, coeffs, 32 * n);
     for (unsigned b = 0; b < k; b++) { /* MultivarPoly: vars[0] <-> index bit 0 (utilities.go:15-22) */
         n >>= 1;
-        for (size_t i = 0; i < n; i++) {
+        u64 *nx = (u64 *)malloc(32 * (n ? n : 1));
+#pragma omp parallel for schedule(static) if (n >= 1024)
+        for (long ii = 0; ii < (long)n; ii++) {
+            size_t i = (size_t)ii;
             u64 t[4];
             pko_fe_mul(tmp + 4 * (2 * i + 1), r + 4 * b, t);
-            pko_fe_add(tmp + 4 * (2 * i), t, tmp + 4 * i);
+            pko_fe_add(tmp + 4 * (2 * i), t, nx + 4 * i);
         }
+        free(tmp);
+        tmp = nx;
     }
     memcpy(out, tmp, 32 * n);
     free(tmp);
 }
 void pko_fold_pairs(u64 *v, size_t len, const u64 r[4]) {
-    for (size_t i = 0; i < len / 2; i++) {
+    size_t h = len / 2;
+    u64 *tmp = (u64 *)malloc(32 * (h ? h : 1));
+#pragma omp parallel for schedule(static) if (h >= 1024)
+    for (long ii = 0; ii < (long)h; ii++) {
+        size_t i = (size_t)ii;
         u64 d[4];
         pko_fe_sub(v + 4 * (2 * i + 1), v + 4 * (2 * i), d);
         pko_fe_mul(d, r, d);
-        pko_fe_add(v + 4 * (2 * i), d, v + 4 * i);
+        pko_fe_add(v + 4 * (2 * i), d, tmp + 4 * i);
     }
+    memcpy(v, tmp, 32 * h);
+    free(tmp);
 }
 int pko_sumcheck_quadratic_round(u64 *f, u64 *w, size_t len, const u64 *fold, u64 out[12]) {
     if (len < 1 || (len & (len - 1))) return -1;
@@ -630,17 +666,26 @@ int pko_sumcheck_quadratic_round(u64 *f, u64 *w, size_t len, const u64 *fold, u6
     if (len < 2) return -1;
     u64 acc[3][4];
     memset(acc, 0, sizeof acc);
-    for (size_t i = 0; i < len / 2; i++) {
-        const u64 *f0 = f + 8 * i, *f1 = f + 8 * i + 4, *w0 = w + 8 * i, *w1 = w + 8 * i + 4;
-        u64 t[4], u[4], v[4];
-        pko_fe_mul(f0, w0, t);
-        pko_fe_add(acc[0], t, acc[0]);
-        pko_fe_mul(f1, w1, t);
-        pko_fe_add(acc[1], t, acc[1]);
-        dbl_sub(f1, f0, u); /* f(2) = 2 f1 - f0 */
-        dbl_sub(w1, w0, v);
-        pko_fe_mul(u, v, t);
-        pko_fe_add(acc[2], t, acc[2]);
+#pragma omp parallel
+    {
+        u64 loc[3][4];
+        memset(loc, 0, sizeof loc);
+#pragma omp for schedule(static) nowait
+        for (long ii = 0; ii < (long)(len / 2); ii++) {
+            size_t i = (size_t)ii;
+            const u64 *f0 = f + 8 * i, *f1 = f + 8 * i + 4, *w0 = w + 8 * i, *w1 = w + 8 * i + 4;
+            u64 t[4], u[4], v[4];
+            pko_fe_mul(f0, w0, t);
+            pko_fe_add(loc[0], t, loc[0]);
+            pko_fe_mul(f1, w1, t);
+            pko_fe_add(loc[1], t, loc[1]);
+            dbl_sub(f1, f0, u); /* f(2) = 2 f1 - f0 */
+            dbl_sub(w1, w0, v);
+            pko_fe_mul(u, v, t);
+            pko_fe_add(loc[2], t, loc[2]);
+        }
+#pragma omp critical
+        for (int k = 0; k < 3; k++) pko_fe_add(acc[k], loc[k], acc[k]);
     }
     memcpy(out, acc, 96);
     return 0;
