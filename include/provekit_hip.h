@@ -145,6 +145,9 @@ int pk_ntt(pk_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, unsigned log_n, u
  * inverse, in place over 2^n_vars FEs: for every index bit h, v[i|h] -= v[i] (resp. +=). */
 int pk_to_coeffs(pk_ctx *ctx, uint64_t *d_evals, unsigned n_vars);
 int pk_to_evals(pk_ctx *ctx, uint64_t *d_coeffs, unsigned n_vars);
+/* out-of-place forms (d_src untouched; saves the copy when both forms are needed, whir_r1cs.rs:193-198) */
+int pk_to_coeffs_into(pk_ctx *ctx, const uint64_t *d_src, uint64_t *d_dst, unsigned n_vars);
+int pk_to_evals_into(pk_ctx *ctx, const uint64_t *d_src, uint64_t *d_dst, unsigned n_vars);
 
 /* ------------------------------------------------------------------ S2 / W2: equality-polynomial tables
  * calculate_evaluations_over_boolean_hypercube_for_eq / eval_eq

@@ -78,6 +78,8 @@ SIGNATURES = {
     "pk_ntt": (C.c_int, [vp, vp, vp, C.c_uint, C.c_uint]),
     "pk_to_coeffs": (C.c_int, [vp, vp, C.c_uint]),
     "pk_to_evals": (C.c_int, [vp, vp, C.c_uint]),
+    "pk_to_coeffs_into": (C.c_int, [vp, vp, vp, C.c_uint]),
+    "pk_to_evals_into": (C.c_int, [vp, vp, vp, C.c_uint]),
     "pk_eq_table": (C.c_int, [vp, vp, C.c_uint, vp]),
     "pk_eq_accumulate": (C.c_int, [vp, vp, C.c_uint, vp, vp, C.c_uint, C.c_int]),
     "pk_sumcheck_cubic_round": (C.c_int, [vp, vp, vp, vp, vp, sz, vp, vp]),

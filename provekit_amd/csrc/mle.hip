@@ -45,14 +45,15 @@ __device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, int i, const fe& x
 // variable (index bit) h: v[i | h] -= v[i].  SUB=false gives the inverse (to_evals).
 // low kernel: bits [0, LOGT) on a contiguous tile of 2^LOGT elements held in LDS.
 template <bool SUB>
-__global__ __launch_bounds__(256) void wavelet_low_kernel(fe* __restrict__ data, unsigned logt) {
+__global__ __launch_bounds__(256) void wavelet_low_kernel(const fe* src, fe* data, unsigned logt) {
     extern __shared__ uint4 lds[];
     const int T = 1 << logt;
     uint4* lo = lds;
     uint4* hi = lds + T;
     fe* base = data + (size_t)blockIdx.x * T;
+    const fe* sbase = src + (size_t)blockIdx.x * T;  // src == data for the in-place form
     for (int e = threadIdx.x; e < T; e += 256) {
-        const uint4* q = reinterpret_cast<const uint4*>(base + e);
+        const uint4* q = reinterpret_cast<const uint4*>(sbase + e);
         lo[e] = q[0];
         hi[e] = q[1];
     }
@@ -74,10 +75,9 @@ __global__ __launch_bounds__(256) void wavelet_low_kernel(fe* __restrict__ data,
     }
 }
 // high kernel: bits [s, s+logr): element index = u*2^(s+logr) + r*2^s + v; tile = [2^logr][4 adjacent v]
-template <bool SUB>
+template <bool SUB, int BT>
 __global__ __launch_bounds__(256) void wavelet_high_kernel(fe* __restrict__ data, unsigned s, unsigned logr) {
     extern __shared__ uint4 lds[];
-    constexpr int BT = 4;
     const int R = 1 << logr;
     const int TILE = R * BT;
     uint4* lo = lds;
@@ -111,25 +111,38 @@ __global__ __launch_bounds__(256) void wavelet_high_kernel(fe* __restrict__ data
     }
 }
 
+// d_src == nullptr: in place; otherwise the first sweep reads d_src and writes d_data (saves a 32 B/element copy)
 template <bool SUB>
-int wavelet(pk_ctx* ctx, uint64_t* d_data, unsigned n_vars) {
+int wavelet(pk_ctx* ctx, const uint64_t* d_src, uint64_t* d_data, unsigned n_vars) {
     PK_REQUIRE(ctx, d_data, "null pointer");
     PK_REQUIRE(ctx, n_vars <= 30, "too many variables");
-    if (n_vars == 0) return PK_OK;
-    ProfScope prof(ctx, SUB ? "to_coeffs" : "to_evals");
     fe* D = (fe*)d_data;
+    const fe* S = d_src ? (const fe*)d_src : D;
+    if (n_vars == 0) {
+        if (d_src && d_src != d_data) PK_HIP(ctx, hipMemcpyAsync(D, S, 32, hipMemcpyDeviceToDevice, ctx->stream));
+        return PK_OK;
+    }
+    ProfScope prof(ctx, SUB ? "to_coeffs" : "to_evals");
     unsigned logt = n_vars < 11 ? n_vars : 11;
     size_t lds = ((size_t)2 << logt) * 16;
     PK_HIP(ctx, hipFuncSetAttribute((const void*)wavelet_low_kernel<SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 16));
-    wavelet_low_kernel<SUB><<<(unsigned)((size_t)1 << (n_vars - logt)), 256, lds, ctx->stream>>>(D, logt);
+    wavelet_low_kernel<SUB><<<(unsigned)((size_t)1 << (n_vars - logt)), 256, lds, ctx->stream>>>(S, D, logt);
     unsigned s = logt;
-    PK_HIP(ctx, hipFuncSetAttribute((const void*)wavelet_high_kernel<SUB>, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 16));
+    PK_HIP(ctx, hipFuncSetAttribute((const void*)wavelet_high_kernel<SUB, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 16));
+    PK_HIP(ctx, hipFuncSetAttribute((const void*)wavelet_high_kernel<SUB, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 1 << 16));
     while (s < n_vars) {
-        unsigned logr = n_vars - s < 9 ? n_vars - s : 9;
-        size_t tiles = ((size_t)1 << (n_vars - logr)) / 4;
-        size_t l2 = ((size_t)2 << logr) * 4 * 16;
-        wavelet_high_kernel<SUB><<<(unsigned)tiles, 256, l2, ctx->stream>>>(D, s, logr);
-        s += logr;
+        // up to 10 index bits per sweep (2^10 rows x 2 adjacent elements = 64 KiB of LDS), 9 with 4-element rows otherwise
+        unsigned left = n_vars - s;
+        if (left == 10 && s >= 1) {
+            size_t tiles = ((size_t)1 << (n_vars - 10)) / 2;
+            wavelet_high_kernel<SUB, 2><<<(unsigned)tiles, 256, ((size_t)2 << 10) * 2 * 16, ctx->stream>>>(D, s, 10);
+            s += 10;
+        } else {
+            unsigned logr = left < 9 ? left : 9;
+            size_t tiles = ((size_t)1 << (n_vars - logr)) / 4;
+            wavelet_high_kernel<SUB, 4><<<(unsigned)tiles, 256, ((size_t)2 << logr) * 4 * 16, ctx->stream>>>(D, s, logr);
+            s += logr;
+        }
     }
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
@@ -365,11 +378,22 @@ extern "C" {
 
 int pk_to_coeffs(pk_ctx* ctx, uint64_t* d_evals, unsigned n_vars) {
     if (!ctx) return PK_ERR_BAD_ARG;
-    return wavelet<true>(ctx, d_evals, n_vars);
+    return wavelet<true>(ctx, nullptr, d_evals, n_vars);
 }
 int pk_to_evals(pk_ctx* ctx, uint64_t* d_coeffs, unsigned n_vars) {
     if (!ctx) return PK_ERR_BAD_ARG;
-    return wavelet<false>(ctx, d_coeffs, n_vars);
+    return wavelet<false>(ctx, nullptr, d_coeffs, n_vars);
+}
+// out-of-place forms: d_dst receives the transform of d_src (which is left untouched)
+int pk_to_coeffs_into(pk_ctx* ctx, const uint64_t* d_src, uint64_t* d_dst, unsigned n_vars) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, d_src && d_src != d_dst, "source must differ from destination");
+    return wavelet<true>(ctx, d_src, d_dst, n_vars);
+}
+int pk_to_evals_into(pk_ctx* ctx, const uint64_t* d_src, uint64_t* d_dst, unsigned n_vars) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, d_src && d_src != d_dst, "source must differ from destination");
+    return wavelet<false>(ctx, d_src, d_dst, n_vars);
 }
 
 int pk_eq_accumulate(pk_ctx* ctx, uint64_t* d_w, unsigned n_vars, const uint64_t* points, const uint64_t* scales, unsigned q,

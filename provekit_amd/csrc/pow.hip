@@ -100,8 +100,9 @@ int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
     memcpy(th.v, thr, 32);
     unsigned long long best = ~0ull, base = 0;
     PK_HIP(ctx, hipMemcpyAsync(d_best, &best, 8, hipMemcpyHostToDevice, ctx->stream));
-    // first window = 8x the expected work (miss probability e^-8), then doubling; never more lanes than nonces
-    unsigned wbits = (unsigned)bits + 3;
+    // first window = 2x the expected work (miss probability e^-2; a miss costs one more round trip), then doubling:
+    // ~2.7x the expected hashes on average instead of a fixed large window; never more lanes than nonces
+    unsigned wbits = (unsigned)bits + 1;
     if (wbits < 12) wbits = 12;
     if (wbits > 26) wbits = 26;
     unsigned long long window = 1ull << wbits;

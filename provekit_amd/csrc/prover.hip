@@ -270,8 +270,7 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
     ALLOC(w0, N);
     ALLOC(w1, N / 2 ? N / 2 : 1);
     bp_[0] = p0; bp_[1] = p1; bw_[0] = w0; bw_[1] = w1;
-    CK(pk_memcpy_d2d(ctx, p0, d_c, 32 * N));
-    CK(pk_to_evals(ctx, U(p0), n));
+    CK(pk_to_evals_into(ctx, U(d_c), U(p0), n));
     // initial combination randomness; weights = sum gamma^i w_i over [OOD constraints..., statement weights...]
     fe gamma = T.challenge_scalar();
     fe g = fe_one();
@@ -462,13 +461,12 @@ int batch_commit(pk_ctx* ctx, Arena& A, unsigned m, const pk_whir_config& cfg, c
     random_fe_kernel<<<grid_for(ctx, half, 256), 256, 0, ctx->stream>>>(f + half, half, seed);
     random_fe_kernel<<<grid_for(ctx, N, 256), 256, 0, ctx->stream>>>(g, N, seed ^ 0xa5a5a5a5a5a5a5a5ULL);
     PK_LAUNCH_CHECK(ctx);
-    CK(pk_memcpy_d2d(ctx, fe_, f, 32 * N));
-    CK(pk_memcpy_d2d(ctx, ge_, g, 32 * N));
-    CK(pk_to_coeffs(ctx, U(f), m));
-    CK(pk_to_coeffs(ctx, U(g), m));
-    out.f_evals = fe_;
-    out.g_evals = ge_;
-    fe* polys[2] = {f, g};
+    // f, g hold the evaluation forms (kept for the weighted sums); the coefficient forms go to fc, gc
+    CK(pk_to_coeffs_into(ctx, U(f), U(fe_), m));
+    CK(pk_to_coeffs_into(ctx, U(g), U(ge_), m));
+    out.f_evals = f;
+    out.g_evals = g;
+    fe* polys[2] = {fe_, ge_};
     return whir_commit(ctx, A, cfg, polys, 2, T, out.com);
 }
 

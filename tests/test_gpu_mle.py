@@ -255,3 +255,19 @@ def test_axpy(ctx, oracle):
     sc.axpy(ctx, dy, beta, ctx.upload(x), n)
     exp = oracle.binop("pko_fe_add", y, oracle.binop("pko_fe_mul", x, np.tile(beta, (n, 1))))
     assert np.array_equal(ctx.download_fe(dy, n), exp)
+
+
+@pytest.mark.parametrize("n_vars", [0, 5, 12, 21])
+def test_to_coeffs_out_of_place(ctx, oracle, n_vars):
+    from provekit_amd._lib import lib
+    from provekit_amd.field import random_field
+
+    ev = random_field(1 << n_vars, 333 + n_vars)
+    src, dst, ref = ctx.upload(ev), ctx.alloc_fe(1 << n_vars), ctx.upload(ev)
+    ctx._check(lib.pk_to_coeffs_into(ctx.handle, src.ptr, dst.ptr, n_vars))
+    ctx._check(lib.pk_to_coeffs(ctx.handle, ref.ptr, n_vars))
+    assert np.array_equal(ctx.download_fe(dst, 1 << n_vars), ctx.download_fe(ref, 1 << n_vars))
+    assert np.array_equal(ctx.download_fe(src, 1 << n_vars), ev)  # source untouched
+    back = ctx.alloc_fe(1 << n_vars)
+    ctx._check(lib.pk_to_evals_into(ctx.handle, dst.ptr, back.ptr, n_vars))
+    assert np.array_equal(ctx.download_fe(back, 1 << n_vars), ev)
