@@ -60,6 +60,23 @@ def leaf_hash_bytes(cfg_list):
     return total, launches
 
 
+def ntt_roofline(prof, steps, m, cfg_w, cfg_b):
+    """RS-encode kernels (deinterleave + NTT passes) of one proof, one proof at a time: 64 B per codeword element."""
+    elems = 0
+    for n_vars, batch, rounds in ((m, 2, cfg_w.n_rounds), (cfg_b.n_vars, 2, cfg_b.n_rounds)):
+        rows = 1 << (n_vars + 1 - 4)
+        elems += rows * 16 * batch
+        for _ in range(rounds):
+            rows >>= 1
+            elems += rows * 16
+    ms = sum(prof.get(k, (0, 0.0))[1] for k in ("ntt_pass", "ntt_pass_last", "deinterleave")) / max(steps, 1)
+    achieved = 64.0 * elems / (ms * 1e-3) / 1e9 if ms else 0.0
+    return {"kernels": "deinterleave_kernel + ntt8_pass_kernel (all RS-encodes of one proof)", "bound": "hbm", "achieved": achieved,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "ms_per_proof": ms,
+            "algorithmic_bytes_per_proof": 64.0 * elems,
+            "note": "integer-ALU bound: ~0.5*log2(N)+passes modular multiplies per element (DESIGN.md 4)"}
+
+
 def cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg):
     """The same step through the CPU oracle (oracle/pk_oracle.c, OpenMP over the host cores) -- a reported
     baseline only.  The 2^8 blinding WHIR (microseconds of work) is left out; everything else is the full size."""
@@ -67,13 +84,13 @@ def cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg):
     import oracle_lib as o
     from provekit_amd.field import random_field
 
-    t0 = time.perf_counter()
     half = 1 << (m - 1)
     z = random_field(n_wit, 1)
+    mask, g = random_field(half, 2), random_field(2 * half, 3)  # input / RNG generation stays outside the timed region
+    t0 = time.perf_counter()
     f = np.zeros((2 * half, 4), np.uint64)
     f[:n_wit] = z
-    f[half:] = random_field(half, 2)
-    g = random_field(2 * half, 3)
+    f[half:] = mask
     fc, gc = o.to_coeffs(f, m), o.to_coeffs(g, m)
     leaves = o.rs_encode(np.concatenate([fc, gc]), 2, m, 1, 4)
     o.merkle_commit(leaves)
@@ -102,12 +119,12 @@ def cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg):
         o.dot(w, f), o.dot(w, g)
     # WHIR opening
     beta = random_field(1, 7)[0]
-    cw = o.binop("pko_fe_add", fc, o.hadamard(gc, np.tile(beta, (2 * half, 1))))
+    cw = o.vec_axpy(fc, beta, gc)
     p = o.to_evals(cw, m)
     one = o.to_mont(o.ints_to_limbs([1]))[0]
     w = o.eq_accumulate_univariate(np.zeros((2 * half, 4), np.uint64), m, zpt, one)
     for x in ws:
-        w = o.binop("pko_fe_add", w, x)
+        w = o.vec_add(w, x)
 
     def rounds(p, w, k):
         rs, fold = [], None
@@ -353,6 +370,9 @@ def main():
                     "note": "same kernel, one proof at a time (untimed extra pass)",
                 },
             },
+            # BASELINE.json's metric also asks for achieved HBM GB/s on the WHIR NTT: algorithmic bytes = 64 B per codeword
+            # element (one logical read + write) over the measured time of all encode kernels of a proof
+            "roofline_ntt": ntt_roofline(prof_iso, iso_steps, m, cfg_w, cfg_b),
             "single_stream": {"ms_per_proof": 1e3 * iso_dt, "proofs_per_s": 1.0 / iso_dt},
             "stage_ms_per_step": stage_ms,
         }

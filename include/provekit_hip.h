@@ -43,6 +43,7 @@ extern "C" {
 #define PK_ERR_HIP (-3)
 #define PK_ERR_RCCL (-4)
 #define PK_ERR_NO_DEVICE (-5)
+#define PK_ERR_UNSATISFIED (-6) /* pk_r1cs_test_witness_satisfaction: a constraint failed */
 
 /* leaf-matrix layouts: element (leaf i, column j) lives at */
 #define PK_LEAF_MAJOR 0 /* i*width + j : ark / whir order (a leaf is contiguous)        */
@@ -218,6 +219,11 @@ int pk_r1cs_matvec(pk_ctx *ctx, const pk_r1cs *r1cs, int matrix, int transpose, 
 /* calculate_external_row_of_r1cs_matrices (sumcheck.rs:207-218): d_out = [eq^T A | eq^T B | eq^T C],
  * 3 * num_witnesses FEs; d_eq_alpha holds at least num_constraints FEs */
 int pk_r1cs_external_row(pk_ctx *ctx, const pk_r1cs *r1cs, const uint64_t *d_eq_alpha, uint64_t *d_out);
+/* R1CSSolver::test_witness_satisfaction (provekit/prover/src/r1cs.rs:41-60): PK_OK when (A z) o (B z) == C z;
+ * otherwise PK_ERR_UNSATISFIED with *first_failed_row = the lowest failing row ("Constraint {row} failed") -- -1 on
+ * success.  n_witness != num_witnesses is PK_ERR_BAD_ARG ("Witness size does not match").  Synchronises the stream. */
+int pk_r1cs_test_witness_satisfaction(pk_ctx *ctx, const pk_r1cs *r1cs, const uint64_t *d_witness, size_t n_witness,
+                                      int64_t *first_failed_row);
 
 /* ------------------------------------------------------------------ P1: proof of work
  * spongefish_pow::PowStrategy for Skyscraper (provekit/common/src/skyscraper/pow.rs:14-30):

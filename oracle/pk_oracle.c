@@ -601,6 +601,19 @@ void pko_hadamard(const u64 *a, const u64 *b, u64 *c, size_t n) {
 #pragma omp parallel for schedule(static) if (n >= 1024)
     for (long i = 0; i < (long)n; i++) pko_fe_mul(a + 4 * i, b + 4 * i, c + 4 * i);
 }
+void pko_vec_add(const u64 *a, const u64 *b, u64 *c, size_t n) {
+#pragma omp parallel for schedule(static) if (n >= 1024)
+    for (long i = 0; i < (long)n; i++) pko_fe_add(a + 4 * i, b + 4 * i, c + 4 * i);
+}
+/* c = a + s*b: the batching combination whir_r1cs.rs / whir batching use on whole vectors */
+void pko_vec_axpy(const u64 *a, const u64 s[4], const u64 *b, u64 *c, size_t n) {
+#pragma omp parallel for schedule(static) if (n >= 1024)
+    for (long i = 0; i < (long)n; i++) {
+        u64 t[4];
+        pko_fe_mul(s, b + 4 * i, t);
+        pko_fe_add(a + 4 * i, t, c + 4 * i);
+    }
+}
 void pko_dot(const u64 *w, const u64 *f, size_t n, u64 out[4]) {
     u64 acc[4] = {0, 0, 0, 0};
 #pragma omp parallel

@@ -107,6 +107,8 @@ int pko_spmv_t(size_t num_rows, size_t num_cols, const uint32_t *new_row_indices
 void pko_hadamard(const uint64_t *a, const uint64_t *b, uint64_t *c, size_t n);
 
 /* ---- S5: Weights::linear(..).weighted_sum (prover/src/whir_r1cs.rs:401-405) ---- */
+void pko_vec_add(const uint64_t *a, const uint64_t *b, uint64_t *c, size_t n);
+void pko_vec_axpy(const uint64_t *a, const uint64_t s[4], const uint64_t *b, uint64_t *c, size_t n);
 void pko_dot(const uint64_t *w, const uint64_t *f, size_t n, uint64_t out[4]);
 
 /* ---- W1: coefficient fold by k challenges (whir_utilities.go:180-186; utilities.go:15-22)

@@ -15,7 +15,7 @@ PK_OK = 0
 PK_LEAF_MAJOR = 0
 PK_COL_MAJOR = 1
 
-_ERR_NAMES = {-1: "PK_ERR_BAD_ARG", -2: "PK_ERR_OOM", -3: "PK_ERR_HIP", -4: "PK_ERR_RCCL", -5: "PK_ERR_NO_DEVICE"}
+_ERR_NAMES = {-1: "PK_ERR_BAD_ARG", -2: "PK_ERR_OOM", -3: "PK_ERR_HIP", -4: "PK_ERR_RCCL", -5: "PK_ERR_NO_DEVICE", -6: "PK_ERR_UNSATISFIED"}
 
 
 class ProveKitHipError(RuntimeError):
@@ -95,6 +95,7 @@ SIGNATURES = {
     "pk_r1cs_witness_bounds": (C.c_int, [vp, vp, vp, C.c_uint, vp, vp, vp]),
     "pk_r1cs_matvec": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),
     "pk_r1cs_external_row": (C.c_int, [vp, vp, vp, vp]),
+    "pk_r1cs_test_witness_satisfaction": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(C.c_int64)]),
     "pk_pow_threshold": (C.c_int, [C.c_double, vp]),
     "pk_pow_solve": (C.c_int, [vp, vp, C.c_double, C.POINTER(C.c_uint64)]),
     "pk_pow_check": (C.c_int, [vp, vp, C.c_double, C.c_uint64, C.POINTER(C.c_int)]),

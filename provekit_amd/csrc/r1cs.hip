@@ -57,6 +57,20 @@ __global__ __launch_bounds__(256) void sparse_gather_kernel(const uint32_t* ptr,
     fe_store(y + i, sparse_row_dot(ptr, idx, val, interner, x, i));
 }
 
+// R1CS::test_witness_satisfaction (provekit/prover/src/r1cs.rs:41-60): (A z)_i (B z)_i == (C z)_i for every row; the first
+// failing row (the one the reference's "Constraint {row} failed" names) is reduced with an atomic min.
+__global__ __launch_bounds__(256) void satisfaction_kernel(const uint32_t* pa, const uint32_t* ia, const uint32_t* va, const uint32_t* pb,
+                                                           const uint32_t* ib, const uint32_t* vb, const uint32_t* pc, const uint32_t* ic,
+                                                           const uint32_t* vc, const fe* __restrict__ interner, const fe* __restrict__ z,
+                                                           size_t num_rows, unsigned long long* __restrict__ first_bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= num_rows) return;
+    fe ra = sparse_row_dot(pa, ia, va, interner, z, i);
+    fe rb = sparse_row_dot(pb, ib, vb, interner, z, i);
+    fe rc = sparse_row_dot(pc, ic, vc, interner, z, i);
+    if (!fe_eq(fe_mulx(ra, rb), rc)) atomicMin(first_bad, (unsigned long long)i);
+}
+
 int upload_u32(pk_ctx* ctx, const std::vector<uint32_t>& v, uint32_t** out) {
     PK_HIP(ctx, hipMalloc((void**)out, (v.size() ? v.size() : 1) * 4));
     if (!v.empty()) PK_HIP(ctx, hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
@@ -162,6 +176,34 @@ int pk_r1cs_matvec(pk_ctx* ctx, const pk_r1cs* r, int matrix, int transpose, con
     ProfScope prof(ctx, "sparse_matvec");
     sparse_gather_kernel<<<(unsigned)((n_out + 255) / 256), 256, 0, ctx->stream>>>(ptr, idx, val, r->d_interner, (const fe*)d_x, n_out, (fe*)d_y);
     PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+int pk_r1cs_test_witness_satisfaction(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_witness, size_t n_witness, int64_t* first_failed_row) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, r && first_failed_row, "null pointer");
+    PK_REQUIRE(ctx, n_witness == r->num_witnesses, "Witness size does not match");  // r1cs.rs:42-45
+    *first_failed_row = -1;
+    if (!r->num_constraints) return PK_OK;
+    PK_REQUIRE(ctx, d_witness, "null pointer");
+    int rc = ensure_scratch(ctx, 8);
+    if (rc) return rc;
+    unsigned long long* d_bad = (unsigned long long*)ctx->d_scratch;
+    PK_HIP(ctx, hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
+    {
+        ProfScope prof(ctx, "r1cs_satisfaction");
+        satisfaction_kernel<<<(unsigned)((r->num_constraints + 255) / 256), 256, 0, ctx->stream>>>(
+            r->csr_ptr[0], r->csr_idx[0], r->csr_val[0], r->csr_ptr[1], r->csr_idx[1], r->csr_val[1], r->csr_ptr[2], r->csr_idx[2], r->csr_val[2],
+            r->d_interner, (const fe*)d_witness, r->num_constraints, d_bad);
+        PK_LAUNCH_CHECK(ctx);
+    }
+    unsigned long long bad = 0;
+    PK_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad != ~0ull) {
+        *first_failed_row = (int64_t)bad;
+        return set_err(ctx, PK_ERR_UNSATISFIED, "Constraint %llu failed", bad);  // r1cs.rs:57
+    }
     return PK_OK;
 }
 

@@ -72,3 +72,16 @@ class R1CS:
         out = self.ctx.alloc_fe(max(n_out, 1))
         self.ctx._check(lib.pk_r1cs_matvec(self.ctx.handle, self.handle, matrix, int(transpose), d_x.ptr if isinstance(d_x, DeviceBuffer) else d_x, out.ptr))
         return out
+
+    def test_witness_satisfaction(self, d_witness, n_witness: int | None = None):
+        """R1CSSolver::test_witness_satisfaction (provekit/prover/src/r1cs.rs:41-60): raises ProveKitHipError
+        ("Constraint {row} failed", .row = first failing row) unless (A z) o (B z) == C z."""
+        from ._lib import ProveKitHipError
+
+        row = C.c_int64(-1)
+        n = self.num_witnesses if n_witness is None else n_witness
+        try:
+            self.ctx._check(lib.pk_r1cs_test_witness_satisfaction(self.ctx.handle, self.handle, d_witness.ptr if isinstance(d_witness, DeviceBuffer) else d_witness, n, C.byref(row)))
+        except ProveKitHipError as e:
+            e.row = row.value
+            raise

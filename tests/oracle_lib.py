@@ -60,6 +60,20 @@ def binop(name, a, b):
     return out
 
 
+def vec_add(a, b):
+    a, b = fe_arr(a).reshape(-1, 4), fe_arr(b).reshape(-1, 4)
+    out = np.empty_like(a)
+    L.pko_vec_add(_p(a), _p(b), _p(out), C.c_size_t(a.shape[0]))
+    return out
+
+
+def vec_axpy(a, s, b):
+    a, b, s = fe_arr(a).reshape(-1, 4), fe_arr(b).reshape(-1, 4), fe_arr(s).reshape(4)
+    out = np.empty_like(a)
+    L.pko_vec_axpy(_p(a), _p(s), _p(b), _p(out), C.c_size_t(a.shape[0]))
+    return out
+
+
 def to_mont(a):
     a = fe_arr(a).reshape(-1, 4)
     out = np.empty_like(a)

@@ -1,0 +1,53 @@
+"""CPU: the `.np` proof container (provekit/common/src/file/{mod,bin}.rs): header bytes as in the reference's fixture,
+round trip, the error conditions of read_bin, and -- when the reference tree is mounted -- decoding the real fixture."""
+import hashlib
+import os
+
+import pytest
+
+FIXTURE = "/root/reference/tooling/provekit-bench/benches/poseidon-1000.np"
+# first 20 bytes of tooling/provekit-bench/benches/poseidon-1000.np
+FIXTURE_HEADER = bytes([0xDC, 0xDF, 0x4F, 0x5A, 0x6B, 0x70, 0x01, 0x00]) + b"NPSProof" + b"\x00\x00\x00\x00"
+FIXTURE_TRANSCRIPT_LEN = 268756
+
+
+def test_header_and_roundtrip(tmp_path):
+    from provekit_amd.file import decode_np, encode_np, read_np, write_np
+
+    t = os.urandom(70000) + bytes(1000)
+    blob = encode_np(t)
+    assert blob[:20] == FIXTURE_HEADER
+    assert decode_np(blob) == t
+    p = tmp_path / "proof.np"
+    write_np(str(p), t)
+    assert read_np(str(p)) == t
+    assert decode_np(encode_np(b"")) == b""
+
+
+def test_read_errors(tmp_path):
+    from provekit_amd.file import decode_np, encode_np, write_np
+
+    blob = bytearray(encode_np(b"abc"))
+    with pytest.raises(ValueError, match="magic"):
+        decode_np(b"\x00" + bytes(blob[1:]))
+    bad = bytes(blob[:8]) + b"NrProScm" + bytes(blob[16:])
+    with pytest.raises(ValueError, match="format"):
+        decode_np(bad)
+    bad = bytes(blob[:16]) + b"\x01\x00" + bytes(blob[18:])
+    with pytest.raises(ValueError, match="major"):
+        decode_np(bad)
+    with pytest.raises(ValueError):
+        decode_np(bytes(blob[:-3]))
+    with pytest.raises(ValueError, match="extension"):
+        write_np(str(tmp_path / "proof.bin"), b"abc")
+
+
+@pytest.mark.skipif(not os.path.exists(FIXTURE), reason="reference tree not mounted (GPU box)")
+def test_decodes_the_reference_fixture():
+    from provekit_amd.file import decode_np, encode_np
+
+    raw = open(FIXTURE, "rb").read()
+    assert raw[:20] == FIXTURE_HEADER
+    t = decode_np(raw)
+    assert len(t) == FIXTURE_TRANSCRIPT_LEN
+    assert decode_np(encode_np(t)) == t

@@ -118,3 +118,38 @@ def test_prove_rejects_wrong_witness_length(ctx, oracle):
         ctx._check(lib.pk_prove(ctx.handle, scheme.handle, d.ptr, nw - 1, 1, scheme._buf, len(scheme._buf), C.byref(n)))
     with pytest.raises(ProveKitHipError):  # scheme capacity (whir_r1cs.rs:47-54)
         WhirR1CSScheme(ctx, r1cs, 5, 5, WhirConfig.for_size(5, 0.0), blinding_config_for(5, 0.0))
+
+
+def test_witness_satisfaction(ctx, oracle):
+    """pk_r1cs_test_witness_satisfaction == R1CSSolver::test_witness_satisfaction (provekit/prover/src/r1cs.rs:41-60):
+    Ok for a satisfying witness; "Constraint {row} failed" with the FIRST failing row otherwise; length check."""
+    import pyref as pr
+    from provekit_amd import ProveKitHipError
+    from provekit_amd.sparse_matrix import R1CS
+
+    nc = 3000
+    nw, z, coeffs, trips = satisfiable_r1cs(nc, 500, 11)
+    r1cs = R1CS(ctx, *(to_sparse(nc, nw, t) for t in trips), oracle.to_mont(oracle.ints_to_limbs(coeffs)))
+    up = lambda v: ctx.upload(oracle.to_mont(oracle.ints_to_limbs(v)))
+    r1cs.test_witness_satisfaction(up(z))
+    # break two outputs: rows 1700 and 2900 (output witness of row i is z[1 + n_in + i]); later rows that READ those
+    # outputs may also fail, so the first failing row is exactly 1700 only if no earlier row reads z[1+500+1700] -- true,
+    # rows only read earlier outputs
+    zb = list(z)
+    zb[1 + 500 + 2900] = (zb[1 + 500 + 2900] + 1) % pr.P
+    zb[1 + 500 + 1700] = (zb[1 + 500 + 1700] + 5) % pr.P
+    with pytest.raises(ProveKitHipError, match="Constraint 1700 failed") as ei:
+        r1cs.test_witness_satisfaction(up(zb))
+    assert ei.value.row == 1700 and ei.value.code == -6
+    # oracle agrees row by row: first row with (Az)(Bz) != Cz
+    mats = [(np.array(t[0]), np.array(t[1]), [coeffs[v] for v in t[2]]) for t in trips]
+    def mv(M):
+        out = [0] * nc
+        for r, c, v in zip(*M):
+            out[int(r)] = (out[int(r)] + v * zb[int(c)]) % pr.P
+        return out
+    a, b, c = mv(mats[0]), mv(mats[1]), mv(mats[2])
+    assert next(i for i in range(nc) if a[i] * b[i] % pr.P != c[i]) == 1700
+    with pytest.raises(ProveKitHipError, match="Witness size does not match"):
+        r1cs.test_witness_satisfaction(up(z), n_witness=nw - 1)
+    r1cs.close()
