@@ -302,6 +302,9 @@ int pk_selftest_permute(uint64_t l[4], uint64_t r[4]);
 int pk_selftest_arith(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
 /* the same ops run by a kernel on device buffers (device-vs-host codegen diff in the GPU suite) */
 int pk_selftest_arith_device(pk_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n);
+/* measurement aid (SURVEY 8d "measured_peak_modmul_per_s"): rate of register-resident 9x29-bit Montgomery squarings,
+ * ilp (1|2|4) independent chains per lane, waves_per_simd (1..8) resident waves, iters squarings per chain */
+int pk_selftest_modmul_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double *modmul_per_s);
 
 #ifdef __cplusplus
 }

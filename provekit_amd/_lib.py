@@ -114,6 +114,7 @@ SIGNATURES = {
     "pk_selftest_permute": (C.c_int, [vp, vp]),
     "pk_selftest_arith": (C.c_int, [C.c_int, vp, vp, vp, sz]),
     "pk_selftest_arith_device": (C.c_int, [vp, C.c_int, vp, vp, vp, sz]),
+    "pk_selftest_modmul_rate": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),
 }
 
 

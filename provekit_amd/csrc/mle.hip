@@ -204,7 +204,7 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_kernel(fe* __restr
                                                                      fe* __restrict__ eq, size_t len, fe_arg fold_arg,
                                                                      fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                                      fe* __restrict__ result, unsigned seq) {
-    __shared__ uint4 smem[3 * RED_THREADS * 2];
+    __shared__ uint4 smem[3 * 16];
     const fe alpha = from_arg(fold_arg);
     const size_t npairs = FOLD ? len / 4 : len / 2;
     const size_t off = npairs;          // partner of i is i + off (quarter 1 after folding, or the upper half)
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_kernel(const f
                                                                          size_t out_len, fe_arg fold_arg, fe* __restrict__ f_out,
                                                                          fe* __restrict__ w_out, fe* __restrict__ partials,
                                                                          unsigned* __restrict__ ticket, fe* __restrict__ result, unsigned seq) {
-    __shared__ uint4 smem[3 * RED_THREADS * 2];
+    __shared__ uint4 smem[3 * 16];
     const fe r = from_arg(fold_arg);
     fe acc[3] = {fe_zero(), fe_zero(), fe_zero()};
     const size_t npairs = out_len / 2;
@@ -294,7 +294,7 @@ template <int NV>
 __global__ __launch_bounds__(RED_THREADS) void dot_kernel(const fe* __restrict__ w, const fe* __restrict__ f, const fe* __restrict__ g,
                                                           size_t n, fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                           fe* __restrict__ result, unsigned seq) {
-    __shared__ uint4 smem[NV * RED_THREADS * 2];
+    __shared__ uint4 smem[NV * 16];
     fe acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++) acc[k] = fe_zero();
@@ -322,7 +322,7 @@ __device__ __forceinline__ fe fe_pow_u64(fe base, u64 e) {
 __global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restrict__ c, size_t n, fe_arg z_arg, fe_arg zT_arg,
                                                              fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                              fe* __restrict__ result, unsigned seq) {
-    __shared__ uint4 smem[RED_THREADS * 2];
+    __shared__ uint4 smem[16];
     const fe z = from_arg(z_arg), zT = from_arg(zT_arg);
     const size_t T = (size_t)gridDim.x * blockDim.x;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -344,15 +344,12 @@ struct fold_args {
 __global__ __launch_bounds__(256) void fold_coeffs_kernel(const fe* __restrict__ c, size_t n_out, unsigned k, fold_args ra,
                                                           fe* __restrict__ out) {
     __shared__ uint4 wts[256 * 2];
-    // weights for j in [0, 2^k): built by doubling
-    if (threadIdx.x == 0) {
-        uint4* lo = wts;
-        uint4* hi = wts + 256;
-        lds_put(lo, hi, 0, fe_one());
-        for (unsigned b = 0; b < k; b++) {
-            fe rb = from_arg(ra.r[b]);
-            for (int j = 0; j < (1 << b); j++) lds_put(lo, hi, (1 << b) + j, fe_mulx(lds_get(lo, hi, j), rb));
-        }
+    // weight j = prod_b r_b^{bit_b(j)}: thread j builds its own with at most k multiplications (no serial doubling pass)
+    if (threadIdx.x < (1u << k)) {
+        fe w = fe_one();
+        for (unsigned b = 0; b < k; b++)
+            if ((threadIdx.x >> b) & 1u) w = fe_mulx(w, from_arg(ra.r[b]));
+        lds_put(wts, wts + 256, threadIdx.x, w);
     }
     __syncthreads();
     const int fw = 1 << k;

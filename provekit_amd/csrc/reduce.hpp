@@ -11,41 +11,106 @@ constexpr int RED_THREADS = 256;
 constexpr int PK_FLAG_WORD = 256;  // u32 index of the completion flag inside the pinned result page (byte 1024)
 constexpr int RED_MAX_BLOCKS = 1024;
 
-// Sum K field elements per thread across the block; result valid in thread 0.
-// smem must hold K * RED_THREADS fe (as 2 uint4 each).
-template <int K>
-__device__ __forceinline__ void block_reduce_fe(fe (&acc)[K], uint4* smem) {
-    const unsigned tid = threadIdx.x;
+// ---- wide sums ----------------------------------------------------------------------------------------------------
+// A sum of up to 1024 field elements is carried as 8 independent u64 limb sums (each < 2^42): adding two of them is 8
+// plain 64-bit adds, no carry chain and no conditional subtraction, so the 6 shuffle steps of a wavefront reduction cost
+// a quarter of what fe_add-based steps did.  One modular reduction at the very end.
+struct wide {
+    u64 l[8];
+};
+__device__ __forceinline__ wide wide_zero() {
+    wide w;
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-        smem[(k * RED_THREADS + tid) * 2] = make_uint4(acc[k].v[0], acc[k].v[1], acc[k].v[2], acc[k].v[3]);
-        smem[(k * RED_THREADS + tid) * 2 + 1] = make_uint4(acc[k].v[4], acc[k].v[5], acc[k].v[6], acc[k].v[7]);
+    for (int i = 0; i < 8; i++) w.l[i] = 0;
+    return w;
+}
+__device__ __forceinline__ void wide_add_fe(wide& w, const fe& x) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) w.l[i] += x.v[i];
+}
+// limb sums of at most 1024 values < p  ->  the sum mod p, fully reduced
+__host__ __device__ __forceinline__ fe wide_reduce(const wide& w) {
+    u32 a[9];
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += w.l[i];
+        a[i] = (u32)c;
+        c >>= 32;
     }
-    __syncthreads();
-    for (unsigned s = RED_THREADS / 2; s >= 1; s >>= 1) {
-        if (tid < s) {
+    a[8] = (u32)c;  // total < 2^10 p < 2^264
+    // quotient estimate from the top 40 bits: 2^256 / p = 5.2901... > 1354 / 256, so q never overshoots and is at most 2 short
+    const u64 hi = ((u64)a[8] << 32) | a[7];
+    const u32 q = (u32)((hi * 1354u) >> 40);
+    u64 mc = 0;
+    u32 borrow = 0;
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                uint4 l = smem[(k * RED_THREADS + tid + s) * 2], h = smem[(k * RED_THREADS + tid + s) * 2 + 1];
-                fe o;
-                o.v[0] = l.x; o.v[1] = l.y; o.v[2] = l.z; o.v[3] = l.w;
-                o.v[4] = h.x; o.v[5] = h.y; o.v[6] = h.z; o.v[7] = h.w;
-                acc[k] = fe_add(acc[k], o);
-                smem[(k * RED_THREADS + tid) * 2] = make_uint4(acc[k].v[0], acc[k].v[1], acc[k].v[2], acc[k].v[3]);
-                smem[(k * RED_THREADS + tid) * 2 + 1] = make_uint4(acc[k].v[4], acc[k].v[5], acc[k].v[6], acc[k].v[7]);
-            }
+    for (int i = 0; i < 9; i++) {
+        mc += (u64)q * (i < 8 ? kPlimb(i) : 0u);
+        u64 t = (u64)a[i] - (u32)mc - borrow;
+        a[i] = (u32)t;
+        borrow = (u32)(t >> 32) & 1u;
+        mc >>= 32;
+    }
+#pragma unroll
+    for (int rep = 0; rep < 3; rep++) {  // remainder < 3p + p
+        u32 d[9];
+        u32 b = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            u64 t = (u64)a[i] - (i < 8 ? kPlimb(i) : 0u) - b;
+            d[i] = (u32)t;
+            b = (u32)(t >> 32) & 1u;
         }
-        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 9; i++) a[i] = b ? a[i] : d[i];
     }
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = a[i];
+    return r;
 }
 
-// Single-launch grid reduction: every block stores its K partial sums, takes a ticket, and the block that
-// draws the last ticket sums all partials and writes the K results (agent-scope release/acquire around the
-// ticket, MI355X_MICROARCH.md "Workgroup dispatch ... inter-workgroup visibility").  `result` may point to
-// device-visible pinned host memory, so the host needs no copy after the stream sync.
-// write-through (sc1) store / L1-bypassing load of one field element: the cross-workgroup hand-off uses these plus
-// `s_waitcnt vmcnt(0)` before the ticket, i.e. the microarch guide's "sc1 payload -> drained -> flag" form.  No
-// agent/system release fence: those write back the whole L2, which holds megabytes of freshly folded sumcheck data.
+__device__ __forceinline__ u64 shfl_down_u64(u64 x, unsigned off) {
+    u32 lo = __shfl_down((u32)x, off, 64), hi = __shfl_down((u32)(x >> 32), off, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+// Sum K wide values per thread across the 256-thread block.  Returns the reduced sum number k in thread k (k < K);
+// other threads return garbage.  smem: at least 4*K*8 u64 (the callers' K*256 fe buffer is far larger).
+template <int K>
+__device__ __forceinline__ fe block_reduce_wide(wide (&w)[K], uint4* smem) {
+#pragma unroll
+    for (unsigned off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < K; k++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) w[k].l[i] += shfl_down_u64(w[k].l[i], off);
+    }
+    u64* sm = reinterpret_cast<u64*>(smem);
+    const unsigned tid = threadIdx.x, wave = tid >> 6;
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) sm[(k * 4 + wave) * 8 + i] = w[k].l[i];
+    }
+    __syncthreads();
+    wide t = wide_zero();
+    if (tid < K) {
+#pragma unroll
+        for (int v = 0; v < RED_THREADS / 64; v++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) t.l[i] += sm[(tid * 4 + v) * 8 + i];
+    }
+    return wide_reduce(t);
+}
+
+// Single-launch grid reduction: every block stores its K partial sums (write-through, sc1), drains them
+// (`s_waitcnt vmcnt(0)`), takes a ticket, and the block that draws the last ticket sums all partials and writes the K
+// results to `result` -- device-visible pinned host memory, so the host needs no copy after the stream sync.  This is the
+// microarch guide's "sc1 payload -> drained -> flag" hand-off; no agent/system release fence, which would write back the
+// whole L2 holding megabytes of freshly folded sumcheck data.
 __device__ __forceinline__ void fe_store_sc1(fe* p, const fe& x) {
     unsigned* q = reinterpret_cast<unsigned*>(p);
 #pragma unroll
@@ -61,68 +126,44 @@ __device__ __forceinline__ fe fe_load_sc1(const fe* p) {
 template <int K>
 __device__ __forceinline__ void grid_finish_fe(fe (&acc)[K], uint4* smem, fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                fe* __restrict__ result, unsigned seq = 0) {
+    static_assert(K <= 64, "the K results live in the first wavefront");
     __shared__ unsigned s_last;
-    block_reduce_fe<K>(acc, smem);
-    if (threadIdx.x == 0) {
+    wide w[K];
 #pragma unroll
-        for (int k = 0; k < K; k++) fe_store_sc1(partials + (size_t)blockIdx.x * K + k, acc[k]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // partials are out before the ticket is drawn
-        unsigned t = atomicAdd(ticket, 1u);
-        s_last = (t == gridDim.x - 1) ? 1u : 0u;
+    for (int k = 0; k < K; k++) {
+        w[k] = wide_zero();
+        wide_add_fe(w[k], acc[k]);
+    }
+    fe mine = block_reduce_wide<K>(w, smem);  // thread k holds sum k
+    const unsigned tid = threadIdx.x;
+    if (tid < 64) {                           // the first wavefront: lanes < K store, then lane 0 draws the ticket
+        if (tid < K) fe_store_sc1(partials + (size_t)blockIdx.x * K + tid, mine);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's partials are out before the ticket is drawn
+        if (tid == 0) {
+            unsigned t = atomicAdd(ticket, 1u);
+            s_last = (t == gridDim.x - 1) ? 1u : 0u;
+        }
     }
     __syncthreads();
     if (!s_last) return;
 #pragma unroll
-    for (int k = 0; k < K; k++) acc[k] = fe_zero();
-    for (unsigned b = threadIdx.x; b < gridDim.x; b += RED_THREADS) {
+    for (int k = 0; k < K; k++) w[k] = wide_zero();
+    for (unsigned b = tid; b < gridDim.x; b += RED_THREADS) {  // gridDim.x <= RED_MAX_BLOCKS: at most 4 per thread
 #pragma unroll
-        for (int k = 0; k < K; k++) acc[k] = fe_add(acc[k], fe_load_sc1(partials + (size_t)b * K + k));
+        for (int k = 0; k < K; k++) wide_add_fe(w[k], fe_load_sc1(partials + (size_t)b * K + k));
     }
-    __syncthreads();
-    block_reduce_fe<K>(acc, smem);
-    if (threadIdx.x == 0) {
+    mine = block_reduce_wide<K>(w, smem);
+    if (tid < 64) {
         unsigned* out = reinterpret_cast<unsigned*>(result);  // pinned, fine-grained host memory
+        if (tid < K) {
 #pragma unroll
-        for (int k = 0; k < K; k++)
-#pragma unroll
-            for (int i = 0; i < 8; i++) __hip_atomic_store(out + 8 * k + i, acc[k].v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
+            for (int i = 0; i < 8; i++) __hip_atomic_store(out + 8 * tid + i, mine.v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm for the next launch
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // publish: the host may spin on this word instead of paying a stream synchronisation
-        __hip_atomic_store(out + PK_FLAG_WORD, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) __hip_atomic_store(out + PK_FLAG_WORD, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-}
-
-// second stage: sum `nblocks` partial K-vectors (layout partials[block*K + k]) into out[k]
-template <int K>
-__global__ __launch_bounds__(RED_THREADS) void reduce_partials_kernel(const fe* __restrict__ partials, unsigned nblocks,
-                                                                      fe* __restrict__ out) {
-    __shared__ uint4 smem[K * RED_THREADS * 2];
-    fe acc[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) acc[k] = fe_zero();
-    for (unsigned b = threadIdx.x; b < nblocks; b += RED_THREADS) {
-#pragma unroll
-        for (int k = 0; k < K; k++) acc[k] = fe_add(acc[k], fe_load(partials + (size_t)b * K + k));
-    }
-    block_reduce_fe<K>(acc, smem);
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < K; k++) fe_store(out + k, acc[k]);
-    }
-}
-
-// host helper: finish a K-vector reduction whose per-block partials sit at ctx->d_scratch[0 .. nblocks*K)
-// and copy the K results to `host_out` (synchronises the stream).
-template <int K>
-inline int finish_reduction(pk_ctx* ctx, unsigned nblocks, uint64_t* host_out) {
-    fe* partials = (fe*)ctx->d_scratch;
-    fe* result = partials + (size_t)RED_MAX_BLOCKS * 8;
-    reduce_partials_kernel<K><<<1, RED_THREADS, 0, ctx->stream>>>(partials, nblocks, result);
-    PK_LAUNCH_CHECK(ctx);
-    PK_HIP(ctx, hipMemcpyAsync(host_out, result, 32 * K, hipMemcpyDeviceToHost, ctx->stream));
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PK_OK;
 }
 
 inline int reduction_scratch(pk_ctx* ctx) {

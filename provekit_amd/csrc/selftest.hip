@@ -1,6 +1,7 @@
 // selftest.hip -- host-side execution of the exact __host__ __device__ arithmetic the kernels use
 // (fe29.hpp, skyscraper29.hpp), so the CPU test suite can check it against the oracle without a GPU.
 #include "ctx.hpp"
+#include "reduce.hpp"
 #include "skyscraper29.hpp"
 #include "transcript.hpp"
 
@@ -34,6 +35,12 @@ PK_HD fe selftest_op(int op, const fe& x, const fe& y) {
         case 11: r = pack29(mont261_29(unpack29<0>(x), unpack29<0>(y))); break;
         case 12: r = pack29(cond_sub_p29(unpack29<0>(x))); break;
         case 13: r = pack29(bar29(unpack29<0>(x))); break;
+        case 14: {  // wide_reduce (reduce.hpp): 700*x + 324*y as limb sums, the 1024-term worst case of a grid reduction
+            wide w;
+            for (int i = 0; i < 8; i++) w.l[i] = 700ull * x.v[i] + 324ull * y.v[i];
+            r = wide_reduce(w);
+            break;
+        }
         default: break;
     }
     return r;
@@ -46,7 +53,54 @@ __global__ void selftest_kernel(int op, const fe* a, const fe* b, fe* out, size_
     fe_store(out + i, selftest_op(op, x, y));
 }
 
+// peak-rate probe for SURVEY 8d's second roofline ("achieved modmul/s over measured peak modmul/s"): ILP independent
+// register-resident chains of the 9x29-bit Montgomery squaring the hash and NTT kernels use, nothing else.
+template <int ILP>
+__global__ __launch_bounds__(256) void modmul_rate_kernel(const fe* __restrict__ in, fe* __restrict__ out, unsigned iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    fe29 x[ILP];
+#pragma unroll
+    for (int k = 0; k < ILP; k++) {
+        x[k] = unpack_reduce29(fe_load(in + (i % 64)));
+        x[k].v[0] += (u32)k;
+    }
+    for (unsigned it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < ILP; k++) x[k] = sqr256_29(x[k]);
+    }
+    fe29 acc = x[0];
+#pragma unroll
+    for (int k = 1; k < ILP; k++) acc = add29(acc, x[k]);
+    normalize29(acc);
+    if (acc.v[8] == 0xffffffffu) fe_store(out + i, pack29(acc));  // never true (limbs stay < 2^30); keeps the chain live
+}
+
 extern "C" {
+
+int pk_selftest_modmul_rate(pk_ctx* ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double* modmul_per_s) {
+    if (!ctx || !modmul_per_s) return PK_ERR_BAD_ARG;
+    PK_REQUIRE(ctx, waves_per_simd >= 1 && waves_per_simd <= 8 && (ilp == 1 || ilp == 2 || ilp == 4) && iters >= 1, "waves 1..8, ilp 1|2|4");
+    int rc = ensure_scratch(ctx, 64 * 32);
+    if (rc) return rc;
+    PK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0x11, 64 * 32, ctx->stream));
+    const unsigned blocks = (unsigned)ctx->num_cus * waves_per_simd;  // 256 threads = 4 waves = 1 per SIMD
+    auto launch = [&](unsigned n) {
+        const fe* in = (const fe*)ctx->d_scratch;
+        fe* out = (fe*)ctx->d_scratch;
+        if (ilp == 1) modmul_rate_kernel<1><<<blocks, 256, 0, ctx->stream>>>(in, out, n);
+        else if (ilp == 2) modmul_rate_kernel<2><<<blocks, 256, 0, ctx->stream>>>(in, out, n);
+        else modmul_rate_kernel<4><<<blocks, 256, 0, ctx->stream>>>(in, out, n);
+    };
+    launch(16);
+    PK_LAUNCH_CHECK(ctx);
+    float ms = 0;
+    if ((rc = pk_timer_start(ctx))) return rc;
+    launch(iters);
+    PK_LAUNCH_CHECK(ctx);
+    if ((rc = pk_timer_stop(ctx, &ms))) return rc;
+    *modmul_per_s = (double)blocks * 256.0 * ilp * iters / (ms * 1e-3);
+    return PK_OK;
+}
 
 // the same ops executed by a kernel (device pointers): lets the GPU suite diff device vs host codegen
 int pk_selftest_arith_device(pk_ctx* ctx, int op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n) {
@@ -78,7 +132,7 @@ int pk_selftest_arith(int op, const uint64_t* a, const uint64_t* b, uint64_t* ou
     if (!a || !out || (!b && (op == 0 || op == 1 || op == 2 || op == 4))) return PK_ERR_BAD_ARG;
     for (size_t i = 0; i < n; i++) {
         fe x = load_host(a + 4 * i), y = b ? load_host(b + 4 * i) : x;
-        if (op < 0 || op > 13) return PK_ERR_BAD_ARG;
+        if (op < 0 || op > 14) return PK_ERR_BAD_ARG;
         fe r = selftest_op(op, x, y);
         store_host(out + 4 * i, r);
     }

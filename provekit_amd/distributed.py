@@ -34,7 +34,12 @@ class HipShardBackend:
         # one explicit (non-default) stream shared by the library's kernels and torch's ops / the collective
         self.stream = torch.cuda.Stream(device=self.device)
         ctx.set_stream(self.stream.cuda_stream)
-        self._keep = []
+        self._scratch = None  # grow-only encode workspace
+        self._pool = {}       # released leaf-shard buffers by size: a steady stream of commits never calls hipMalloc
+
+    def release(self, leaves: DeviceBuffer):
+        """hand a leaf shard returned by commit() back for reuse (callers that keep it for openings simply do not)"""
+        self._pool.setdefault(leaves.nbytes, []).append(leaves)
 
     def encode_and_hash_shard(self, d_polys, n_vars, log_inv_rate, fold, shard, n_shards):
         ctx = self.ctx
@@ -42,15 +47,19 @@ class HipShardBackend:
         rows = 1 << (n_vars + log_inv_rate - fold)
         width = batch << fold
         local_rows = rows // n_shards
-        leaves = ctx.alloc_fe(width * local_rows)
-        scratch = ctx.alloc_fe(width * (rows + 2 * local_rows))
+        free = self._pool.get(32 * width * local_rows)
+        leaves = free.pop() if free else ctx.alloc_fe(width * local_rows)
+        need = 32 * width * (rows + 2 * local_rows)
+        if self._scratch is None or self._scratch.nbytes < need:
+            self._scratch = None
+            self._scratch = ctx.alloc(need)
+        scratch = self._scratch
         ptrs = (C.c_void_p * batch)(*[p.ptr if isinstance(p, DeviceBuffer) else p for p in d_polys])
         ctx._check(lib.pk_rs_encode_shard(ctx.handle, ptrs, batch, n_vars, log_inv_rate, fold, shard, n_shards, leaves.ptr, scratch.ptr))
         with torch.cuda.stream(self.stream):
             digests = torch.empty((local_rows, 4), dtype=torch.int64, device=self.device)
         ctx._check(lib.pk_leaf_hash(ctx.handle, leaves.ptr, local_rows, width, PK_COL_MAJOR, digests.data_ptr()))
-        self._keep = [leaves, scratch]  # the shard of the codeword matrix stays resident for openings
-        return leaves, digests
+        return leaves, digests  # the caller owns the shard of the codeword matrix (resident for openings)
 
     def new_nodes(self, rows):
         with torch.cuda.stream(self.stream):

@@ -103,3 +103,12 @@ def test_host_sponge_permutation_and_tag(oracle):
         out = (C.c_uint8 * 32)()
         assert lib.pk_selftest_keccak_tag(data, len(data), out) == 0
         assert bytes(out) == hashlib.sha3_256(m).digest()
+
+
+def test_wide_reduce(oracle):
+    """reduce.hpp wide_reduce: limb sums of up to 1024 field elements -> the sum mod p (op 14 forms 700 x + 324 y)"""
+    edge = [0, 1, P - 1, P - 2, P // 2, (1 << 253), P - (1 << 224), (1 << 224) - 1]
+    xs = [a for a in edge for _ in edge] + rand_fe(3000, 21)
+    ys = [b for _ in edge for b in edge] + rand_fe(3000, 22)
+    got = oracle.limbs_to_ints(run(14, oracle.ints_to_limbs(xs), oracle.ints_to_limbs(ys)))
+    assert got == [(700 * x + 324 * y) % P for x, y in zip(xs, ys)]

@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("op", range(14))
+@pytest.mark.parametrize("op", range(15))
 def test_device_equals_host(ctx, oracle, op):
     from provekit_amd._lib import lib
     from provekit_amd.field import random_field
