@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Mint tests/golden/fixture_whir.json: values of the WHIR rows (N1 RS-encode, N2 batch stacking, T1 to_coeffs layout,
+W1 fold, W3 sumcheck convention, E1 OOD evaluation, S6 blinding algebra) DERIVED FROM THE REFERENCE'S OWN PROOF
+tooling/provekit-bench/benches/poseidon-1000.np -- a data file of the reference's benches -- by plain algebra.
+
+Run in the BUILD container only (reads /root/reference).  Output is data; the tests read only the JSON.
+
+What the real proof gives (SURVEY Appendix A offsets) and what is derived here:
+  * the blinding commitment T_b0 (root @96) is opened at ALL 32 leaves: an inverse DFT of each of its 32 columns yields
+    the two committed coefficient vectors f0, f1 (256 each); the upper half of every inverse DFT is zero only for the
+    right root of unity and leaf layout (checked) -- so  rs_encode(f0, f1) == the reference's leaves  is a known answer;
+  * to_evals(f0) = [80 blinding coefficients | 48 zeros | 128 mask values]: the zero band pins the evaluation layout,
+    and sum_over_hypercube of the 20 cubic univariates equals the scalar the reference absorbed @192;
+  * the round tree T_b1 (root @3232) commits f' (16 coefficients), read directly off its (identical) leaves;
+    f' == fold(f0 + beta f1, r) has a UNIQUE solution with r_k among the roots of h_k(X) = h_{k+1}(0) + h_{k+1}(1)
+    (the 4x3 sumcheck scalars @2848) -- 16 equations, 3 unknowns: pins batching order, fold order, sumcheck convention;
+  * OOD: the common root z of f0(X) = ans0 (@128) and f1(X) = ans1 (@160): pins OOD evaluation = univariate at z;
+  * the witness WHIR's last round tree T4 (root @249176, 2^14 leaves): its 9 opened leaves determine f4 (32
+    coefficients; 2 leaves solve, 7 check); f5 (2 final coefficients @259984) == fold(f4, r) with r from the sumcheck
+    scalars @259600; the 11 opened leaves of T3 (root @233312) satisfy fold(leaf_i, r3) == f4(w_{2^15}^i).
+All Merkle data verify under Skyscraper v1 (the fixture predates the v2 switch)."""
+import itertools
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, HERE)
+import pyref as pr  # noqa: E402
+import gen_golden as G  # noqa: E402
+
+P = pr.P
+hx = G.hx
+
+
+def inv(a):
+    return pow(a % P, -1, P)
+
+
+def idft(vals, w):
+    n, winv, ninv = len(vals), inv(w), inv(len(vals))
+    return [sum(v * pow(winv, i * k, P) for i, v in enumerate(vals)) * ninv % P for k in range(n)]
+
+
+def to_evals(c):
+    v, n, h = list(c), len(c), 1
+    while h < n:
+        for i in range(n):
+            if i & h:
+                v[i] = (v[i] + v[i ^ h]) % P
+        h <<= 1
+    return v
+
+
+def sqrt_mod(a):
+    a %= P
+    if a == 0:
+        return [0]
+    if pow(a, (P - 1) // 2, P) != 1:
+        return []
+    q, s = P - 1, 0
+    while q % 2 == 0:
+        q //= 2
+        s += 1
+    z = 5
+    while pow(z, (P - 1) // 2, P) != P - 1:
+        z += 1
+    m, c, t, r = s, pow(z, q, P), pow(a, q, P), pow(a, (q + 1) // 2, P)
+    while t != 1:
+        i, tt = 0, t
+        while tt != 1:
+            tt = tt * tt % P
+            i += 1
+        b = pow(c, 1 << (m - i - 1), P)
+        m, c = i, b * b % P
+        t, r = t * c % P, r * b % P
+    return [r, (P - r) % P]
+
+
+def quad_from_evals(e0, e1, e2):
+    a = (e2 - 2 * e1 + e0) * inv(2) % P
+    return a, (e1 - e0 - a) % P, e0
+
+
+def sumcheck_roots(H):
+    """r_k candidates for k = 0..2 from h_k(r_k) = h_{k+1}(0) + h_{k+1}(1)"""
+    out = []
+    for k in range(3):
+        a, b, c = quad_from_evals(*H[k])
+        c = (c - H[k + 1][0] - H[k + 1][1]) % P
+        out.append([(-b + s) * inv(2 * a) % P for s in sqrt_mod(b * b - 4 * a * c)])
+    return out
+
+
+def fold_first(block, rs):
+    for r in rs:
+        block = [(block[2 * i] + r * block[2 * i + 1]) % P for i in range(len(block) // 2)]
+    return block
+
+
+# --- polynomial arithmetic for the OOD root (dense, ascending coefficients)
+def pmod(a, m):
+    a = a[:]
+    dm, im = len(m) - 1, inv(m[-1])
+    while len(a) - 1 >= dm and a:
+        if a[-1]:
+            f = a[-1] * im % P
+            off = len(a) - 1 - dm
+            for i in range(dm + 1):
+                a[off + i] = (a[off + i] - f * m[i]) % P
+        a.pop()
+    while a and a[-1] == 0:
+        a.pop()
+    return a
+
+
+def pmulmod(a, b, m):
+    out = [0] * (len(a) + len(b) - 1)
+    for i, x in enumerate(a):
+        if x:
+            for j, y in enumerate(b):
+                out[i + j] = (out[i + j] + x * y) % P
+    return pmod(out, m)
+
+
+def pgcd(a, b):
+    while b:
+        a, b = b, pmod(a, b)
+    return a
+
+
+def common_root(f0, a0, f1, a1):
+    """the z with f0(z) = a0 and f1(z) = a1: gcd(f0 - a0, f1 - a1, X^p - X)"""
+    g0 = f0[:]
+    g0[0] = (g0[0] - a0) % P
+    g1 = f1[:]
+    g1[0] = (g1[0] - a1) % P
+    g = pgcd(g0, g1)
+    assert len(g) == 2, "expected one common linear factor, got degree %d" % (len(g) - 1)
+    return (-g[0]) * inv(g[1]) % P
+
+
+def main():
+    T = G.read_transcript()
+    fe = lambda off: int.from_bytes(T[off : off + 32], "little")
+
+    def hint_set(off):
+        pay, nxt = G.parse_hint(T, off)
+        leaves = G.parse_stir_answers(pay)
+        pay2, _ = G.parse_hint(T, nxt)
+        sib, pre, suf, idx = G.parse_multipath(pay2)
+        return leaves, idx
+
+    out = {"source": "derived from tooling/provekit-bench/benches/poseidon-1000.np (see gen_fixture_whir.py)", "hash_version": 1}
+
+    # ---------------------------------------------------------------- blinding commitment: full codeword
+    leaves, idx = hint_set(3304)
+    assert idx == list(range(32)) and all(len(l) == 32 for l in leaves)
+    w32 = pr.root_of_unity(5)
+    f = [[0] * 256 for _ in range(2)]
+    for b in range(2):
+        for j in range(16):
+            c = idft([leaves[i][b * 16 + j] for i in range(32)], w32)
+            assert not any(c[16:]), "not a rate-1/2 codeword in this layout"
+            for t in range(16):
+                f[b][16 * t + j] = c[t]
+    assert pr.rs_encode_naive(f, 8, 1, 4) == leaves
+    ev = to_evals(f[0])
+    assert not any(ev[80:128]) and all(ev[:80]) and all(ev[128:])
+    g = [ev[4 * i : 4 * i + 4] for i in range(20)]
+    cub = lambda c, x: (c[0] + c[1] * x + c[2] * x * x + c[3] * x * x * x) % P
+    sum_g = pow(2, 19, P) * sum(cub(gi, 0) + cub(gi, 1) for gi in g) % P
+    assert sum_g == fe(192)
+    z = common_root(f[0], fe(128), f[1], fe(160))
+    assert pr.eval_univariate(f[0], z) == fe(128) and pr.eval_univariate(f[1], z) == fe(160)
+    # round tree: identical leaves = the 16 coefficients of f'
+    l1, idx1 = hint_set(39552)
+    assert all(l == l1[0] for l in l1)
+    fp = l1[0]
+    H = [[fe(2848 + 96 * k + 32 * i) for i in range(3)] for k in range(4)]
+    sols = []
+    for r012 in itertools.product(*sumcheck_roots(H)):
+        A = [fold_first(f[0][t : t + 16], r012) for t in range(0, 256, 16)]
+        B = [fold_first(f[1][t : t + 16], r012) for t in range(0, 256, 16)]
+        # f'[t] = A0 + r3 A1 + beta B0 + (r3 beta) B1: solve 3 of the 16 equations, check the other 13 and r3*beta
+        M = [[A[t][1], B[t][0], B[t][1], (fp[t] - A[t][0]) % P] for t in range(16)]
+        S = [row[:] for row in M[:3]]
+        ok = True
+        for c in range(3):
+            piv = next((r for r in range(c, 3) if S[r][c]), None)
+            if piv is None:
+                ok = False
+                break
+            S[c], S[piv] = S[piv], S[c]
+            iv = inv(S[c][c])
+            S[c] = [x * iv % P for x in S[c]]
+            for r in range(3):
+                if r != c and S[r][c]:
+                    fct = S[r][c]
+                    S[r] = [(x - fct * y) % P for x, y in zip(S[r], S[c])]
+        if not ok:
+            continue
+        r3, beta, r3b = S[0][3], S[1][3], S[2][3]
+        if r3 * beta % P == r3b and all((m[0] * r3 + m[1] * beta + m[2] * r3b - m[3]) % P == 0 for m in M):
+            sols.append((list(r012) + [r3], beta))
+    assert len(sols) == 1, sols
+    r0, beta = sols[0]
+    F = [(a + beta * b) % P for a, b in zip(*f)]
+    assert pr.fold_coeffs(F, r0) == fp
+    out["blinding"] = {
+        "n_vars": 8, "root_T0": hx(fe(96)), "f0": [hx(x) for x in f[0]], "f1": [hx(x) for x in f[1]],
+        "leaves_T0": [[hx(x) for x in l] for l in leaves],
+        "sum_g": hx(sum_g), "ood_point": hx(z), "ood_answers": [hx(fe(128)), hx(fe(160))],
+        "sumcheck_evals": [[hx(x) for x in h] for h in H], "folding_randomness": [hx(x) for x in r0], "batching_randomness": hx(beta),
+        "f_folded": [hx(x) for x in fp], "root_T1": hx(fe(3232)), "opened_T1": idx1,
+    }
+
+    # ---------------------------------------------------------------- witness WHIR, last two round trees
+    l4, idx4 = hint_set(260056)
+    w14 = pr.root_of_unity(14)
+    x4 = [pow(w14, i, P) for i in idx4]
+    f4 = [0] * 32
+    for j in range(16):
+        b = (l4[1][j] - l4[0][j]) * inv(x4[1] - x4[0]) % P
+        f4[j], f4[16 + j] = (l4[0][j] - b * x4[0]) % P, b
+    assert all((f4[j] + f4[16 + j] * x4[k]) % P == l4[k][j] for k in range(9) for j in range(16))
+    H4 = [[fe(259600 + 96 * k + 32 * i) for i in range(3)] for k in range(4)]
+    f5 = [fe(259984), fe(260016)]
+    sols = []
+    for r012 in itertools.product(*sumcheck_roots(H4)):
+        fb = [fold_first(f4[0:16], r012), fold_first(f4[16:32], r012)]
+        if fb[0][1]:
+            r3 = (f5[0] - fb[0][0]) * inv(fb[0][1]) % P
+            if (fb[1][0] + r3 * fb[1][1]) % P == f5[1]:
+                sols.append(list(r012) + [r3])
+    assert len(sols) == 1
+    r4 = sols[0]
+    assert pr.fold_coeffs(f4, r4) == f5
+    # T3 openings fold to f4 at w_{2^15}^i
+    l3, idx3 = hint_set(249248)
+    w15 = pr.root_of_unity(15)
+    H3 = [[fe(249176 - 384 + 96 * k + 32 * i) for i in range(3)] for k in range(4)]
+    sols = []
+    for r012 in itertools.product(*sumcheck_roots(H3)):
+        r3s = set()
+        for lf, i in zip(l3, idx3):
+            lo_hi = fold_first(lf, r012)
+            want = pr.eval_univariate(f4, pow(w15, i, P))
+            r3s.add((want - lo_hi[0]) * inv(lo_hi[1]) % P)
+        if len(r3s) == 1:
+            sols.append(list(r012) + [r3s.pop()])
+    assert len(sols) == 1
+    r3 = sols[0]
+    assert all(pr.multivar_poly(lf, r3) == pr.eval_univariate(f4, pow(w15, i, P)) for lf, i in zip(l3, idx3))
+    out["witness_tail"] = {
+        "T4": {"root": hx(fe(249176)), "n_vars": 5, "log_inv_rate": 13, "height": 14, "opened": idx4, "leaves": [[hx(x) for x in l] for l in l4],
+               "f4": [hx(x) for x in f4]},
+        "final": {"sumcheck_evals": [[hx(x) for x in h] for h in H4], "folding_randomness": [hx(x) for x in r4], "final_coefficients": [hx(x) for x in f5]},
+        "T3": {"root": hx(fe(233312)), "height": 15, "opened": idx3, "leaves": [[hx(x) for x in l] for l in l3],
+               "sumcheck_evals": [[hx(x) for x in h] for h in H3], "folding_randomness": [hx(x) for x in r3]},
+    }
+    json.dump(out, open(os.path.join(HERE, "fixture_whir.json"), "w"), indent=0)
+    print("fixture_whir.json written; all relations hold")
+
+
+if __name__ == "__main__":
+    main()

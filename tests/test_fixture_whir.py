@@ -1,0 +1,153 @@
+"""Known answers DERIVED FROM THE REFERENCE'S OWN PROOF (tests/golden/fixture_whir.json, minted by gen_fixture_whir.py from
+tooling/provekit-bench/benches/poseidon-1000.np): commitments, folds, OOD evaluations and sumcheck relations the real
+prover produced.  CPU half: the C oracle reproduces them.  GPU half (marked gpu): the HIP library reproduces them through
+the C ABI.  Hash version 1 throughout (the fixture predates the Skyscraper v2 switch)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FX = json.load(open(os.path.join(G, "fixture_whir.json")))
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+ints = lambda hs: [int(h, 16) for h in hs]
+
+
+def quad(evals, x):
+    """value at x of the quadratic through (0,e0),(1,e1),(2,e2) -- utilities.go:148-154"""
+    e0, e1, e2 = evals
+    a = (e2 - 2 * e1 + e0) * pow(2, -1, P) % P
+    return (a * x * x + (e1 - e0 - a) * x + e0) % P
+
+
+def mont(o, xs):
+    return o.to_mont(o.ints_to_limbs(xs))
+
+
+def canon_ints(o, a):
+    return o.limbs_to_ints(o.from_mont(a))
+
+
+# ------------------------------------------------------------------------------------------------ CPU: oracle
+def test_oracle_blinding_commitment_is_the_references(oracle):
+    b = FX["blinding"]
+    f0, f1 = ints(b["f0"]), ints(b["f1"])
+    leaves = oracle.rs_encode(mont(oracle, f0 + f1), 2, 8, 1, 4)
+    assert [canon_ints(oracle, l) for l in leaves] == [ints(l) for l in b["leaves_T0"]]
+    assert oracle.limbs_to_ints(oracle.merkle_commit(leaves, version=1)[1:2])[0] == int(b["root_T0"], 16)
+    # evaluation layout: [4*m_0 blinding coefficients | zero padding | mask]  (whir_r1cs.rs:228-250, 186-199)
+    ev = canon_ints(oracle, oracle.to_evals(mont(oracle, f0), 8))
+    assert not any(ev[80:128]) and all(ev[:80]) and all(ev[128:])
+    assert canon_ints(oracle, oracle.to_coeffs(oracle.to_evals(mont(oracle, f0), 8), 8)) == f0
+    # sum_over_hypercube (whir_r1cs.rs:172-180) of the 20 cubics == the scalar absorbed by the real prover
+    cub = lambda c, x: (c[0] + c[1] * x + c[2] * x * x + c[3] * x ** 3) % P
+    assert pow(2, 19, P) * sum(cub(ev[4 * i : 4 * i + 4], 0) + cub(ev[4 * i : 4 * i + 4], 1) for i in range(20)) % P == int(b["sum_g"], 16)
+    # OOD answers are univariate evaluations at one common point
+    z = mont(oracle, [int(b["ood_point"], 16)])[0]
+    for f, ans in zip((f0, f1), b["ood_answers"]):
+        assert canon_ints(oracle, oracle.eval_univariate(mont(oracle, f), z)[None])[0] == int(ans, 16)
+
+
+def test_oracle_fold_batching_and_round_tree(oracle):
+    b = FX["blinding"]
+    f0, f1, beta, r = mont(oracle, ints(b["f0"])), mont(oracle, ints(b["f1"])), mont(oracle, [int(b["batching_randomness"], 16)])[0], mont(oracle, ints(b["folding_randomness"]))
+    folded = oracle.fold_coeffs(oracle.vec_axpy(f0, beta, f1), 8, r)
+    assert canon_ints(oracle, folded) == ints(b["f_folded"])
+    # sumcheck binding (whir_utilities.go:102-125): h_k(r_k) == h_{k+1}(0) + h_{k+1}(1)
+    H, rr = [ints(h) for h in b["sumcheck_evals"]], ints(b["folding_randomness"])
+    for k in range(3):
+        assert quad(H[k], rr[k]) == (H[k + 1][0] + H[k + 1][1]) % P
+    # the round commitment of the folded polynomial: 16 leaves at rate 2^-4, every leaf = the 16 coefficients
+    leaves = oracle.rs_encode(folded, 1, 4, 4, 4)
+    assert leaves.shape[0] == 16 and all(canon_ints(oracle, l) == ints(b["f_folded"]) for l in leaves)
+    assert oracle.limbs_to_ints(oracle.merkle_commit(leaves, version=1)[1:2])[0] == int(b["root_T1"], 16)
+
+
+def test_oracle_witness_tail(oracle):
+    w = FX["witness_tail"]
+    f4 = mont(oracle, ints(w["T4"]["f4"]))
+    leaves = oracle.rs_encode(f4, 1, w["T4"]["n_vars"], w["T4"]["log_inv_rate"], 4)
+    assert leaves.shape[0] == 1 << w["T4"]["height"]
+    for i, l in zip(w["T4"]["opened"], w["T4"]["leaves"]):
+        assert canon_ints(oracle, leaves[i]) == ints(l)
+    assert oracle.limbs_to_ints(oracle.merkle_commit(leaves, version=1)[1:2])[0] == int(w["T4"]["root"], 16)
+    r4 = mont(oracle, ints(w["final"]["folding_randomness"]))
+    assert canon_ints(oracle, oracle.fold_coeffs(f4, 5, r4)) == ints(w["final"]["final_coefficients"])
+    H, rr = [ints(h) for h in w["final"]["sumcheck_evals"]], ints(w["final"]["folding_randomness"])
+    for k in range(3):
+        assert quad(H[k], rr[k]) == (H[k + 1][0] + H[k + 1][1]) % P
+    # STIR consistency one level up (whir_utilities.go:180-186, whir.go:99,141): fold(leaf_i, r) == f4(w_{2^15}^i)
+    r3 = mont(oracle, ints(w["T3"]["folding_randomness"]))
+    w15 = oracle.root_of_unity(15)
+    for i, l in zip(w["T3"]["opened"], w["T3"]["leaves"]):
+        x = np.empty(4, dtype=np.uint64)
+        oracle.L.pko_fe_pow(oracle._p(w15), int(i), oracle._p(x))
+        lhs = oracle.fold_coeffs(mont(oracle, ints(l)), 4, r3)[0]
+        assert np.array_equal(lhs, oracle.eval_univariate(f4, x))
+
+
+# ------------------------------------------------------------------------------------------------ GPU: HIP path
+@pytest.fixture()
+def ctx_v1(ctx):
+    ctx.set_hash_version(1)
+    yield ctx
+    ctx.set_hash_version(2)
+
+
+@pytest.mark.gpu
+def test_hip_blinding_commitment_is_the_references(ctx_v1, oracle):
+    from provekit_amd import sumcheck as sc
+    from provekit_amd.whir import commit_batch
+
+    ctx, b = ctx_v1, FX["blinding"]
+    f0, f1 = ints(b["f0"]), ints(b["f1"])
+    d0, d1 = ctx.upload(mont(oracle, f0)), ctx.upload(mont(oracle, f1))
+    c = commit_batch(ctx, [d0, d1], 8, 1, 4)
+    assert int.from_bytes(c.root, "little") == int(b["root_T0"], 16)
+    lv, _, _ = c.open(np.arange(32, dtype=np.uint64), canonical_leaves=True)
+    assert [oracle.limbs_to_ints(l) for l in lv] == [ints(l) for l in b["leaves_T0"]]
+    c.close()
+    z = mont(oracle, [int(b["ood_point"], 16)])[0]
+    for d, ans in zip((d0, d1), b["ood_answers"]):
+        assert canon_ints(oracle, sc.eval_univariate(ctx, d, 256, z)[None])[0] == int(ans, 16)
+    # batching + fold + round commitment
+    beta, r = mont(oracle, [int(b["batching_randomness"], 16)])[0], mont(oracle, ints(b["folding_randomness"]))
+    sc.axpy(ctx, d0, beta, d1, 256)  # d0 <- f0 + beta f1
+    d_f = sc.fold_coeffs(ctx, d0, 8, r)
+    assert canon_ints(oracle, ctx.download_fe(d_f, 16)) == ints(b["f_folded"])
+    c1 = commit_batch(ctx, [d_f], 4, 4, 4)
+    assert int.from_bytes(c1.root, "little") == int(b["root_T1"], 16)
+    c1.close()
+    # to_evals layout on the device
+    d_e = ctx.upload(mont(oracle, f0))
+    sc.to_evals(ctx, d_e, 8)
+    ev = canon_ints(oracle, ctx.download_fe(d_e, 256))
+    assert not any(ev[80:128]) and all(ev[:80]) and all(ev[128:])
+
+
+@pytest.mark.gpu
+def test_hip_witness_tail(ctx_v1, oracle):
+    from provekit_amd import sumcheck as sc
+    from provekit_amd.whir import commit_batch
+
+    ctx, w = ctx_v1, FX["witness_tail"]
+    d4 = ctx.upload(mont(oracle, ints(w["T4"]["f4"])))
+    c = commit_batch(ctx, [d4], w["T4"]["n_vars"], w["T4"]["log_inv_rate"], 4)
+    assert c.n_leaves == 1 << w["T4"]["height"]
+    assert int.from_bytes(c.root, "little") == int(w["T4"]["root"], 16)
+    lv, _, _ = c.open(np.array(w["T4"]["opened"], dtype=np.uint64), canonical_leaves=True)
+    assert [oracle.limbs_to_ints(l) for l in lv] == [ints(l) for l in w["T4"]["leaves"]]
+    c.close()
+    d5 = sc.fold_coeffs(ctx, d4, 5, mont(oracle, ints(w["final"]["folding_randomness"])))
+    assert canon_ints(oracle, ctx.download_fe(d5, 2)) == ints(w["final"]["final_coefficients"])
+    r3 = mont(oracle, ints(w["T3"]["folding_randomness"]))
+    w15 = oracle.root_of_unity(15)
+    # the 11 opened leaves, zero-padded to 16, are folded by ONE coefficient fold of a 2^8 vector (leaf k = block k)
+    n3 = len(w["T3"]["leaves"])
+    flat = [v for l in w["T3"]["leaves"] for v in ints(l)] + [0] * (16 * (16 - n3))
+    folded = ctx.download_fe(sc.fold_coeffs(ctx, ctx.upload(mont(oracle, flat)), 8, r3), 16)
+    for k, i in enumerate(w["T3"]["opened"]):
+        x = np.empty(4, dtype=np.uint64)
+        oracle.L.pko_fe_pow(oracle._p(w15), int(i), oracle._p(x))
+        assert np.array_equal(folded[k], sc.eval_univariate(ctx, d4, 32, x))
