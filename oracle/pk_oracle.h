@@ -16,11 +16,17 @@
  *       inputs + the algebraic definition a*b*2^-256 mod p checked in Python.
  *   - PoW threshold conversion             : PINNED by skyscraper/core/src/pow.rs:88-103.
  *   - Merkle leaf layout / tree orientation: PINNED by the proof fixture.
- *   - RS-encode / fold / OOD / sumcheck kernels: the reference holds no golden
- *       vectors for these ("parity unpinned" at value level); they are pinned
- *       to the mathematical definition by an independent Python big-int
- *       restatement (tests/golden/gen_golden.py) and by the verifier equations
- *       in the Go files under recursive-verifier/app/circuit/.
+ *   - RS-encode, batch stacking, to_coeffs layout, coefficient fold, OOD
+ *       evaluation, quadratic-sumcheck binding, blinding sum: PINNED by values
+ *       derived from the reference's own proof (tests/golden/fixture_whir.json:
+ *       recovered coefficient vectors -> the reference's leaves and Merkle roots,
+ *       fold -> the next committed polynomial, OOD answers, final coefficients).
+ *   - eq table, cubic sumcheck round, sparse products, eq_accumulate: the
+ *       reference holds no golden vectors and the fixture exposes none of their
+ *       inputs ("parity unpinned" at value level); pinned to the mathematical
+ *       definition by an independent Python big-int restatement
+ *       (tests/golden/gen_golden.py) and by the verifier equations in the Go
+ *       files under recursive-verifier/app/circuit/.
  *
  * Conventions: a field element (FE) is 4 x uint64 little-endian limbs. Unless a
  * function says "canonical", FEs are in Montgomery form (x*2^256 mod p), which
