@@ -51,6 +51,7 @@ int pk_ctx_destroy(pk_ctx* ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+    if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
     for (auto& r : ctx->prof) {
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);
@@ -73,8 +74,7 @@ int pk_ctx_set_stream(pk_ctx* ctx, void* hip_stream) {
 
 int pk_ctx_sync(pk_ctx* ctx) {
     if (!ctx) return PK_ERR_BAD_ARG;
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PK_OK;
+    return sync_stream(ctx);
 }
 
 int pk_ctx_set_hash_version(pk_ctx* ctx, int version) {
@@ -200,6 +200,38 @@ int ensure_scratch(pk_ctx* ctx, size_t bytes) {
     size_t sz = bytes < (1u << 20) ? (1u << 20) : bytes;
     PK_HIP(ctx, hipMalloc(&ctx->d_scratch, sz));
     ctx->scratch_bytes = sz;
+    ctx->red_armed = ctx->pow_armed = false;  // the ticket / best words live in this buffer
+    return PK_OK;
+}
+int ensure_pinned(pk_ctx* ctx) {
+    if (ctx->h_pinned) return PK_OK;
+    PK_HIP(ctx, hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocMapped));
+    memset(ctx->h_pinned, 0, 4096);
+    ctx->pinned_bytes = 4096;
+    return PK_OK;
+}
+int sync_stream(pk_ctx* ctx) {
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->mail_off = 0;  // nothing in flight reads or writes the mailbox any more
+    return PK_OK;
+}
+int mail_alloc(pk_ctx* ctx, size_t bytes, void** out) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (ctx->mail_off + bytes > ctx->mail_bytes) {
+        int rc = sync_stream(ctx);  // in-flight kernels may still use earlier allocations
+        if (rc) return rc;
+        if (bytes > ctx->mail_bytes) {
+            size_t cap = (size_t)1 << 20;
+            while (cap < bytes) cap <<= 1;
+            if (ctx->h_mail) PK_HIP(ctx, hipHostFree(ctx->h_mail));
+            ctx->h_mail = nullptr;
+            ctx->mail_bytes = 0;
+            PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_mail, cap, hipHostMallocMapped));
+            ctx->mail_bytes = cap;
+        }
+    }
+    *out = ctx->h_mail + ctx->mail_off;
+    ctx->mail_off += bytes;
     return PK_OK;
 }
 int ensure_ws(pk_ctx* ctx, size_t bytes) {

@@ -37,7 +37,18 @@ struct pk_ctx {
     unsigned red_seq = 0;  // sequence number of the last reduction launch (completion flag in h_pinned)
     void* d_ws = nullptr;  // large reusable workspace (NTT scratch); grows, never shrinks
     size_t ws_bytes = 0;
+    // "mailbox": device-visible pinned host memory the kernels read small inputs from and write small outputs to, so
+    // the Fiat-Shamir round trips need no copy operations (each hipMemcpyAsync is a blit dispatch for the command processor).
+    // Bump-allocated; the offset rewinds at every stream synchronisation (pk::sync_stream).
+    char* h_mail = nullptr;
+    size_t mail_bytes = 0, mail_off = 0;
+    bool pow_armed = false;  // pow.hip: device-side best/ticket words initialised
+    bool red_armed = false;  // reduce.hpp: ticket word zeroed
 };
+
+// fixed slots in the 4 KiB h_pinned page: [0,1024) reduction results, word 256 completion flag (reduce.hpp)
+#define PK_PIN_ROOT 2048 /* 32 B: the root of the last Merkle tree built on this context (hash.hip) */
+#define PK_PIN_POW 2112  /* 8 B: the nonce found by the last proof-of-work launch (pow.hip) */
 
 namespace pk {
 
@@ -110,6 +121,10 @@ struct ProfScope {
 };
 
 int ensure_scratch(pk_ctx* ctx, size_t bytes);
+int ensure_pinned(pk_ctx* ctx);                               // the 4 KiB result page
+int sync_stream(pk_ctx* ctx);                                 // hipStreamSynchronize + rewind the mailbox
+int mail_alloc(pk_ctx* ctx, size_t bytes, void** out);        // 64-B aligned; valid until the next sync_stream
+int read_root(pk_ctx* ctx, const uint64_t* d_nodes, size_t n_leaves, uint64_t root[4]);  // hash.hip: after pk_merkle_*
 int ensure_ws(pk_ctx* ctx, size_t bytes);
 void ntt_release_ctx(pk_ctx* ctx);  // ntt.hip: frees the per-context twiddle tables
 

@@ -43,28 +43,44 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const fe* __restrict__ l
     fe_store(digests + i, pack29(h));
 }
 
-// one level of ark MerkleTree::new: nodes[i] = C(nodes[2i], nodes[2i+1]) for i in [first, first+count)
+// `levels` consecutive levels of ark MerkleTree::new in one launch: nodes[i] = C(nodes[2i], nodes[2i+1]).  A workgroup
+// owns 256 adjacent nodes of the widest level (node count `count`, heap offset = count) and the 128, 64, ... nodes above
+// them; whole wavefronts retire as the subtree narrows, so nothing is wasted, and a level costs one compression latency
+// instead of a launch.
 template <int VERSION>
-__global__ __launch_bounds__(256) void merkle_level_kernel(fe* __restrict__ nodes, size_t first, size_t count) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= count) return;
-    size_t i = first + t;
-    fe29 l = unpack29<0>(fe_load(nodes + 2 * i)), r = unpack29<0>(fe_load(nodes + 2 * i + 1));  // digests are canonical
-    fe_store(nodes + i, pack29(compress29<VERSION>(l, r)));
+__global__ __launch_bounds__(256) void merkle_levels_kernel(fe* __restrict__ nodes, size_t count, unsigned levels) {
+    size_t base = (size_t)blockIdx.x * 256;  // first owned node of the widest level, relative to that level
+    unsigned width = 256;
+    for (unsigned l = 0; l < levels; l++) {
+        if (threadIdx.x < width && base + threadIdx.x < count) {
+            size_t i = count + base + threadIdx.x;
+            fe29 a = unpack29<0>(fe_load(nodes + 2 * i)), b = unpack29<0>(fe_load(nodes + 2 * i + 1));  // digests are canonical
+            fe_store(nodes + i, pack29(compress29<VERSION>(a, b)));
+        }
+        __threadfence_block();
+        __syncthreads();
+        count >>= 1;
+        base >>= 1;
+        width >>= 1;
+    }
 }
 
-// the top of the tree (<= 512 nodes per level) in one workgroup: no launch per level
+// the top of the tree (<= 512 nodes per level) in one workgroup; also clears the unused heap slot 0 and mirrors the root
+// into pinned host memory (the host reads it after the stream synchronisation, no copy operation)
 template <int VERSION>
-__global__ __launch_bounds__(512) void merkle_top_kernel(fe* __restrict__ nodes, size_t top_leaves) {
+__global__ __launch_bounds__(512) void merkle_top_kernel(fe* __restrict__ nodes, size_t top_leaves, fe* __restrict__ host_root) {
     for (size_t lvl = top_leaves / 2; lvl >= 1; lvl >>= 1) {
         if (threadIdx.x < lvl) {
             size_t i = lvl + threadIdx.x;
             fe29 l = unpack29<0>(fe_load(nodes + 2 * i)), r = unpack29<0>(fe_load(nodes + 2 * i + 1));
-            fe_store(nodes + i, pack29(compress29<VERSION>(l, r)));
+            fe x = pack29(compress29<VERSION>(l, r));
+            fe_store(nodes + i, x);
+            if (i == 1 && host_root) fe_store(host_root, x);
         }
         __threadfence_block();
         __syncthreads();
     }
+    if (threadIdx.x == 0) fe_store(nodes, fe_zero());
 }
 
 static int leaf_hash_launch(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, uint64_t* d_digests) {
@@ -88,6 +104,17 @@ static int leaf_hash_launch(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leav
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
 }
+
+namespace pk {
+// root of the tree pk_merkle_inner / pk_merkle_commit just built on this context's stream
+int read_root(pk_ctx* ctx, const uint64_t* d_nodes, size_t n_leaves, uint64_t root[4]) {
+    if (n_leaves < 2) return pk_memcpy_d2h(ctx, root, d_nodes + 4, 32);
+    int rc = sync_stream(ctx);
+    if (rc) return rc;
+    memcpy(root, (char*)ctx->h_pinned + PK_PIN_ROOT, 32);
+    return PK_OK;
+}
+}  // namespace pk
 
 extern "C" {
 
@@ -145,22 +172,29 @@ int pk_merkle_inner(pk_ctx* ctx, uint64_t* d_nodes, size_t n_leaves) {
     PK_REQUIRE(ctx, is_pow2(n_leaves), "n_leaves must be a power of two");  // ark MerkleTree::new asserts this
     PK_REQUIRE(ctx, d_nodes, "null pointer");
     fe* N = (fe*)d_nodes;
-    PK_HIP(ctx, hipMemsetAsync(d_nodes, 0, 32, ctx->stream));
+    int rc = ensure_pinned(ctx);
+    if (rc) return rc;
+    fe* host_root = (fe*)((char*)ctx->h_pinned + PK_PIN_ROOT);
     ProfScope prof(ctx, "merkle_inner");
+    if (n_leaves == 1) {  // the leaf digest is the root (heap slot 1); nothing to hash
+        PK_HIP(ctx, hipMemsetAsync(d_nodes, 0, 32, ctx->stream));
+        return PK_OK;
+    }
     size_t lvl = n_leaves / 2;
-    for (; lvl > 512; lvl >>= 1) {
+    while (lvl > 512) {
+        unsigned levels = 0;
+        for (size_t c = lvl; c > 512 && levels < 5; c >>= 1) levels++;
         unsigned grid = (unsigned)((lvl + 255) / 256);
         if (ctx->hash_version == 2)
-            merkle_level_kernel<2><<<grid, 256, 0, ctx->stream>>>(N, lvl, lvl);
+            merkle_levels_kernel<2><<<grid, 256, 0, ctx->stream>>>(N, lvl, levels);
         else
-            merkle_level_kernel<1><<<grid, 256, 0, ctx->stream>>>(N, lvl, lvl);
+            merkle_levels_kernel<1><<<grid, 256, 0, ctx->stream>>>(N, lvl, levels);
+        lvl >>= levels;
     }
-    if (lvl >= 1) {
-        if (ctx->hash_version == 2)
-            merkle_top_kernel<2><<<1, 512, 0, ctx->stream>>>(N, lvl * 2);
-        else
-            merkle_top_kernel<1><<<1, 512, 0, ctx->stream>>>(N, lvl * 2);
-    }
+    if (ctx->hash_version == 2)
+        merkle_top_kernel<2><<<1, 512, 0, ctx->stream>>>(N, lvl * 2, host_root);
+    else
+        merkle_top_kernel<1><<<1, 512, 0, ctx->stream>>>(N, lvl * 2, host_root);
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
 }

@@ -156,19 +156,22 @@ int wavelet(pk_ctx* ctx, const uint64_t* d_src, uint64_t* d_data, unsigned n_var
 // tables layout: [pt][ 2^nhi hi entries | 2^nlo lo entries ]
 __global__ __launch_bounds__(256) void eq_half_tables_kernel(const fe* __restrict__ points, const fe* __restrict__ scales,
                                                              unsigned n_vars, unsigned nhi, unsigned nlo, fe* __restrict__ tables) {
+    // points / scales sit in pinned host memory (the mailbox): fetch this half's <= 15 coordinates in one go
+    __shared__ uint4 xs[2 * 16];
     const unsigned pt = blockIdx.x, half = blockIdx.y;
     const size_t per_pt = ((size_t)1 << nhi) + ((size_t)1 << nlo);
     fe* T = tables + pt * per_pt + (half ? ((size_t)1 << nhi) : 0);
     const fe* x = points + (size_t)pt * n_vars + (half ? nhi : 0);
     const unsigned nv = half ? nlo : nhi;
-    if (threadIdx.x == 0) fe_store(T, half ? fe_one() : fe_load(scales + pt));
+    if (threadIdx.x < nv) lds_put(xs, xs + 16, threadIdx.x, fe_load(x + threadIdx.x));
+    if (threadIdx.x == 32) fe_store(T, half ? fe_one() : fe_load(scales + pt));
     __threadfence_block();
     __syncthreads();
     // Level l appends variable nv-1-l as index bit l, so the last variable is the LSB and variable 0
     // ends up as the MSB, as eval_eq's recursion orders it: T[h+i] = x*T[i] (s1), T[i] -= that (s0).
     for (unsigned l = 0; l < nv; l++) {
         const size_t h = (size_t)1 << l;
-        fe xv = fe_load(x + (nv - 1 - l));
+        fe xv = lds_get(xs, xs + 16, nv - 1 - l);
         for (size_t i = threadIdx.x; i < h; i += 256) {
             fe t = fe_load(T + i);
             fe up = fe_mulx(t, xv);  // s1 = s * x
@@ -278,9 +281,13 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_kernel(const f
     }
     grid_finish_fe<3>(acc, smem, partials, ticket, result, seq);
 }
-// the single-element tail of the fold (out_len == 1): v'[0] = v[0] + r (v[1]-v[0]); no pair to sum
-__global__ void fold_pairs_kernel(const fe* __restrict__ v, fe* __restrict__ out, size_t out_len, fe_arg r_arg) {
+// the single-element tail of the fold (out_len == 1): v'[0] = v[0] + r (v[1]-v[0]); no pair to sum.  blockIdx.y selects
+// one of up to two arrays folded by the same challenge (the sumcheck's polynomial and its weights) in one launch.
+__global__ void fold_pairs_kernel(const fe* __restrict__ v0, fe* __restrict__ out0, const fe* __restrict__ v1, fe* __restrict__ out1,
+                                  size_t out_len, fe_arg r_arg) {
     const fe r = from_arg(r_arg);
+    const fe* v = blockIdx.y ? v1 : v0;
+    fe* out = blockIdx.y ? out1 : out0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < out_len; i += stride) {
         fe x0 = fe_load(v + 2 * i), x1 = fe_load(v + 2 * i + 1);
@@ -310,20 +317,14 @@ __global__ __launch_bounds__(RED_THREADS) void dot_kernel(const fe* __restrict__
 // ---------------------------------------------------------------- E1: univariate evaluation
 // sum_i c[i] z^i with T = gridDim*blockDim lanes: lane g Horner-evaluates the stride-T subsequence c[g], c[g+T], ...
 // in z^T (so every load is coalesced across the wave), scales by z^g and the grid reduces.
-__device__ __forceinline__ fe fe_pow_u64(fe base, u64 e) {
-    fe acc = fe_one();
-    while (e) {
-        if (e & 1) acc = fe_mulx(acc, base);
-        base = fe_sqrx(base);
-        e >>= 1;
-    }
-    return acc;
-}
-__global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restrict__ c, size_t n, fe_arg z_arg, fe_arg zT_arg,
+struct pow2_args {
+    fe_arg p[18];  // z^(2^i)
+};
+__global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restrict__ c, size_t n, pow2_args zp, fe_arg zT_arg,
                                                              fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                              fe* __restrict__ result, unsigned seq) {
     __shared__ uint4 smem[16];
-    const fe z = from_arg(z_arg), zT = from_arg(zT_arg);
+    const fe zT = from_arg(zT_arg);
     const size_t T = (size_t)gridDim.x * blockDim.x;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     fe acc[1] = {fe_zero()};
@@ -331,7 +332,18 @@ __global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restric
         size_t cnt = (n - g + T - 1) / T;  // elements g, g+T, ..., g+(cnt-1)T
         fe h = fe_load(c + g + (cnt - 1) * T);
         for (size_t j = cnt - 1; j-- > 0;) h = fe_add(fe_mulx(h, zT), fe_load(c + g + j * T));
-        acc[0] = fe_mulx(h, fe_pow_u64(z, (u64)g));
+        // z^g from the host's table of z^(2^i): the 8 lane bits by select, the block bits under a uniform branch
+        // (g < 2^18: at most 1024 blocks of 256 lanes)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            fe t = fe_mulx(h, from_arg(zp.p[i]));
+            const bool bit = (threadIdx.x >> i) & 1u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) h.v[k] = bit ? t.v[k] : h.v[k];
+        }
+        for (int i = 8; i < 18; i++)
+            if ((blockIdx.x >> (i - 8)) & 1u) h = fe_mulx(h, from_arg(zp.p[i]));
+        acc[0] = h;
     }
     grid_finish_fe<1>(acc, smem, partials, ticket, result, seq);
 }
@@ -405,22 +417,26 @@ int pk_eq_accumulate(pk_ctx* ctx, uint64_t* d_w, unsigned n_vars, const uint64_t
     }
     const unsigned nlo = (n_vars + 1) / 2, nhi = n_vars - nlo;
     const size_t per_pt = ((size_t)1 << nhi) + ((size_t)1 << nlo);
-    const size_t bytes = 32 * ((size_t)q * n_vars + q + (size_t)q * per_pt);
-    // staging + tables use the context workspace; stream order keeps them clear of earlier kernels (NTT scratch)
-    int rc = ensure_ws(ctx, bytes + 64);
+    // tables use the context workspace; stream order keeps them clear of earlier kernels (NTT scratch).  The points and
+    // scales go through the pinned mailbox, which the table kernel reads directly (no copy operation).
+    int rc = ensure_ws(ctx, 32 * (size_t)q * per_pt + 64);
     if (rc) return rc;
-    fe* d_points = (fe*)ctx->d_ws;
+    PK_REQUIRE(ctx, nlo <= 16, "too many variables");
+    char* mail = nullptr;
+    rc = mail_alloc(ctx, 32 * ((size_t)q * n_vars + q), (void**)&mail);
+    if (rc) return rc;
+    fe* d_points = (fe*)mail;
     fe* d_scales = d_points + (size_t)q * n_vars;
-    fe* d_tables = d_scales + q;
-    if (n_vars) PK_HIP(ctx, hipMemcpyAsync(d_points, points, 32 * (size_t)q * n_vars, hipMemcpyHostToDevice, ctx->stream));
-    PK_HIP(ctx, hipMemcpyAsync(d_scales, scales, 32 * (size_t)q, hipMemcpyHostToDevice, ctx->stream));
+    fe* d_tables = (fe*)ctx->d_ws;
+    if (n_vars) memcpy(d_points, points, 32 * (size_t)q * n_vars);
+    memcpy(d_scales, scales, 32 * (size_t)q);
     {
         ProfScope prof(ctx, "eq_accumulate");
         eq_half_tables_kernel<<<dim3(q, 2), 256, 0, ctx->stream>>>(d_points, d_scales, n_vars, nhi, nlo, d_tables);
         eq_accumulate_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_w, n, nhi, nlo, q, d_tables, overwrite);
     }
     PK_LAUNCH_CHECK(ctx);
-    // the host arrays were read by hipMemcpyAsync from pageable memory: that copy is complete on return
+    // the caller's host arrays were copied into the mailbox above: they may be reused on return
     return PK_OK;
 }
 
@@ -482,10 +498,23 @@ int pk_fold_pairs(pk_ctx* ctx, const uint64_t* d_v, size_t len, const uint64_t* 
     if (!ctx) return PK_ERR_BAD_ARG;
     PK_REQUIRE(ctx, d_v && d_out && r && d_v != d_out, "null or aliased pointer");
     PK_REQUIRE(ctx, is_pow2(len) && len >= 2, "size must be a power of two >= 2");
-    fold_pairs_kernel<<<grid_for(ctx, len / 2, 256), 256, 0, ctx->stream>>>((const fe*)d_v, (fe*)d_out, len / 2, to_arg(r));
+    fold_pairs_kernel<<<grid_for(ctx, len / 2, 256), 256, 0, ctx->stream>>>((const fe*)d_v, (fe*)d_out, nullptr, nullptr, len / 2, to_arg(r));
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
 }
+}  // extern "C"
+namespace pk {
+// two arrays of the same length folded by the same challenge in one launch (the sumcheck's p and w)
+int fold_pairs2(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint64_t* d_v1, uint64_t* d_out1, size_t len, const uint64_t* r) {
+    PK_REQUIRE(ctx, d_v0 && d_out0 && d_v1 && d_out1 && r, "null pointer");
+    PK_REQUIRE(ctx, is_pow2(len) && len >= 2, "size must be a power of two >= 2");
+    fold_pairs_kernel<<<dim3(grid_for(ctx, len / 2, 256), 2), 256, 0, ctx->stream>>>((const fe*)d_v0, (fe*)d_out0, (const fe*)d_v1, (fe*)d_out1,
+                                                                                     len / 2, to_arg(r));
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+}  // namespace pk
+extern "C" {
 
 int pk_dot(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, size_t n, uint64_t out[4]) {
     if (!ctx) return PK_ERR_BAD_ARG;
@@ -534,26 +563,31 @@ int pk_eval_univariate(pk_ctx* ctx, const uint64_t* d_coeffs, size_t n, const ui
     }
     int rc = reduction_scratch(ctx);
     if (rc) return rc;
-    // ~32 coefficients per lane, at most 256 blocks
-    size_t want = (n / 32 + RED_THREADS - 1) / RED_THREADS;
-    unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 256 ? 256 : want));
+    // ~8 coefficients per lane, at most RED_MAX_BLOCKS (1024) blocks
+    size_t want = (n / 8 + RED_THREADS - 1) / RED_THREADS;
+    unsigned blocks = (unsigned)(want < 1 ? 1 : (want > RED_MAX_BLOCKS ? RED_MAX_BLOCKS : want));
     const u64 T = (u64)blocks * RED_THREADS;
-    // z^T on the host (square-and-multiply, ~16 products)
+    // z^(2^i) and z^T on the host (a few dozen products)
     fe zf, zT = fe_one();
     memcpy(zf.v, z, 32);
+    pow2_args zp;
     {
         fe b = zf;
-        for (u64 e = T; e; e >>= 1) {
+        for (int i = 0; i < 18; i++) {
+            memcpy(zp.p[i].v, b.v, 32);
+            if ((T >> i) & 1) zT = fe_mulx(zT, b);
+            b = fe_mulx(b, b);
+        }
+        for (u64 e = T >> 18; e; e >>= 1) {  // T <= 2^18, so at most the top bit is left
             if (e & 1) zT = fe_mulx(zT, b);
             b = fe_mulx(b, b);
         }
     }
-    fe_arg za, zTa;
-    memcpy(za.v, zf.v, 32);
+    fe_arg zTa;
     memcpy(zTa.v, zT.v, 32);
     {
         ProfScope prof(ctx, "eval_univariate");
-        horner_kernel<<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_coeffs, n, za, zTa, red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
+        horner_kernel<<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_coeffs, n, zp, zTa, red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
     }
     PK_LAUNCH_CHECK(ctx);
     return collect_reduction<1>(ctx, out);

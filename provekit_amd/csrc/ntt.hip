@@ -24,6 +24,8 @@
 #include <map>
 #include <vector>
 
+#include <atomic>
+
 #include "ctx.hpp"
 #include "fe29.hpp"
 
@@ -432,15 +434,22 @@ int launch_pass_r(pk_ctx* ctx, const PassParams& p, bool in_r_contig, size_t til
         const size_t tiles8 = (tiles * BT) >> (11 - LOG_R);
         const size_t lds_bytes = 9 * 2048 * 4;
         dim3 grid((unsigned)tiles8, ncols);
-        if (in_r_contig) {
-            PK_HIP(ctx, hipFuncSetAttribute((const void*)ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), true><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(p);
-        } else {
-            PK_HIP(ctx, hipFuncSetAttribute((const void*)ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), false>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), false><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(p);
+        // the 72 KiB dynamic-LDS opt-in is a per-function, per-device attribute: set it once per device, not per launch
+        static std::atomic<unsigned long long> lds_set[2] = {{0}, {0}};
+        const unsigned long long dev_bit = 1ull << (ctx->device & 63);
+        if (!(lds_set[in_r_contig].load(std::memory_order_acquire) & dev_bit)) {
+            if (in_r_contig)
+                PK_HIP(ctx, hipFuncSetAttribute((const void*)ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), true>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            else
+                PK_HIP(ctx, hipFuncSetAttribute((const void*)ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            lds_set[in_r_contig].fetch_or(dev_bit, std::memory_order_release);
         }
+        if (in_r_contig)
+            ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), true><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(p);
+        else
+            ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), false><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(p);
         PK_LAUNCH_CHECK(ctx);
         return PK_OK;
     }

@@ -25,8 +25,12 @@ __device__ __forceinline__ fe from_arg(const fe_arg& a) {
     return r;
 }
 
+// best / ticket: two device words, best == ~0 and ticket == 0 between launches.  The workgroup that draws the last ticket
+// publishes the window's smallest valid nonce (or ~0) to pinned host memory and re-arms both words, so a window costs one
+// launch and one stream synchronisation -- no copy operations.
 __global__ __launch_bounds__(256) void pow_search_kernel(fe_arg challenge_arg, fe_arg threshold_arg, unsigned long long base,
-                                                         unsigned long long count, unsigned long long* best) {
+                                                         unsigned long long count, unsigned long long* best, unsigned* ticket,
+                                                         unsigned long long* host_best) {
     const fe29 challenge = unpack_reduce29(from_arg(challenge_arg));  // generic.rs:81 reduce_partial on arbitrary input
     const fe threshold = from_arg(threshold_arg);
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
@@ -37,6 +41,15 @@ __global__ __launch_bounds__(256) void pow_search_kernel(fe_arg challenge_arg, f
         r.v[1] = (u32)(nonce >> 32);
         fe h = pack29(compress29<2>(challenge, unpack29<0>(r)));
         if (fe_lt(h, threshold)) atomicMin(best, nonce);
+    }
+    __syncthreads();  // every lane of the workgroup has issued its atomicMin
+    if (threadIdx.x == 0) {
+        __threadfence();  // device scope: orders the atomics above before the ticket (L2 is the coherence point; no write-back)
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            unsigned long long b = atomicExch(best, ~0ull);
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(host_best, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -67,6 +80,23 @@ void f64_to_u256(double f, uint64_t out[4]) {
     }
 }
 
+// device words + the pinned result slot; first use (or a re-allocated scratch buffer) initialises best = ~0, ticket = 0
+int pow_words(pk_ctx* ctx, unsigned long long** best, unsigned** ticket, unsigned long long** host_best) {
+    int rc = ensure_scratch(ctx, 64);
+    if (!rc) rc = ensure_pinned(ctx);
+    if (rc) return rc;
+    char* base = (char*)ctx->d_scratch + ctx->scratch_bytes - 64;  // the tail of the scratch buffer: clear of the reduction area
+    *best = (unsigned long long*)base;
+    *ticket = (unsigned*)(base + 8);
+    *host_best = (unsigned long long*)((char*)ctx->h_pinned + PK_PIN_POW);
+    if (!ctx->pow_armed) {
+        PK_HIP(ctx, hipMemsetAsync(base, 0xff, 8, ctx->stream));
+        PK_HIP(ctx, hipMemsetAsync(base + 8, 0, 8, ctx->stream));
+        ctx->pow_armed = true;
+    }
+    return PK_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -92,14 +122,14 @@ int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
     uint64_t thr[4];
     int rc = pk_pow_threshold(bits + 0.01, thr);  // PROVER_BIAS, pow.rs:6,37
     if (rc) return set_err(ctx, rc, "threshold");
-    rc = ensure_scratch(ctx, 64);
+    unsigned long long *d_best, *h_best;
+    unsigned* d_ticket;
+    rc = pow_words(ctx, &d_best, &d_ticket, &h_best);
     if (rc) return rc;
-    unsigned long long* d_best = (unsigned long long*)ctx->d_scratch;
     fe_arg ch, th;
     memcpy(ch.v, challenge, 32);
     memcpy(th.v, thr, 32);
     unsigned long long best = ~0ull, base = 0;
-    PK_HIP(ctx, hipMemcpyAsync(d_best, &best, 8, hipMemcpyHostToDevice, ctx->stream));
     // first window = 2x the expected work (miss probability e^-2; a miss costs one more round trip), then doubling:
     // ~2.7x the expected hashes on average instead of a fixed large window; never more lanes than nonces
     unsigned wbits = (unsigned)bits + 1;
@@ -110,10 +140,11 @@ int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
     for (;;) {
         unsigned long long want = (window + 255) / 256;
         const unsigned grid = (unsigned)(want < (unsigned long long)ctx->num_cus * 16 ? want : (unsigned long long)ctx->num_cus * 16);
-        pow_search_kernel<<<grid, 256, 0, ctx->stream>>>(ch, th, base, window, d_best);
+        pow_search_kernel<<<grid, 256, 0, ctx->stream>>>(ch, th, base, window, d_best, d_ticket, h_best);
         PK_LAUNCH_CHECK(ctx);
-        PK_HIP(ctx, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
-        PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rc = sync_stream(ctx);
+        if (rc) return rc;
+        best = *(volatile unsigned long long*)h_best;
         if (best != ~0ull) break;
         base += window;
         if (window < (1ull << 28)) window <<= 1;
@@ -135,18 +166,18 @@ int pk_pow_check(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
     uint64_t thr[4];
     int rc = pk_pow_threshold(bits, thr);
     if (rc) return set_err(ctx, rc, "threshold");
-    rc = ensure_scratch(ctx, 64);
+    unsigned long long *d_best, *h_best;
+    unsigned* d_ticket;
+    rc = pow_words(ctx, &d_best, &d_ticket, &h_best);
     if (rc) return rc;
-    unsigned long long* d_best = (unsigned long long*)ctx->d_scratch;
-    unsigned long long best = ~0ull;
     fe_arg ch, th;
     memcpy(ch.v, challenge, 32);
     memcpy(th.v, thr, 32);
-    PK_HIP(ctx, hipMemcpyAsync(d_best, &best, 8, hipMemcpyHostToDevice, ctx->stream));
-    pow_search_kernel<<<1, 64, 0, ctx->stream>>>(ch, th, nonce, 1, d_best);
+    pow_search_kernel<<<1, 64, 0, ctx->stream>>>(ch, th, nonce, 1, d_best, d_ticket, h_best);
     PK_LAUNCH_CHECK(ctx);
-    PK_HIP(ctx, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = sync_stream(ctx);
+    if (rc) return rc;
+    const unsigned long long best = *(volatile unsigned long long*)h_best;
     *ok = best == nonce;
     return PK_OK;
 }

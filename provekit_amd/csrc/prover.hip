@@ -26,6 +26,7 @@ int commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, un
                 uint64_t* d_leaves, uint64_t* d_nodes, uint64_t* d_scratch);
 int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, size_t n_leaves, size_t width, const uint64_t* indices,
              size_t k, int canonical_leaves, uint64_t* leaves_out, uint64_t* sibling_digests, uint64_t* auth_paths);
+int fold_pairs2(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint64_t* d_v1, uint64_t* d_out1, size_t len, const uint64_t* r);
 }
 
 struct pk_scheme {
@@ -228,7 +229,7 @@ int whir_commit(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, fe* const* pol
     for (unsigned b = 0; b < batch; b++) ptrs[b] = U(polys[b]);
     CK(commit_into(ctx, ptrs, batch, cfg.n_vars, cfg.starting_log_inv_rate, k, U(leaves), U(nodes), (uint64_t*)ctx->d_ws));
     fe root;
-    CK(pk_memcpy_d2h(ctx, root.v, nodes + 1, 32));
+    CK(read_root(ctx, U(nodes), C.rows, (uint64_t*)root.v));
     T.add_canon(root);
     C.ood_points.resize(cfg.commitment_ood_samples);
     T.challenge_scalars(C.ood_points.data(), C.ood_points.size());
@@ -245,9 +246,11 @@ int whir_commit(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, fe* const* pol
     return PK_OK;
 }
 
-// whir::Prover::prove with `n_weights` linear statement weights (evaluation tables of 2^n FEs on the device)
-int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitment& C, fe* const* d_weights, unsigned n_weights,
-               Transcript& T) {
+// whir::Prover::prove with `n_weights` linear statement weights: evaluation tables over the 2^n hypercube of which only the
+// first weight_len[i] entries are stored -- the rest is zero by construction (create_combined_statement_over_two_polynomials
+// zero-extends each row, whir_r1cs.rs:382-412), so nothing is spent on the zero half
+int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitment& C, fe* const* d_weights, const size_t* weight_len,
+               unsigned n_weights, Transcript& T) {
     const unsigned n = cfg.n_vars, k = cfg.folding_factor;
     const size_t N = (size_t)1 << n;
     // working polynomial c = sum_b beta^b poly_b (mtUtilities.go:98-114)
@@ -286,7 +289,7 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
         for (unsigned i = 0; i < n_weights; i++) {
             uint64_t s[4];
             h_store(s, g);
-            CK(pk_fe_axpy(ctx, U(w0), s, U(d_weights[i]), N));
+            if (weight_len[i]) CK(pk_fe_axpy(ctx, U(w0), s, U(d_weights[i]), weight_len[i]));
             g = h_mul(g, gamma);
         }
     }
@@ -317,8 +320,7 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
         if (have_fold && len >= 2) {  // apply the last challenge: p, w now describe the folded polynomial
             uint64_t f[4];
             h_store(f, fold);
-            CK(pk_fold_pairs(ctx, U(bp_[cur]), len, f, U(bp_[1 - cur])));
-            CK(pk_fold_pairs(ctx, U(bw_[cur]), len, f, U(bw_[1 - cur])));
+            CK(fold_pairs2(ctx, U(bp_[cur]), U(bp_[1 - cur]), U(bw_[cur]), U(bw_[1 - cur]), len, f));
             cur = 1 - cur;
             len /= 2;
         }
@@ -359,7 +361,7 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
         const uint64_t* ptr = U(d_c);
         CK(commit_into(ctx, &ptr, 1, nv, log_inv_rate, k, U(leaves), U(nodes), (uint64_t*)ctx->d_ws));
         fe root;
-        CK(pk_memcpy_d2h(ctx, root.v, nodes + 1, 32));
+        CK(read_root(ctx, U(nodes), rows, (uint64_t*)root.v));
         T.add_canon(root);
         // E1: OOD
         std::vector<fe> ood(cfg.ood_samples[r]);
@@ -432,7 +434,8 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
         for (int i = 0; i < 8; i++) buf.push_back((uint8_t)(cnt >> (8 * i)));
         for (unsigned i = 0; i < n_weights; i++) {
             uint64_t out[4];
-            CK(pk_dot(ctx, U(d_weights[i]), U(d_eq), N, out));
+            if (weight_len[i]) CK(pk_dot(ctx, U(d_weights[i]), U(d_eq), weight_len[i], out));
+            else memset(out, 0, sizeof out);
             fe c = h_to_canon(h_load(out));
             const uint8_t* b = (const uint8_t*)c.v;
             buf.insert(buf.end(), b, b + 32);
@@ -559,7 +562,6 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
         t_start = t;
     };
     const unsigned m = s->m, m_0 = s->m_0;
-    const size_t N = (size_t)1 << m;
 
     // --- commit to the masked witness polynomial (whir_r1cs.rs:57-69)
     BatchCommit W;
@@ -640,14 +642,15 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
             wv[4 * i + 2] = h_mul(alpha[i], alpha[i]);
             wv[4 * i + 3] = h_mul(wv[4 * i + 2], alpha[i]);
         }
-        ALLOC(d_bw, NB2);
-        CK(pk_memcpy_h2d(ctx, d_bw, wv.data(), 32 * NB2));
+        const size_t nbw = 4 * (size_t)m_0;  // the weight is zero beyond the 4 m_0 blinding coefficients
+        ALLOC(d_bw, nbw);
+        CK(pk_memcpy_h2d(ctx, d_bw, wv.data(), 32 * nbw));
         uint64_t fg[8];
-        CK(pk_dot2(ctx, U(d_bw), U(B.f_evals), U(B.g_evals), NB2, fg));
+        CK(pk_dot2(ctx, U(d_bw), U(B.f_evals), U(B.g_evals), nbw, fg));
         fe sums[2] = {h_load(fg), h_load(fg + 4)};
         T.add_scalars(sums, 2);
         fe* wts[1] = {d_bw};
-        CK(whir_prove(ctx, A, s->whir_hiding, B.com, wts, 1, T));
+        CK(whir_prove(ctx, A, s->whir_hiding, B.com, wts, &nbw, 1, T));
     }
     lap("blinding WHIR proof");
     // --- external rows and the statement over the witness commitment (whir_r1cs.rs:81-91, 382-412)
@@ -656,16 +659,15 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     ALLOC(d_rows, 3 * (n_witness ? n_witness : 1));
     CK(pk_r1cs_external_row(ctx, s->r1cs, U(d_eq_alpha), U(d_rows)));  // S4
     fe* wts[3];
+    const size_t wlen[3] = {n_witness, n_witness, n_witness};
     std::vector<uint8_t> claimed;
     {
         std::vector<fe> fsum(3), gsum(3);
         for (int k = 0; k < 3; k++) {
-            ALLOC(d_w, N);
-            CK(pk_memset_zero(ctx, d_w, 32 * N));
-            CK(pk_memcpy_d2d(ctx, d_w, d_rows + (size_t)k * n_witness, 32 * n_witness));
-            wts[k] = d_w;
-            uint64_t o[8];
-            CK(pk_dot2(ctx, U(d_w), U(W.f_evals), U(W.g_evals), N, o));  // S5
+            // the statement weight is row k zero-extended to 2^m (whir_r1cs.rs:391-400): only its support is stored and summed
+            wts[k] = d_rows + (size_t)k * n_witness;
+            uint64_t o[8] = {};
+            if (n_witness) CK(pk_dot2(ctx, U(wts[k]), U(W.f_evals), U(W.g_evals), n_witness, o));  // S5
             fsum[k] = h_load(o);
             gsum[k] = h_load(o + 4);
         }
@@ -683,7 +685,7 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     T.hint(claimed.data(), claimed.size());
     lap("external rows + sums");
     // --- WHIR weighted batch opening (whir_r1cs.rs:94-95)
-    CK(whir_prove(ctx, A, s->whir_witness, W.com, wts, 3, T));
+    CK(whir_prove(ctx, A, s->whir_witness, W.com, wts, wlen, 3, T));
     CK(pk_ctx_sync(ctx));
     lap("witness WHIR proof");
 

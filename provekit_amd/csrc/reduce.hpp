@@ -170,9 +170,12 @@ inline int reduction_scratch(pk_ctx* ctx) {
     int rc = ensure_scratch(ctx, (size_t)RED_MAX_BLOCKS * 8 * 32 + 8 * 32 + 4096);
     if (rc) return rc;
     if (!ctx->h_pinned) {  // device-visible host memory for the few field elements each round returns
-        PK_HIP(ctx, hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocMapped));
-        ctx->pinned_bytes = 4096;
+        rc = ensure_pinned(ctx);
+        if (rc) return rc;
+    }
+    if (!ctx->red_armed) {
         PK_HIP(ctx, hipMemsetAsync((char*)ctx->d_scratch + (size_t)RED_MAX_BLOCKS * 8 * 32 + 8 * 32, 0, 64, ctx->stream));
+        ctx->red_armed = true;
     }
     return PK_OK;
 }
@@ -190,7 +193,8 @@ inline unsigned next_seq(pk_ctx* ctx) {
 // loss with several provers per GPU, so the plain synchronisation is kept; the word stays for diagnostics.)
 template <int K>
 inline int collect_reduction(pk_ctx* ctx, uint64_t* host_out) {
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = sync_stream(ctx);
+    if (rc) return rc;
     memcpy(host_out, ctx->h_pinned, 32 * K);
     return PK_OK;
 }

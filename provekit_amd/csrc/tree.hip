@@ -27,22 +27,25 @@ struct pk_tree {
 
 namespace {
 
-// gather k opened leaves to leaf-major order; optionally convert to canonical (ark-serialize form)
-__global__ __launch_bounds__(256) void gather_leaves_kernel(const fe* __restrict__ leaves, size_t n_leaves, unsigned width, int layout,
-                                                            const unsigned long long* __restrict__ idx, size_t k, int canonical,
-                                                            fe* __restrict__ out) {
+// One launch serves an opening: the first k*width lanes gather the opened leaves to leaf-major order (optionally
+// converted to canonical, the ark-serialize form), the next k*(plen+1) lanes the sibling digests -- out_sib[q] =
+// nodes[(n+i)^1]; out_path[q][d-1] = sibling of the depth-d ancestor, d = 1..logn-1 (root -> leaf).  idx and the three
+// outputs live in the context's pinned mailbox: the kernel reads the indices from and writes the openings to host memory
+// directly, so an opening costs no copy operations.
+__global__ __launch_bounds__(256) void gather_opening_kernel(const fe* __restrict__ leaves, const fe* __restrict__ nodes, size_t n_leaves,
+                                                             unsigned width, int layout, unsigned logn,
+                                                             const unsigned long long* __restrict__ idx, size_t k, int canonical,
+                                                             fe* __restrict__ out_leaves, fe* __restrict__ out_sib, fe* __restrict__ out_path) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= k * width) return;
-    size_t q = t / width, j = t % width;
-    size_t i = idx[q];
-    fe x = fe_load(leaves + (layout == PK_COL_MAJOR ? j * n_leaves + i : i * (size_t)width + j));
-    fe_store(out + t, canonical ? fe_from_montx(x) : x);
-}
-// sibling digests: out_sib[q] = nodes[(n+i)^1]; out_path[q][d-1] = sibling of the depth-d ancestor, d = 1..logn-1 (root -> leaf)
-__global__ __launch_bounds__(256) void gather_paths_kernel(const fe* __restrict__ nodes, size_t n_leaves, unsigned logn,
-                                                           const unsigned long long* __restrict__ idx, size_t k, fe* __restrict__ out_sib,
-                                                           fe* __restrict__ out_path) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n1 = k * width;
+    if (t < n1) {
+        size_t q = t / width, j = t % width;
+        size_t i = idx[q];
+        fe x = fe_load(leaves + (layout == PK_COL_MAJOR ? j * n_leaves + i : i * (size_t)width + j));
+        fe_store(out_leaves + t, canonical ? fe_from_montx(x) : x);
+        return;
+    }
+    t -= n1;
     const unsigned plen = logn ? logn - 1 : 0;
     if (t >= k * (size_t)(plen + 1)) return;
     size_t q = t / (plen + 1), d = t % (plen + 1);
@@ -116,7 +119,7 @@ int pk_commit(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsi
     rc = ensure_ws(ctx, 2 * rows * width * 32);
     if (!rc) rc = pk_rs_encode(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, (uint64_t*)t->d_leaves, (uint64_t*)ctx->d_ws);
     if (!rc) rc = pk_merkle_commit(ctx, (const uint64_t*)t->d_leaves, rows, width, PK_COL_MAJOR, (uint64_t*)t->d_nodes);
-    if (!rc && root_out) rc = pk_memcpy_d2h(ctx, root_out, t->d_nodes + 1, 32);
+    if (!rc && root_out) rc = read_root(ctx, (const uint64_t*)t->d_nodes, rows, (uint64_t*)root_out);
     if (rc) {
         pk_tree_destroy(ctx, t);
         return rc;
@@ -144,7 +147,7 @@ int pk_tree_from_leaves(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, 
         return set_err(ctx, PK_ERR_OOM, "hipMalloc of the tree failed");
     }
     int rc = pk_merkle_commit(ctx, d_leaves, n_leaves, width, layout, (uint64_t*)t->d_nodes);
-    if (!rc && root_out) rc = pk_memcpy_d2h(ctx, root_out, t->d_nodes + 1, 32);
+    if (!rc && root_out) rc = read_root(ctx, (const uint64_t*)t->d_nodes, n_leaves, (uint64_t*)root_out);
     if (rc) {
         pk_tree_destroy(ctx, t);
         return rc;
@@ -177,23 +180,24 @@ int pk_tree_open(pk_ctx* ctx, const pk_tree* t, const uint64_t* indices, size_t 
     const unsigned plen = logn ? logn - 1 : 0;
     PK_REQUIRE(ctx, plen == 0 || auth_paths, "null pointer");
     for (size_t q = 0; q < k; q++) PK_REQUIRE(ctx, indices[q] < t->n_leaves, "leaf index out of range");
-    const size_t idx_bytes = ((k * 8 + 31) / 32) * 32;
-    int rc = ensure_ws(ctx, idx_bytes + 32 * (k * t->width + k + k * plen));
+    const size_t idx_bytes = ((k * 8 + 63) / 64) * 64;
+    const size_t n1 = k * t->width, n2 = k * (size_t)(plen + 1);
+    char* mail = nullptr;
+    int rc = mail_alloc(ctx, idx_bytes + 32 * (n1 + k + k * plen), (void**)&mail);
     if (rc) return rc;
-    unsigned long long* d_idx = (unsigned long long*)ctx->d_ws;
-    fe* d_leaves_out = (fe*)((char*)ctx->d_ws + idx_bytes);
-    fe* d_sib = d_leaves_out + k * t->width;
-    fe* d_path = d_sib + k;
-    PK_HIP(ctx, hipMemcpyAsync(d_idx, indices, k * 8, hipMemcpyHostToDevice, ctx->stream));
-    size_t n1 = k * t->width, n2 = k * (size_t)(plen + 1);
-    gather_leaves_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, ctx->stream>>>(t->d_leaves, t->n_leaves, (unsigned)t->width, t->layout, d_idx, k,
-                                                                              canonical_leaves, d_leaves_out);
-    gather_paths_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, ctx->stream>>>(t->d_nodes, t->n_leaves, logn, d_idx, k, d_sib, d_path);
+    unsigned long long* m_idx = (unsigned long long*)mail;
+    fe* m_leaves = (fe*)(mail + idx_bytes);
+    fe* m_sib = m_leaves + n1;
+    fe* m_path = m_sib + k;
+    memcpy(m_idx, indices, k * 8);
+    gather_opening_kernel<<<(unsigned)((n1 + n2 + 255) / 256), 256, 0, ctx->stream>>>(t->d_leaves, t->d_nodes, t->n_leaves, (unsigned)t->width, t->layout,
+                                                                                      logn, m_idx, k, canonical_leaves, m_leaves, m_sib, m_path);
     PK_LAUNCH_CHECK(ctx);
-    PK_HIP(ctx, hipMemcpyAsync(leaves_out, d_leaves_out, 32 * n1, hipMemcpyDeviceToHost, ctx->stream));
-    if (logn) PK_HIP(ctx, hipMemcpyAsync(sibling_digests, d_sib, 32 * k, hipMemcpyDeviceToHost, ctx->stream));
-    if (plen) PK_HIP(ctx, hipMemcpyAsync(auth_paths, d_path, 32 * k * plen, hipMemcpyDeviceToHost, ctx->stream));
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // not sync_stream: the mailbox is read below
+    memcpy(leaves_out, m_leaves, 32 * n1);
+    if (logn) memcpy(sibling_digests, m_sib, 32 * k);
+    if (plen) memcpy(auth_paths, m_path, 32 * k * plen);
+    ctx->mail_off = 0;
     return PK_OK;
 }
 
