@@ -1,15 +1,16 @@
 // hash.hip -- Skyscraper batch compression and Merkle-tree kernels.
 //
-// One lane = one compression chain.  The work is integer-ALU bound (12 Montgomery
-// squarings per compression, ~1.6k quarter-rate v_mad_u64_u32 per lane), so the
-// kernels are organised for occupancy and coalesced 32-byte-per-lane traffic, not
-// for LDS reuse:
+// One lane = one compression chain.  The work is integer-ALU bound (14 Montgomery
+// squarings + 4 bars per v2 compression: ~1.9k v_mad_u64_u32 and ~3.6k other VALU
+// instructions per lane), so the kernels are organised for occupancy and
+// coalesced 32-byte-per-lane traffic, not for LDS reuse:
 //   compress_many : lane i reads message i (64 B contiguous), writes hash i (32 B).
 //   leaf_hash     : lane i owns leaf i; in PK_COL_MAJOR (the layout pk_commit keeps
 //                   in HBM) column j of all leaves is contiguous, so every step of
 //                   the 31-deep left fold is one coalesced 2 KiB wave read.
-//   merkle_level  : lane i owns inner node i of one level; children 2i,2i+1 are
-//                   adjacent in the heap, so a wave reads 4 KiB contiguous.
+//   merkle_levels : lane i owns inner node i of the widest of up to 5 fused levels;
+//                   children 2i,2i+1 are adjacent in the heap, so a wave reads 4 KiB
+//                   contiguous; the workgroup then walks up its own subtree.
 #include "ctx.hpp"
 #include "skyscraper29.hpp"
 
