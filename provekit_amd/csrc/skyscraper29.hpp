@@ -20,7 +20,8 @@ PK_HD constexpr u32 rc29(int rci, int k) {
     return (u32)(((lo | (hi << 32)) >> sh)) & M29;
 }
 
-// bar on an almost-reduced value: canonicalise, swap halves, byte S-box, back to almost-reduced
+// bar on an almost-reduced value: canonicalise, swap halves, byte S-box; the result is normalized and < 2.3p (one clamped
+// quotient step) -- enough for the round's own reduce_almost29, which sees r + bar + rc < 4.3p (quotient <= 4)
 PK_HD fe29 bar29(const fe29& l) {
     fe x = pack29(cond_sub_p29(l));
     fe y;
@@ -29,22 +30,21 @@ PK_HD fe29 bar29(const fe29& l) {
         y.v[i] = sbox4(x.v[i + 4]);
         y.v[i + 4] = sbox4(x.v[i]);
     }
-    fe29 r = unpack29<0>(y);  // < 2^256 < 6p
+    fe29 r = unpack29<0>(y);  // < 2^256 < 5.3p
     u32 q = quot_estimate29(r.v[8]);
-    u32 q1 = q > 3u ? 3u : q;  // keep q*p_k inside the signed 32-bit limb range
+    u32 q1 = q > 3u ? 3u : q;  // keep q*p_k inside the signed 32-bit limb range; leaves < 2.3p
     sub_qp29(r, q1);
     normalize29(r);
-    reduce_almost29(r);
     return r;
 }
 
 template <int RCI, bool BAR>
 PK_HD void sky_round29(fe29& l, fe29& r) {
-    fe29 f = BAR ? bar29(l) : sqr256_29(l);  // sqr: < l^2/2^256 + p < 1.2p
+    fe29 f = BAR ? bar29(l) : sqr256_29(l);  // sqr: < l^2/2^256 + p < 1.2p;  bar: < 2.3p
     fe29 s;
 #pragma unroll
     for (int k = 0; k < 9; k++) s.v[k] = r.v[k] + f.v[k] + ((RCI != 0 && RCI != 17) ? rc29(RCI, k) : 0u);
-    reduce_almost29(s);  // s < 3.2p  ->  quotient estimate <= 3
+    reduce_almost29(s);  // s < 4.3p  ->  quotient estimate <= 4 (4 p_k < 2^31: the signed limb sweep still holds)
     r = l;
     l = s;
 }
