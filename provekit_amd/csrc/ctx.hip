@@ -205,7 +205,7 @@ int ensure_scratch(pk_ctx* ctx, size_t bytes) {
 }
 int ensure_pinned(pk_ctx* ctx) {
     if (ctx->h_pinned) return PK_OK;
-    PK_HIP(ctx, hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocMapped));
+    PK_HIP(ctx, hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocMapped | hipHostMallocCoherent));
     memset(ctx->h_pinned, 0, 4096);
     ctx->pinned_bytes = 4096;
     return PK_OK;
@@ -226,7 +226,7 @@ int mail_alloc(pk_ctx* ctx, size_t bytes, void** out) {
             if (ctx->h_mail) PK_HIP(ctx, hipHostFree(ctx->h_mail));
             ctx->h_mail = nullptr;
             ctx->mail_bytes = 0;
-            PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_mail, cap, hipHostMallocMapped));
+            PK_HIP(ctx, hipHostMalloc((void**)&ctx->h_mail, cap, hipHostMallocMapped | hipHostMallocCoherent));
             ctx->mail_bytes = cap;
         }
     }
