@@ -358,7 +358,7 @@ def main():
         # command is used; null when it is missing or was taken on another workload size.
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01c_pmc_leaf_hash.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc_leaf_hash.json")))
             if m == 21:
                 traffic = pmc["traffic_bytes_per_launch"]
         except Exception:
