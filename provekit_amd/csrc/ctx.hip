@@ -44,7 +44,7 @@ int pk_ctx_create(int device, pk_ctx** out) {
 }
 
 int pk_ctx_destroy(pk_ctx* ctx) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     pk::ntt_release_ctx(ctx);
@@ -67,18 +67,18 @@ int pk_ctx_destroy(pk_ctx* ctx) {
 const char* pk_last_error(const pk_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
 int pk_ctx_set_stream(pk_ctx* ctx, void* hip_stream) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return PK_OK;
 }
 
 int pk_ctx_sync(pk_ctx* ctx) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     return sync_stream(ctx);
 }
 
 int pk_ctx_set_hash_version(pk_ctx* ctx, int version) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, version == 1 || version == 2, "hash version must be 1 or 2");
     ctx->hash_version = version;
     return PK_OK;
@@ -92,14 +92,14 @@ int pk_malloc(pk_ctx* ctx, size_t bytes, void** d_ptr) {
     return PK_OK;
 }
 int pk_free(pk_ctx* ctx, void* d_ptr) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     if (!d_ptr) return PK_OK;
     PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PK_HIP(ctx, hipFree(d_ptr));
     return PK_OK;
 }
 int pk_memcpy_h2d(pk_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, bytes == 0 || (d_dst && src), "null pointer");
     if (!bytes) return PK_OK;
     PK_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -107,7 +107,7 @@ int pk_memcpy_h2d(pk_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
     return PK_OK;
 }
 int pk_memcpy_d2h(pk_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, bytes == 0 || (dst && d_src), "null pointer");
     if (!bytes) return PK_OK;
     PK_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -115,26 +115,27 @@ int pk_memcpy_d2h(pk_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
     return PK_OK;
 }
 int pk_memcpy_d2d(pk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, bytes == 0 || (d_dst && d_src), "null pointer");
     if (!bytes) return PK_OK;
     PK_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return PK_OK;
 }
 int pk_memset_zero(pk_ctx* ctx, void* d_dst, size_t bytes) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, bytes == 0 || d_dst, "null pointer");
     if (!bytes) return PK_OK;
     PK_HIP(ctx, hipMemsetAsync(d_dst, 0, bytes, ctx->stream));
     return PK_OK;
 }
 int pk_timer_start(pk_ctx* ctx) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     return PK_OK;
 }
 int pk_timer_stop(pk_ctx* ctx, float* ms) {
     if (!ctx || !ms) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     PK_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
     PK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev_start, ctx->ev_stop));
@@ -142,12 +143,12 @@ int pk_timer_stop(pk_ctx* ctx, float* ms) {
 }
 
 int pk_profile_enable(pk_ctx* ctx, int on) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     ctx->prof_on = on != 0;
     return PK_OK;
 }
 int pk_profile_reset(pk_ctx* ctx) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (auto& r : ctx->prof) {
         ctx->ev_pool.push_back(r.e0);
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void fe_elementwise_kernel(const fe* __restric
 
 template <int OP>
 static int launch_elementwise(pk_ctx* ctx, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, n == 0 || (a && out && (b || OP >= OP_TO_MONT)), "null pointer");
     if (!n) return PK_OK;
     fe_elementwise_kernel<OP><<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((const fe*)a, (const fe*)b, (fe*)out, n);

@@ -78,6 +78,15 @@ inline int set_err(pk_ctx* ctx, int code, const char* fmt, ...) {
 
 #define PK_LAUNCH_CHECK(ctx) PK_HIP(ctx, hipGetLastError())
 
+// first line of every entry point that touches the device: the HIP current device is per host thread, and callers (one
+// prover thread per context, one context per GPU) need not have selected this context's device on the calling thread
+#define PK_ENTER(ctx)                                                                              \
+    do {                                                                                           \
+        if (!(ctx)) return PK_ERR_BAD_ARG;                                                         \
+        if (hipSetDevice((ctx)->device) != hipSuccess)                                             \
+            return pk::set_err(ctx, PK_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device);         \
+    } while (0)
+
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 inline unsigned ilog2(size_t x) {
     unsigned l = 0;

@@ -120,7 +120,7 @@ int read_root(pk_ctx* ctx, const uint64_t* d_nodes, size_t n_leaves, uint64_t ro
 extern "C" {
 
 int pk_compress_many(pk_ctx* ctx, const uint8_t* d_messages, uint8_t* d_hashes, size_t n) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, n == 0 || (d_messages && d_hashes), "null pointer");
     if (!n) return PK_OK;
     ProfScope prof(ctx, "compress_many");
@@ -134,7 +134,7 @@ int pk_compress_many(pk_ctx* ctx, const uint8_t* d_messages, uint8_t* d_hashes, 
 }
 
 int pk_compress_many_host(pk_ctx* ctx, const uint8_t* messages, size_t messages_len, uint8_t* hashes, size_t hashes_len) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     // generic.rs:18-25: "Message length not a multiple of 64" / "Hashes length not a multiple of 32" / mismatch
     PK_REQUIRE(ctx, messages_len % 64 == 0, "message length not a multiple of 64");
     PK_REQUIRE(ctx, hashes_len % 32 == 0, "hashes length not a multiple of 32");
@@ -159,7 +159,7 @@ int pk_compress_many_host(pk_ctx* ctx, const uint8_t* messages, size_t messages_
 }
 
 int pk_leaf_hash(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, uint64_t* d_digests) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, width >= 1, "leaf width must be >= 1 (IncorrectInputLength(0))");  // whir.rs:47
     PK_REQUIRE(ctx, width < (1u << 20), "leaf width too large");
     PK_REQUIRE(ctx, layout == PK_LEAF_MAJOR || layout == PK_COL_MAJOR, "unknown layout");
@@ -169,7 +169,7 @@ int pk_leaf_hash(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t 
 }
 
 int pk_merkle_inner(pk_ctx* ctx, uint64_t* d_nodes, size_t n_leaves) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, is_pow2(n_leaves), "n_leaves must be a power of two");  // ark MerkleTree::new asserts this
     PK_REQUIRE(ctx, d_nodes, "null pointer");
     fe* N = (fe*)d_nodes;
@@ -201,7 +201,7 @@ int pk_merkle_inner(pk_ctx* ctx, uint64_t* d_nodes, size_t n_leaves) {
 }
 
 int pk_merkle_commit(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, uint64_t* d_nodes) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, is_pow2(n_leaves), "n_leaves must be a power of two");
     PK_REQUIRE(ctx, d_nodes, "null pointer");
     int rc = pk_leaf_hash(ctx, d_leaves, n_leaves, width, layout, d_nodes + 4 * n_leaves);

@@ -386,28 +386,28 @@ __global__ __launch_bounds__(256) void axpy_kernel(fe* __restrict__ y, const fe*
 extern "C" {
 
 int pk_to_coeffs(pk_ctx* ctx, uint64_t* d_evals, unsigned n_vars) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     return wavelet<true>(ctx, nullptr, d_evals, n_vars);
 }
 int pk_to_evals(pk_ctx* ctx, uint64_t* d_coeffs, unsigned n_vars) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     return wavelet<false>(ctx, nullptr, d_coeffs, n_vars);
 }
 // out-of-place forms: d_dst receives the transform of d_src (which is left untouched)
 int pk_to_coeffs_into(pk_ctx* ctx, const uint64_t* d_src, uint64_t* d_dst, unsigned n_vars) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, d_src && d_src != d_dst, "source must differ from destination");
     return wavelet<true>(ctx, d_src, d_dst, n_vars);
 }
 int pk_to_evals_into(pk_ctx* ctx, const uint64_t* d_src, uint64_t* d_dst, unsigned n_vars) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, d_src && d_src != d_dst, "source must differ from destination");
     return wavelet<false>(ctx, d_src, d_dst, n_vars);
 }
 
 int pk_eq_accumulate(pk_ctx* ctx, uint64_t* d_w, unsigned n_vars, const uint64_t* points, const uint64_t* scales, unsigned q,
                      int overwrite) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, d_w && (q == 0 || (points && scales)), "null pointer");
     PK_REQUIRE(ctx, n_vars <= 30, "too many variables");
     const size_t n = (size_t)1 << n_vars;
@@ -441,14 +441,14 @@ int pk_eq_accumulate(pk_ctx* ctx, uint64_t* d_w, unsigned n_vars, const uint64_t
 }
 
 int pk_eq_table(pk_ctx* ctx, const uint64_t* r, unsigned m, uint64_t* d_out) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     static const uint64_t one[4] = {0xac96341c4ffffffbULL, 0x36fc76959f60cd29ULL, 0x666ea36f7879462eULL, 0x0e0a77c19a07df2fULL};
     return pk_eq_accumulate(ctx, d_out, m, r, one, 1, 1);
 }
 
 int pk_sumcheck_cubic_round(pk_ctx* ctx, uint64_t* d_a, uint64_t* d_b, uint64_t* d_c, uint64_t* d_eq, size_t len,
                             const uint64_t* fold_or_null, uint64_t out[12]) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, d_a && d_b && d_c && d_eq && out, "null pointer");
     PK_REQUIRE(ctx, is_pow2(len) && len >= 2, "size must be a power of two >= 2");  // sumcheck.rs:22-23
     PK_REQUIRE(ctx, !fold_or_null || len >= 4, "size must be >= 4 when folding");    // sumcheck.rs:27
@@ -471,7 +471,7 @@ int pk_sumcheck_cubic_round(pk_ctx* ctx, uint64_t* d_a, uint64_t* d_b, uint64_t*
 
 int pk_sumcheck_quadratic_round(pk_ctx* ctx, const uint64_t* d_f, const uint64_t* d_w, size_t len, const uint64_t* fold_or_null,
                                 uint64_t* d_f_out, uint64_t* d_w_out, uint64_t out[12]) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, d_f && d_w && out, "null pointer");
     PK_REQUIRE(ctx, is_pow2(len), "size must be a power of two");
     size_t out_len = fold_or_null ? len / 2 : len;
@@ -495,7 +495,7 @@ int pk_sumcheck_quadratic_round(pk_ctx* ctx, const uint64_t* d_f, const uint64_t
 }
 
 int pk_fold_pairs(pk_ctx* ctx, const uint64_t* d_v, size_t len, const uint64_t* r, uint64_t* d_out) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, d_v && d_out && r && d_v != d_out, "null or aliased pointer");
     PK_REQUIRE(ctx, is_pow2(len) && len >= 2, "size must be a power of two >= 2");
     fold_pairs_kernel<<<grid_for(ctx, len / 2, 256), 256, 0, ctx->stream>>>((const fe*)d_v, (fe*)d_out, nullptr, nullptr, len / 2, to_arg(r));
@@ -517,7 +517,7 @@ int fold_pairs2(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint6
 extern "C" {
 
 int pk_dot(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, size_t n, uint64_t out[4]) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, out && (n == 0 || (d_w && d_f)), "null pointer");
     if (n == 0) {
         memset(out, 0, 32);
@@ -536,7 +536,7 @@ int pk_dot(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, size_t n, uint
 }
 
 int pk_dot2(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, const uint64_t* d_g, size_t n, uint64_t out[8]) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, out && (n == 0 || (d_w && d_f && d_g)), "null pointer");
     if (n == 0) {
         memset(out, 0, 64);
@@ -555,7 +555,7 @@ int pk_dot2(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, const uint64_
 }
 
 int pk_eval_univariate(pk_ctx* ctx, const uint64_t* d_coeffs, size_t n, const uint64_t z[4], uint64_t out[4]) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, out && z && (n == 0 || d_coeffs), "null pointer");
     if (n == 0) {
         memset(out, 0, 32);
@@ -594,7 +594,7 @@ int pk_eval_univariate(pk_ctx* ctx, const uint64_t* d_coeffs, size_t n, const ui
 }
 
 int pk_fold_coeffs(pk_ctx* ctx, const uint64_t* d_coeffs, unsigned n_vars, const uint64_t* r, unsigned k, uint64_t* d_out) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, d_coeffs && d_out && (k == 0 || r), "null pointer");
     PK_REQUIRE(ctx, k <= 8 && k <= n_vars, "fold factor out of range");
     fold_args ra{};
@@ -607,7 +607,7 @@ int pk_fold_coeffs(pk_ctx* ctx, const uint64_t* d_coeffs, unsigned n_vars, const
 }
 
 int pk_fe_axpy(pk_ctx* ctx, uint64_t* d_y, const uint64_t* beta, const uint64_t* d_x, size_t n) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, beta && (n == 0 || (d_y && d_x)), "null pointer");
     if (!n) return PK_OK;
     axpy_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_y, (const fe*)d_x, n, to_arg(beta));

@@ -638,7 +638,7 @@ int deinterleave(pk_ctx* ctx, const fe* coeffs, size_t n_coeffs, unsigned fold, 
 extern "C" {
 
 int pk_ntt(pk_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, unsigned log_n, unsigned ncols) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, d_in && d_out, "null pointer");
     PK_REQUIRE(ctx, ncols >= 1, "ncols must be >= 1");
     size_t N = (size_t)1 << log_n;
@@ -655,7 +655,7 @@ int pk_ntt(pk_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, unsigned log_n, u
 
 int pk_rs_encode(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
                  unsigned fold, uint64_t* d_leaves, uint64_t* d_scratch) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, d_coeffs && d_leaves && d_scratch, "null pointer");
     PK_REQUIRE(ctx, batch >= 1 && batch <= 16, "batch out of range");
     PK_REQUIRE(ctx, fold <= n_vars && fold <= 8, "fold out of range");
@@ -677,7 +677,7 @@ int pk_rs_encode(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, u
 // d_scratch: (batch*2^fold) * (rows + 2*rows/G) FEs.
 int pk_rs_encode_shard(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
                        unsigned fold, unsigned shard, unsigned n_shards, uint64_t* d_leaves_local, uint64_t* d_scratch) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, d_coeffs && d_leaves_local && d_scratch, "null pointer");
     PK_REQUIRE(ctx, batch >= 1 && batch <= 16, "batch out of range");
     PK_REQUIRE(ctx, fold <= n_vars && fold <= 8, "fold out of range");

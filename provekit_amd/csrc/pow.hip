@@ -112,7 +112,7 @@ int pk_pow_threshold(double difficulty, uint64_t out[4]) {
 
 // PowStrategy::solve (provekit/common/src/skyscraper/pow.rs:27-29) -> pow::solve (pow.rs:33-41)
 int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t* nonce) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, challenge && nonce, "null pointer");
     PK_REQUIRE(ctx, bits >= 0.0 && bits < 60.0, "bits must be smaller than 60");  // skyscraper/pow.rs:16
     if (bits == 0.0) {  // pow.rs:34-36
@@ -156,7 +156,7 @@ int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
 
 // PowStrategy::check (skyscraper/pow.rs:23-25) -> pow::verify (pow.rs:24-26): NO prover bias
 int pk_pow_check(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t nonce, int* ok) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, challenge && ok, "null pointer");
     PK_REQUIRE(ctx, bits >= 0.0 && bits < 60.0, "bits must be smaller than 60");
     if (bits == 0.0) {

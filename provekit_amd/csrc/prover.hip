@@ -497,7 +497,7 @@ std::string domain_separator_for(const pk_scheme& s) {
 extern "C" {
 
 int pk_scheme_destroy(pk_ctx* ctx, pk_scheme* s) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     if (!s) return PK_OK;
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(s->arena);
@@ -508,6 +508,7 @@ int pk_scheme_destroy(pk_ctx* ctx, pk_scheme* s) {
 int pk_scheme_create(pk_ctx* ctx, const pk_r1cs* r1cs, size_t num_constraints, size_t num_witnesses, unsigned m, unsigned m_0,
                      const pk_whir_config* whir_witness, const pk_whir_config* whir_for_hiding_spartan, pk_scheme** out) {
     if (!ctx || !out) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     *out = nullptr;
     PK_REQUIRE(ctx, r1cs && whir_witness && whir_for_hiding_spartan, "null pointer");
     PK_REQUIRE(ctx, m >= 1 && m <= 27 && m_0 <= 27, "scheme size out of range");
@@ -545,7 +546,7 @@ int pk_scheme_create(pk_ctx* ctx, const pk_r1cs* r1cs, size_t num_constraints, s
 
 int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witness, uint64_t rng_seed, uint8_t* transcript_out,
              size_t cap, size_t* len) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, s && d_witness && len, "null pointer");
     PK_REQUIRE(ctx, n_witness == s->num_witnesses, "Unexpected witness length for R1CS instance");  // whir_r1cs.rs:43-46
     Arena A{s->arena, s->arena_bytes};

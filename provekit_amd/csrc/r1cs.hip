@@ -82,7 +82,7 @@ int upload_u32(pk_ctx* ctx, const std::vector<uint32_t>& v, uint32_t** out) {
 extern "C" {
 
 int pk_r1cs_destroy(pk_ctx* ctx, pk_r1cs* r) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     if (!r) return PK_OK;
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(r->d_interner);
@@ -97,6 +97,7 @@ int pk_r1cs_destroy(pk_ctx* ctx, pk_r1cs* r) {
 int pk_r1cs_create(pk_ctx* ctx, size_t num_constraints, size_t num_witnesses, const pk_sparse_matrix mats[3],
                    const uint64_t* interner, size_t n_interned, pk_r1cs** out) {
     if (!ctx || !out) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     *out = nullptr;
     PK_REQUIRE(ctx, mats && (interner || n_interned == 0), "null pointer");
     PK_REQUIRE(ctx, num_constraints < (1ull << 32) && num_witnesses < (1ull << 32), "dimension above u32");
@@ -152,7 +153,7 @@ int pk_r1cs_create(pk_ctx* ctx, size_t num_constraints, size_t num_witnesses, co
 
 int pk_r1cs_witness_bounds(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, unsigned m0, uint64_t* d_a, uint64_t* d_b,
                            uint64_t* d_c) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, r && d_z && d_a && d_b && d_c, "null pointer");
     PK_REQUIRE(ctx, m0 <= 30 && r->num_constraints <= ((size_t)1 << m0), "R1CS constraints exceed scheme capacity");  // whir_r1cs.rs:52-54
     size_t padded = (size_t)1 << m0;
@@ -165,7 +166,7 @@ int pk_r1cs_witness_bounds(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, u
 }
 
 int pk_r1cs_matvec(pk_ctx* ctx, const pk_r1cs* r, int matrix, int transpose, const uint64_t* d_x, uint64_t* d_y) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, r && d_x && d_y, "null pointer");
     PK_REQUIRE(ctx, matrix >= 0 && matrix < 3, "matrix must be 0 (A), 1 (B) or 2 (C)");
     size_t n_out = transpose ? r->num_witnesses : r->num_constraints;
@@ -180,7 +181,7 @@ int pk_r1cs_matvec(pk_ctx* ctx, const pk_r1cs* r, int matrix, int transpose, con
 }
 
 int pk_r1cs_test_witness_satisfaction(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_witness, size_t n_witness, int64_t* first_failed_row) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, r && first_failed_row, "null pointer");
     PK_REQUIRE(ctx, n_witness == r->num_witnesses, "Witness size does not match");  // r1cs.rs:42-45
     *first_failed_row = -1;
@@ -209,7 +210,7 @@ int pk_r1cs_test_witness_satisfaction(pk_ctx* ctx, const pk_r1cs* r, const uint6
 
 // calculate_external_row_of_r1cs_matrices (sumcheck.rs:207-218): [eq^T A, eq^T B, eq^T C], each num_witnesses long
 int pk_r1cs_external_row(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_eq_alpha, uint64_t* d_out) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, r && d_eq_alpha && d_out, "null pointer");
     for (int m = 0; m < 3; m++) {
         int rc = pk_r1cs_matvec(ctx, r, m, 1, d_eq_alpha, d_out + 4 * (size_t)m * r->num_witnesses);

@@ -79,6 +79,7 @@ extern "C" {
 
 int pk_selftest_modmul_rate(pk_ctx* ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double* modmul_per_s) {
     if (!ctx || !modmul_per_s) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, waves_per_simd >= 1 && waves_per_simd <= 8 && (ilp == 1 || ilp == 2 || ilp == 4) && iters >= 1, "waves 1..8, ilp 1|2|4");
     int rc = ensure_scratch(ctx, 64 * 32);
     if (rc) return rc;
@@ -105,6 +106,7 @@ int pk_selftest_modmul_rate(pk_ctx* ctx, unsigned waves_per_simd, unsigned ilp, 
 // the same ops executed by a kernel (device pointers): lets the GPU suite diff device vs host codegen
 int pk_selftest_arith_device(pk_ctx* ctx, int op, const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, size_t n) {
     if (!ctx || !d_a || !d_out) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     if (!n) return PK_OK;
     selftest_kernel<<<(unsigned)((n + 63) / 64), 64, 0, ctx->stream>>>(op, (const fe*)d_a, (const fe*)d_b, (fe*)d_out, n);
     PK_LAUNCH_CHECK(ctx);

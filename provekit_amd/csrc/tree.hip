@@ -88,7 +88,7 @@ int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, siz
 extern "C" {
 
 int pk_tree_destroy(pk_ctx* ctx, pk_tree* t) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     if (!t) return PK_OK;
     (void)hipStreamSynchronize(ctx->stream);
     if (t->owns_leaves) (void)hipFree(t->d_leaves);
@@ -100,6 +100,7 @@ int pk_tree_destroy(pk_ctx* ctx, pk_tree* t) {
 int pk_commit(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
               uint8_t root_out[32], pk_tree** out) {
     if (!ctx || !out) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     *out = nullptr;
     PK_REQUIRE(ctx, d_coeffs, "null pointer");
     PK_REQUIRE(ctx, batch >= 1 && batch <= 16, "batch out of range");
@@ -132,6 +133,7 @@ int pk_commit(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsi
 int pk_tree_from_leaves(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, uint8_t root_out[32],
                         pk_tree** out) {
     if (!ctx || !out) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     *out = nullptr;
     PK_REQUIRE(ctx, d_leaves, "null pointer");
     PK_REQUIRE(ctx, is_pow2(n_leaves), "n_leaves must be a power of two");
@@ -166,14 +168,14 @@ int pk_tree_info(const pk_tree* t, size_t* n_leaves, size_t* width, const uint64
 }
 
 int pk_tree_root(pk_ctx* ctx, const pk_tree* t, uint8_t root[32]) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, t && root, "null pointer");
     return pk_memcpy_d2h(ctx, root, t->d_nodes + 1, 32);
 }
 
 int pk_tree_open(pk_ctx* ctx, const pk_tree* t, const uint64_t* indices, size_t k, int canonical_leaves, uint64_t* leaves_out,
                  uint64_t* sibling_digests, uint64_t* auth_paths) {
-    if (!ctx) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
     PK_REQUIRE(ctx, t && (k == 0 || (indices && leaves_out && sibling_digests)), "null pointer");
     if (!k) return PK_OK;
     const unsigned logn = ilog2(t->n_leaves);
