@@ -235,6 +235,10 @@ int pk_pow_threshold(double difficulty, uint64_t out[4]);
 int pk_pow_solve(pk_ctx *ctx, const uint8_t challenge[32], double bits, uint64_t *nonce);
 int pk_pow_check(pk_ctx *ctx, const uint8_t challenge[32], double bits, uint64_t nonce, int *ok);
 
+/* The leaf half of an opening by itself: k rows of a codeword matrix the caller holds on the device (one rank's shard of
+ * a multi-GPU commit -- SURVEY 8e: leaf i is served by GPU i mod G) gathered to leaf-major host memory, k*width FEs. */
+int pk_gather_leaves(pk_ctx *ctx, const uint64_t *d_leaves, size_t n_leaves, size_t width, int layout,
+                     const uint64_t *indices, size_t k, int canonical_leaves, uint64_t *leaves_out);
 /* ------------------------------------------------------------------ commitment handle + openings (N1+N2+M1+M2, Q1)
  * pk_commit: the data-parallel body of whir's CommitmentWriter::commit_batch
  * (provekit/prover/src/whir_r1cs.rs:200-206): RS-encode `batch` coefficient vectors, hash the leaves

@@ -105,6 +105,7 @@ SIGNATURES = {
     "pk_tree_root": (C.c_int, [vp, vp, vp]),
     "pk_tree_open": (C.c_int, [vp, vp, vp, sz, C.c_int, vp, vp, vp]),
     "pk_tree_destroy": (C.c_int, [vp, vp]),
+    "pk_gather_leaves": (C.c_int, [vp, vp, sz, sz, C.c_int, vp, sz, C.c_int, vp]),
     "pk_multipath_serialize": (C.c_int, [vp, sz, sz, vp, vp, vp, sz, C.POINTER(sz)]),
     "pk_scheme_create": (C.c_int, [vp, vp, sz, sz, C.c_uint, C.c_uint, vp, vp, C.POINTER(vp)]),
     "pk_scheme_destroy": (C.c_int, [vp, vp]),

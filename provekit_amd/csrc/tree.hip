@@ -203,6 +203,31 @@ int pk_tree_open(pk_ctx* ctx, const pk_tree* t, const uint64_t* indices, size_t 
     return PK_OK;
 }
 
+// The leaf half of an opening on its own: gather k rows of a codeword matrix the caller holds (e.g. one rank's shard of
+// a multi-GPU commit, SURVEY 8e "Openings": leaf i is served by GPU i mod G) to leaf-major host memory.
+int pk_gather_leaves(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, const uint64_t* indices, size_t k,
+                     int canonical_leaves, uint64_t* leaves_out) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, k == 0 || (d_leaves && indices && leaves_out), "null pointer");
+    PK_REQUIRE(ctx, layout == PK_COL_MAJOR || layout == PK_LEAF_MAJOR, "unknown layout");
+    if (!k || !width) return PK_OK;
+    for (size_t q = 0; q < k; q++) PK_REQUIRE(ctx, indices[q] < n_leaves, "leaf index out of range");
+    const size_t idx_bytes = ((k * 8 + 63) / 64) * 64, n1 = k * width;
+    char* mail = nullptr;
+    int rc = mail_alloc(ctx, idx_bytes + 32 * n1, (void**)&mail);
+    if (rc) return rc;
+    unsigned long long* m_idx = (unsigned long long*)mail;
+    fe* m_leaves = (fe*)(mail + idx_bytes);
+    memcpy(m_idx, indices, k * 8);
+    gather_opening_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, ctx->stream>>>((const fe*)d_leaves, nullptr, n_leaves, (unsigned)width, layout, 0, m_idx, k,
+                                                                                canonical_leaves, m_leaves, nullptr, nullptr);
+    PK_LAUNCH_CHECK(ctx);
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(leaves_out, m_leaves, 32 * n1);
+    ctx->mail_off = 0;
+    return PK_OK;
+}
+
 // ark MultiPath, uncompressed ark-serialize: Vec<T> = u64 length + items; digests = 32 B canonical LE.
 // Fields in order: leaf_siblings_hashes, auth_paths_prefix_lenghts, auth_paths_suffixes, leaf_indexes.
 // `indices` must be sorted ascending and unique (whir sorts+dedups STIR queries); paths are root->leaf.

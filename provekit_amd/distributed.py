@@ -61,6 +61,16 @@ class HipShardBackend:
         ctx._check(lib.pk_leaf_hash(ctx.handle, leaves.ptr, local_rows, width, PK_COL_MAJOR, digests.data_ptr()))
         return leaves, digests  # the caller owns the shard of the codeword matrix (resident for openings)
 
+    def gather_local_leaves(self, leaves, local_rows_total, width, local_rows):
+        """rows `local_rows` of this rank's shard (column-major on the device) -> (len, width, 4) int64 tensor on the device"""
+        idx = np.ascontiguousarray(local_rows, dtype=np.uint64)
+        out = np.zeros((len(idx), width, 4), dtype=np.uint64)
+        if len(idx):
+            self.ctx._check(lib.pk_gather_leaves(self.ctx.handle, leaves.ptr, local_rows_total, width, PK_COL_MAJOR, idx.ctypes.data, len(idx), 0,
+                                                 out.ctypes.data))
+        with torch.cuda.stream(self.stream):
+            return torch.from_numpy(out.view(np.int64)).to(self.device)
+
     def new_nodes(self, rows):
         with torch.cuda.stream(self.stream):
             return torch.zeros((2 * rows, 4), dtype=torch.int64, device=self.device)
@@ -103,3 +113,30 @@ class ShardedCommitter:
     def owner_of_leaf(self, i: int) -> tuple[int, int]:
         """(rank, local row) that holds leaf i"""
         return i % self.world, i // self.world
+
+    def open(self, indices, leaves_local, nodes, width: int):
+        """STIR openings of a sharded commitment (SURVEY 8e "Openings"): leaf i is served by rank i mod G -- every rank
+        gathers the rows it owns and ONE all-reduce (each row is non-zero on exactly one rank; k*width*32 bytes, ~100 KiB)
+        gives everybody the opened leaves; sibling digests and auth paths come from the replicated inner tree.
+        -> (leaves (k, width, 4) uint64 Montgomery, sibling digests (k, 4), auth paths root->leaf (k, log2(rows)-1, 4)),
+        the same triple Commitment.open(canonical_leaves=False) returns for an unsharded tree."""
+        import contextlib
+
+        idx = [int(i) for i in indices]
+        rows = nodes.shape[0] // 2
+        logn = rows.bit_length() - 1
+        mine = [(q, i // self.world) for q, i in enumerate(idx) if i % self.world == self.rank]
+        got = self.backend.gather_local_leaves(leaves_local, rows // self.world, width, [r for _, r in mine])
+        scope = self.backend.stream_ctx() if hasattr(self.backend, "stream_ctx") else contextlib.nullcontext()
+        with scope:
+            full = torch.zeros((len(idx), width, 4), dtype=torch.int64, device=nodes.device)
+            if mine:
+                full[torch.tensor([q for q, _ in mine], device=nodes.device)] = got.to(nodes.device)
+            if self.world > 1:
+                dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+            pos = torch.tensor(idx, dtype=torch.int64, device=nodes.device) + rows
+            sib = nodes[pos ^ 1]
+            paths = torch.stack([nodes[(pos >> (logn - d)) ^ 1] for d in range(1, logn)], dim=1) if logn > 1 else torch.zeros(
+                (len(idx), 0, 4), dtype=torch.int64, device=nodes.device)
+            to_np = lambda t: t.cpu().numpy().view(np.uint64)
+            return to_np(full), to_np(sib), to_np(paths)

@@ -26,6 +26,10 @@ class OracleShardBackend:
         dig = self.o.leaf_hash(local)
         return local, torch.from_numpy(dig.view(np.int64).copy())
 
+    def gather_local_leaves(self, leaves, local_rows_total, width, local_rows):
+        assert leaves.shape[:2] == (local_rows_total, width)
+        return torch.from_numpy(np.ascontiguousarray(leaves[list(local_rows)]).view(np.int64).reshape(len(local_rows), width, 4))
+
     def new_nodes(self, rows):
         return torch.zeros((2 * rows, 4), dtype=torch.int64)
 
@@ -48,9 +52,13 @@ def _worker(rank, world, port, n_vars, q):
     polys = [random_field(1 << n_vars, 70 + b) for b in range(2)]  # every rank holds the full coefficient vectors
     sc = ShardedCommitter(OracleShardBackend(o))
     root, nodes, local = sc.commit(polys, n_vars)
-    q.put((rank, root.tolist(), nodes[1:5].numpy().view(np.uint64).tolist(), local.shape[0], sc.owner_of_leaf(5)))
+    opened = sc.open(OPEN_IDX, local, nodes, 32)
+    q.put((rank, root.tolist(), nodes[1:5].numpy().view(np.uint64).tolist(), local.shape[0], sc.owner_of_leaf(5), [a.tolist() for a in opened]))
     dist.barrier()
     dist.destroy_process_group()
+
+
+OPEN_IDX = [0, 1, 2, 7, 20, 33, 62, 63]  # owners alternate between the two ranks
 
 
 def _free_port():
@@ -79,8 +87,16 @@ def test_sharded_commit_gloo(oracle, world):
     polys = [random_field(1 << n_vars, 70 + b) for b in range(2)]
     leaves = oracle.rs_encode(np.concatenate(polys), 2, n_vars, 1, 4)
     exp = oracle.merkle_commit(leaves)
-    for rank, root, top, n_local, owner in res:
+    n = leaves.shape[0]
+    logn = n.bit_length() - 1
+    for rank, root, top, n_local, owner, opened in res:
         assert root == exp[1].tolist(), f"rank {rank} root mismatch"
         assert top == exp[1:5].tolist()
-        assert n_local == leaves.shape[0] // world
+        assert n_local == n // world
         assert owner == (5 % world, 5 // world)
+        lv, sib, paths = (np.array(a, dtype=np.uint64) for a in opened)
+        assert np.array_equal(lv, leaves[OPEN_IDX]), f"rank {rank}: opened leaves"
+        for q, i in enumerate(OPEN_IDX):
+            assert np.array_equal(sib[q], exp[(n + i) ^ 1])
+            for d in range(1, logn):
+                assert np.array_equal(paths[q, d - 1], exp[((n + i) >> (logn - d)) ^ 1])

@@ -61,3 +61,39 @@ def test_sharded_committer_simulated_ranks(ctx, oracle):
             assert nodes[1].cpu().numpy().view(np.uint64).tobytes() == expect
     finally:
         ctx.set_stream(None)
+
+
+def test_sharded_open_matches_unsharded(ctx, oracle):
+    """ShardedCommitter.open (world 1 on this box): the same triple Commitment.open returns; and pk_gather_leaves on a
+    real shard (rank g of 4) returns rows g, g+4, ... of the unsharded codeword."""
+    from provekit_amd._lib import PK_COL_MAJOR, lib
+    from provekit_amd.distributed import HipShardBackend, ShardedCommitter
+    from provekit_amd.field import random_field
+    from provekit_amd.whir import commit_batch
+
+    n_vars, G = 11, 4
+    polys = [ctx.upload(random_field(1 << n_vars, 190 + b)) for b in range(2)]
+    ref = commit_batch(ctx, polys, n_vars)
+    rows = ref.n_leaves
+    idx = np.array([0, 3, 4, 77, rows // 2 + 1, rows - 1], dtype=np.uint64)
+    lv_ref, sib_ref, paths_ref = ref.open(idx, canonical_leaves=False)
+    be = HipShardBackend(ctx)
+    try:
+        sc = ShardedCommitter(be, rank=0, world=1)
+        root, nodes, local = sc.commit(polys, n_vars)
+        assert root.tobytes() == ref.root
+        lv, sib, paths = sc.open(idx, local, nodes, 32)
+        assert np.array_equal(lv, lv_ref) and np.array_equal(sib, sib_ref) and np.array_equal(paths, paths_ref)
+        all_rows = np.arange(rows, dtype=np.uint64)
+        full, _, _ = ref.open(all_rows, canonical_leaves=False)
+        for g in range(G):
+            shard, _ = be.encode_and_hash_shard(polys, n_vars, 1, 4, g, G)
+            want = np.arange(g, rows, G)
+            local_rows = np.array([1, 0, rows // G - 1, 5], dtype=np.uint64)
+            out = np.zeros((len(local_rows), 32, 4), dtype=np.uint64)
+            ctx._check(lib.pk_gather_leaves(ctx.handle, shard.ptr, rows // G, 32, PK_COL_MAJOR, local_rows.ctypes.data, len(local_rows), 0, out.ctypes.data))
+            assert np.array_equal(out, full[want[local_rows.astype(np.int64)]])
+            be.release(shard)
+    finally:
+        ctx.set_stream(None)
+    ref.close()
