@@ -153,3 +153,54 @@ def test_witness_satisfaction(ctx, oracle):
     with pytest.raises(ProveKitHipError, match="Witness size does not match"):
         r1cs.test_witness_satisfaction(up(z), n_witness=nw - 1)
     r1cs.close()
+
+
+def test_prove_verify_midsize(ctx, oracle):
+    """m = 17, m_0 = 16: three WHIR rounds on trees of 2^14..2^12 leaves -- the register-NTT, fused-Merkle-level and
+    pinned-mailbox paths of the bench-size prover, under the independent verifier (incl. the R1CS matrix check)."""
+    run_case(ctx, oracle, m=17, m_0=16, nc=60000, n_in=5000, seed=17, pow_bits=10.0)
+
+
+def test_prove_verify_bench_size(ctx, oracle):
+    """The bench's own statement size and WHIR schedule (m = 21, m_0 = 20, queries 109/28/16/11, final 9) on a SATISFIABLE
+    instance: the proof must pass every check of the independent verifier (transcript, 2^18-leaf Merkle openings, both
+    sumchecks, folds, PoW); the O(nnz) matrix evaluation of the deferred weights is left to the smaller cases above."""
+    import verifier as V
+    from provekit_amd.field import random_field
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS, SparseMatrix
+
+    m, m_0 = 21, 20
+    nc, n_in = 1 << 19, (1 << 19) - 8
+    nw = 1 + n_in + nc
+    rng = np.random.default_rng(21)
+    coeffs = [1, 2, 3, 5, oracle.P - 1, 7, oracle.P - 2, 11]
+    interner = oracle.to_mont(oracle.ints_to_limbs(coeffs))
+    one = oracle.to_mont(oracle.ints_to_limbs([1]))
+    z = np.concatenate([one, random_field(n_in, 5), np.zeros((nc, 4), dtype=np.uint64)])
+    mats = []
+    for _ in range(2):  # A, B read only the inputs, so the outputs c_i = (A z)_i (B z)_i come from two products
+        cols = np.sort(rng.integers(0, 1 + n_in - 2, size=(nc, 3), dtype=np.int64), axis=1) + np.arange(3)
+        mats.append((np.arange(nc, dtype=np.uint32) * 3, cols.reshape(-1).astype(np.uint32), rng.integers(0, len(coeffs), size=3 * nc).astype(np.uint32)))
+    az, bz = (oracle.spmv(nc, nw, nri, ci, v, interner, z) for nri, ci, v in mats)
+    z[1 + n_in :] = oracle.hadamard(az, bz)
+    mats.append((np.arange(nc, dtype=np.uint32), (1 + n_in + np.arange(nc)).astype(np.uint32), np.zeros(nc, dtype=np.uint32)))
+    r1cs = R1CS(ctx, *(SparseMatrix(nc, nw, *t) for t in mats), interner)
+    d_z = ctx.upload(z)
+    r1cs.test_witness_satisfaction(d_z)
+    cfg_w, cfg_b = WhirConfig.poseidon_witness(), blinding_config_for(m_0)
+    scheme = WhirR1CSScheme(ctx, r1cs, m, m_0, cfg_w, cfg_b)
+    proof = scheme.prove(d_z, seed=1)
+
+    def vcfg(c):
+        return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples)
+
+    args = (scheme.domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
+    assert V.verify(proof, *args)
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 1
+    with pytest.raises((V.VerifyError, Exception)):
+        V.verify(bytes(bad), *args)
+    scheme.close()
+    r1cs.close()
