@@ -373,6 +373,14 @@ __global__ __launch_bounds__(256) void fold_coeffs_kernel(const fe* __restrict__
     }
 }
 
+// out = a + beta * b (out may alias neither): the batching combination of two committed polynomials in one pass
+__global__ __launch_bounds__(256) void lincomb_kernel(fe* __restrict__ out, const fe* __restrict__ a, const fe* __restrict__ b, size_t n,
+                                                      fe_arg beta_arg) {
+    const fe beta = from_arg(beta_arg);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        fe_store(out + i, fe_add(fe_load(a + i), fe_mulx(beta, fe_load(b + i))));
+}
 // y += beta * x ; y = a o b
 __global__ __launch_bounds__(256) void axpy_kernel(fe* __restrict__ y, const fe* __restrict__ x, size_t n, fe_arg beta_arg) {
     const fe beta = from_arg(beta_arg);
@@ -504,6 +512,13 @@ int pk_fold_pairs(pk_ctx* ctx, const uint64_t* d_v, size_t len, const uint64_t* 
 }
 }  // extern "C"
 namespace pk {
+int lincomb2(pk_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* beta, const uint64_t* d_b, size_t n) {
+    PK_REQUIRE(ctx, beta && (n == 0 || (d_out && d_a && d_b)), "null pointer");
+    if (!n) return PK_OK;
+    lincomb_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_out, (const fe*)d_a, (const fe*)d_b, n, to_arg(beta));
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
 // two arrays of the same length folded by the same challenge in one launch (the sumcheck's p and w)
 int fold_pairs2(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint64_t* d_v1, uint64_t* d_out1, size_t len, const uint64_t* r) {
     PK_REQUIRE(ctx, d_v0 && d_out0 && d_v1 && d_out1 && r, "null pointer");

@@ -26,6 +26,7 @@ int commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, un
                 uint64_t* d_leaves, uint64_t* d_nodes, uint64_t* d_scratch);
 int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, size_t n_leaves, size_t width, const uint64_t* indices,
              size_t k, int canonical_leaves, uint64_t* leaves_out, uint64_t* sibling_digests, uint64_t* auth_paths);
+int lincomb2(pk_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* beta, const uint64_t* d_b, size_t n);
 int fold_pairs2(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint64_t* d_v1, uint64_t* d_out1, size_t len, const uint64_t* r);
 }
 
@@ -204,6 +205,7 @@ int emit_opening_hints(pk_ctx* ctx, Transcript& T, const fe* d_leaves, const fe*
 struct Commitment {  // whir::committer::Witness
     unsigned n_vars = 0, batch = 0;
     fe* polys[4] = {};  // coefficient form
+    fe* evals[4] = {};  // the same polynomials as evaluation tables, when the committer still holds them (else null)
     fe* leaves = nullptr;
     fe* nodes = nullptr;
     size_t rows = 0, width = 0;
@@ -255,16 +257,21 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
     const size_t N = (size_t)1 << n;
     // working polynomial c = sum_b beta^b poly_b (mtUtilities.go:98-114)
     ALLOC(d_c, N);
-    CK(pk_memcpy_d2d(ctx, d_c, C.polys[0], 32 * N));
-    {
-        fe bp = C.beta;
-        for (unsigned b = 1; b < C.batch; b++) {
-            uint64_t s[4];
+    // sum_b beta^b x_b over coefficient tables or evaluation tables: the first two in one pass, the rest by axpy
+    auto batch_combine = [&](fe* dst, fe* const* x) -> int {
+        if (C.batch == 1) return pk_memcpy_d2d(ctx, dst, x[0], 32 * N);
+        uint64_t s[4];
+        h_store(s, C.beta);
+        int rc = lincomb2(ctx, U(dst), U(x[0]), s, U(x[1]), N);
+        fe bp = h_mul(C.beta, C.beta);
+        for (unsigned b = 2; b < C.batch && !rc; b++) {
             h_store(s, bp);
-            CK(pk_fe_axpy(ctx, U(d_c), s, U(C.polys[b]), N));
+            rc = pk_fe_axpy(ctx, U(dst), s, U(x[b]), N);
             bp = h_mul(bp, C.beta);
         }
-    }
+        return rc;
+    };
+    CK(batch_combine(d_c, C.polys));
     // sumcheck operands: p = evaluations of c over the hypercube, w = combined weights; ping-pong halves
     fe* bp_[2];
     fe* bw_[2];
@@ -273,7 +280,12 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
     ALLOC(w0, N);
     ALLOC(w1, N / 2 ? N / 2 : 1);
     bp_[0] = p0; bp_[1] = p1; bw_[0] = w0; bw_[1] = w1;
-    CK(pk_to_evals_into(ctx, U(d_c), U(p0), n));
+    bool have_evals = true;
+    for (unsigned b = 0; b < C.batch; b++) have_evals = have_evals && C.evals[b] != nullptr;
+    if (have_evals)
+        CK(batch_combine(p0, C.evals));  // to_evals is linear: combine the tables the committer kept instead of transforming d_c
+    else
+        CK(pk_to_evals_into(ctx, U(d_c), U(p0), n));
     // initial combination randomness; weights = sum gamma^i w_i over [OOD constraints..., statement weights...]
     fe gamma = T.challenge_scalar();
     fe g = fe_one();
@@ -470,7 +482,10 @@ int batch_commit(pk_ctx* ctx, Arena& A, unsigned m, const pk_whir_config& cfg, c
     out.f_evals = f;
     out.g_evals = g;
     fe* polys[2] = {fe_, ge_};
-    return whir_commit(ctx, A, cfg, polys, 2, T, out.com);
+    int rc = whir_commit(ctx, A, cfg, polys, 2, T, out.com);
+    out.com.evals[0] = f;
+    out.com.evals[1] = g;
+    return rc;
 }
 
 std::string domain_separator_for(const pk_scheme& s) {
