@@ -281,6 +281,113 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_kernel(const f
     }
     grid_finish_fe<3>(acc, smem, partials, ticket, result, seq);
 }
+// ---- small rounds: the work of ONE pair spread over several lanes ------------------------------------------------------
+// Late sumcheck rounds have a handful of pairs; with a lane per pair the round is a chain of 16 (cubic, folding) or 7
+// (quadratic, folding) dependent modular multiplications on one lane of one wavefront -- ~1 us each -- and the kernel holds a
+// hardware queue for that long.  Here the independent products of a pair go to neighbouring lanes (8 resp. 4 per pair),
+// the folded values are exchanged through LDS, and three lanes form the three evaluations: 3 resp. 2 multiplications deep.
+// Same arithmetic, same order of the (exact) field operations per value: results are bit-identical to the wide kernels.
+constexpr size_t SMALL_ROUND_PAIRS = 16384;
+
+__global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_small_kernel(fe* __restrict__ a, fe* __restrict__ b, fe* __restrict__ c,
+                                                                           fe* __restrict__ eq, size_t len, fe_arg fold_arg,
+                                                                           fe* __restrict__ partials, unsigned* __restrict__ ticket,
+                                                                           fe* __restrict__ result, unsigned seq) {
+    __shared__ uint4 smem[3 * 16];
+    __shared__ uint4 xs[2 * RED_THREADS];  // folded value of lane t at [t] (lo) and [RED_THREADS + t] (hi)
+    const fe alpha = from_arg(fold_arg);
+    const size_t npairs = len / 4, off = npairs, foff = len / 2;
+    const unsigned tid = threadIdx.x, g = tid >> 3, role = tid & 7, k = role >> 1, which = role & 1;
+    const size_t i = (size_t)blockIdx.x * (RED_THREADS / 8) + g;
+    fe* arr = k == 0 ? a : k == 1 ? b : k == 2 ? c : eq;
+    if (i < npairs) {  // sumcheck.rs:95-96: p0 += fold*(p2-p0); p1 += fold*(p3-p1)
+        fe* p = arr + i + (which ? off : 0);
+        fe x = fe_load(p), x2 = fe_load(p + foff);
+        x = fe_add(x, fe_mulx(alpha, fe_sub(x2, x)));
+        fe_store(p, x);
+        lds_put(xs, xs + RED_THREADS, tid, x);
+    }
+    __syncthreads();
+    fe acc[3] = {fe_zero(), fe_zero(), fe_zero()};
+    if (i < npairs && role < 3) {
+        const unsigned base = tid & ~7u;
+        auto v = [&](unsigned kk, unsigned w) { return lds_get(xs, xs + RED_THREADS, base + 2 * kk + w); };
+        const fe a0 = v(0, 0), a1 = v(0, 1), b0 = v(1, 0), b1 = v(1, 1), c0 = v(2, 0), c1 = v(2, 1), e0 = v(3, 0), e1 = v(3, 1);
+        // the three evaluations share one shape, X * (Y*Z - S), so the lanes of a pair run the same two multiplications on
+        // operands selected by role (no divergent branches):
+        //   role 0: f0    = eq0 * (a0*b0 - c0)
+        //   role 1: f(-1) = (2eq0-eq1) * ((2a0-a1)(2b0-b1) - (2c0-c1))
+        //   role 2: f_inf = (b1-b0) * ((eq1-eq0)(a1-a0) - 0)
+        auto pick = [&](const fe& x0, const fe& x1) {
+            fe m1 = fe_sub(fe_dbl(x0), x1), d = fe_sub(x1, x0), r;
+#pragma unroll
+            for (int w = 0; w < 8; w++) r.v[w] = role == 0 ? x0.v[w] : role == 1 ? m1.v[w] : d.v[w];
+            return r;
+        };
+        const fe pa = pick(a0, a1), pb = pick(b0, b1), pc = pick(c0, c1), pe = pick(e0, e1);
+        fe X, Y, S;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            X.v[w] = role == 2 ? pb.v[w] : pe.v[w];
+            Y.v[w] = role == 2 ? pe.v[w] : pb.v[w];
+            S.v[w] = role == 2 ? 0u : pc.v[w];
+        }
+        const fe t = fe_mulx(X, fe_sub(fe_mulx(Y, pa), S));
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int w = 0; w < 8; w++) acc[r].v[w] = role == (unsigned)r ? t.v[w] : 0u;
+    }
+    grid_finish_fe<3>(acc, smem, partials, ticket, result, seq);
+}
+
+template <bool FOLD>
+__global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_small_kernel(const fe* __restrict__ f, const fe* __restrict__ w, size_t out_len,
+                                                                               fe_arg fold_arg, fe* __restrict__ f_out, fe* __restrict__ w_out,
+                                                                               fe* __restrict__ partials, unsigned* __restrict__ ticket,
+                                                                               fe* __restrict__ result, unsigned seq) {
+    __shared__ uint4 smem[3 * 16];
+    __shared__ uint4 xs[2 * RED_THREADS];
+    const fe r = from_arg(fold_arg);
+    const size_t npairs = out_len / 2;
+    const unsigned tid = threadIdx.x, g = tid >> 2, role = tid & 3;  // role: 0 f0, 1 f1, 2 w0, 3 w1
+    const size_t i = (size_t)blockIdx.x * (RED_THREADS / 4) + g;
+    if (i < npairs) {
+        const fe* src = role < 2 ? f : w;
+        const unsigned j = role & 1;
+        fe x;
+        if (FOLD) {
+            fe x0 = fe_load(src + 4 * i + 2 * j), x1 = fe_load(src + 4 * i + 2 * j + 1);
+            x = fe_add(x0, fe_mulx(r, fe_sub(x1, x0)));
+            fe_store((role < 2 ? f_out : w_out) + 2 * i + j, x);
+        } else {
+            x = fe_load(src + 2 * i + j);
+        }
+        lds_put(xs, xs + RED_THREADS, tid, x);
+    }
+    __syncthreads();
+    fe acc[3] = {fe_zero(), fe_zero(), fe_zero()};
+    if (i < npairs && role < 3) {
+        const unsigned base = tid & ~3u;
+        const fe f0 = lds_get(xs, xs + RED_THREADS, base), f1 = lds_get(xs, xs + RED_THREADS, base + 1);
+        const fe w0 = lds_get(xs, xs + RED_THREADS, base + 2), w1 = lds_get(xs, xs + RED_THREADS, base + 3);
+        // one multiplication on operands selected by role: h(0) = f0 w0, h(1) = f1 w1, h(2) = (2f1-f0)(2w1-w0)
+        const fe tf = fe_sub(fe_dbl(f1), f0), tw = fe_sub(fe_dbl(w1), w0);
+        fe X, Y;
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            X.v[v] = role == 0 ? f0.v[v] : role == 1 ? f1.v[v] : tf.v[v];
+            Y.v[v] = role == 0 ? w0.v[v] : role == 1 ? w1.v[v] : tw.v[v];
+        }
+        const fe t = fe_mulx(X, Y);
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int v = 0; v < 8; v++) acc[q].v[v] = role == (unsigned)q ? t.v[v] : 0u;
+    }
+    grid_finish_fe<3>(acc, smem, partials, ticket, result, seq);
+}
+
 // the single-element tail of the fold (out_len == 1): v'[0] = v[0] + r (v[1]-v[0]); no pair to sum.  blockIdx.y selects
 // one of up to two arrays folded by the same challenge (the sumcheck's polynomial and its weights) in one launch.
 __global__ void fold_pairs_kernel(const fe* __restrict__ v0, fe* __restrict__ out0, const fe* __restrict__ v1, fe* __restrict__ out1,
@@ -466,7 +573,10 @@ int pk_sumcheck_cubic_round(pk_ctx* ctx, uint64_t* d_a, uint64_t* d_b, uint64_t*
     unsigned blocks = reduction_blocks(ctx, npairs);
     {
         ProfScope prof(ctx, "sumcheck_cubic");
-        if (fold_or_null)
+        if (fold_or_null && npairs <= SMALL_ROUND_PAIRS)
+            sumcheck_cubic_small_kernel<<<(unsigned)((npairs + RED_THREADS / 8 - 1) / (RED_THREADS / 8)), RED_THREADS, 0, ctx->stream>>>(
+                (fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, to_arg(fold_or_null), red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
+        else if (fold_or_null)
             sumcheck_cubic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, to_arg(fold_or_null),
                                                                                   red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
         else
@@ -490,7 +600,17 @@ int pk_sumcheck_quadratic_round(pk_ctx* ctx, const uint64_t* d_f, const uint64_t
     unsigned blocks = reduction_blocks(ctx, out_len / 2);
     {
         ProfScope prof(ctx, "sumcheck_quadratic");
-        if (fold_or_null)
+        const size_t npairs = out_len / 2;
+        const unsigned sblocks = (unsigned)((npairs + RED_THREADS / 4 - 1) / (RED_THREADS / 4));
+        if (npairs <= SMALL_ROUND_PAIRS && fold_or_null)
+            sumcheck_quadratic_small_kernel<true><<<sblocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, to_arg(fold_or_null),
+                                                                                            (fe*)d_f_out, (fe*)d_w_out, red_partials(ctx),
+                                                                                            red_ticket(ctx), red_result(ctx), next_seq(ctx));
+        else if (npairs <= SMALL_ROUND_PAIRS)
+            sumcheck_quadratic_small_kernel<false><<<sblocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, fe_arg{}, nullptr,
+                                                                                             nullptr, red_partials(ctx), red_ticket(ctx),
+                                                                                             red_result(ctx), next_seq(ctx));
+        else if (fold_or_null)
             sumcheck_quadratic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, to_arg(fold_or_null),
                                                                                       (fe*)d_f_out, (fe*)d_w_out, red_partials(ctx), red_ticket(ctx),
                                                                                       red_result(ctx), next_seq(ctx));

@@ -136,6 +136,18 @@ __device__ __forceinline__ void grid_finish_fe(fe (&acc)[K], uint4* smem, fe* __
     }
     fe mine = block_reduce_wide<K>(w, smem);  // thread k holds sum k
     const unsigned tid = threadIdx.x;
+    if (gridDim.x == 1) {  // a single workgroup (the late, tiny rounds): its sums are the results -- no ticket, no second pass
+        if (tid < 64) {
+            unsigned* out = reinterpret_cast<unsigned*>(result);
+            if (tid < K) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) __hip_atomic_store(out + 8 * tid + i, mine.v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (tid == 0) __hip_atomic_store(out + PK_FLAG_WORD, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     if (tid < 64) {                           // the first wavefront: lanes < K store, then lane 0 draws the ticket
         if (tid < K) fe_store_sc1(partials + (size_t)blockIdx.x * K + tid, mine);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wavefront's partials are out before the ticket is drawn

@@ -103,7 +103,7 @@ def test_eq_accumulate_many_points(ctx, oracle):
     assert np.array_equal(ctx.download_fe(d4, 16), M(oracle, g["table"]))
 
 
-@pytest.mark.parametrize("log_len", [1, 2, 3, 8, 13, 16])
+@pytest.mark.parametrize("log_len", [1, 2, 3, 8, 13, 16, 18])
 def test_sumcheck_cubic_rounds_vs_oracle(ctx, oracle, log_len):
     """run the whole m_0-round loop of run_zk_sumcheck_prover's hot part (whir_r1cs.rs:280-345)"""
     from provekit_amd import sumcheck as sc
