@@ -480,6 +480,38 @@ __global__ __launch_bounds__(256) void fold_coeffs_kernel(const fe* __restrict__
     }
 }
 
+// the WHIR fold (k = 4) with the 16 weights formed on the host (11 products) and passed by value: no per-workgroup weight
+// phase.  LANES = 1: one output per lane.  LANES = 16: late rounds with few outputs -- the 16 products of an output go to
+// 16 neighbouring lanes and are summed as limb sums (reduce.hpp), one multiplication deep instead of fifteen.
+struct fold16_args {
+    fe_arg w[16];
+};
+template <int LANES>
+__global__ __launch_bounds__(256) void fold16_kernel(const fe* __restrict__ c, size_t n_out, fold16_args wa, fe* __restrict__ out) {
+    __shared__ uint4 wts[16 * 2];
+    if (threadIdx.x < 16) lds_put(wts, wts + 16, threadIdx.x, from_arg(wa.w[threadIdx.x]));
+    __syncthreads();
+    if (LANES == 1) {
+        const size_t stride = (size_t)gridDim.x * blockDim.x;
+        for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_out; t += stride) {
+            fe acc = fe_load(c + t * 16);
+#pragma unroll 1
+            for (int j = 1; j < 16; j++) acc = fe_add(acc, fe_mulx(fe_load(c + t * 16 + j), lds_get(wts, wts + 16, j)));
+            fe_store(out + t, acc);
+        }
+    } else {
+        const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x, t = g >> 4;
+        const unsigned j = threadIdx.x & 15;
+        wide w = wide_zero();
+        if (t < n_out) wide_add_fe(w, fe_mulx(fe_load(c + g), lds_get(wts, wts + 16, j)));  // c[16 t + j] * w_j (w_0 = 1)
+#pragma unroll
+        for (unsigned off = 8; off >= 1; off >>= 1)
+#pragma unroll
+            for (int i = 0; i < 8; i++) w.l[i] += shfl_down_u64(w.l[i], off);
+        if (j == 0 && t < n_out) fe_store(out + t, wide_reduce(w));
+    }
+}
+
 // out = a + beta * b (out may alias neither): the batching combination of two committed polynomials in one pass
 __global__ __launch_bounds__(256) void lincomb_kernel(fe* __restrict__ out, const fe* __restrict__ a, const fe* __restrict__ b, size_t n,
                                                       fe_arg beta_arg) {
@@ -736,6 +768,23 @@ int pk_fold_coeffs(pk_ctx* ctx, const uint64_t* d_coeffs, unsigned n_vars, const
     for (unsigned b = 0; b < k; b++) ra.r[b] = to_arg(r + 4 * b);
     size_t n_out = (size_t)1 << (n_vars - k);
     ProfScope prof(ctx, "fold_coeffs");
+    if (k == 4) {  // weight j = prod_b r_b^{bit_b(j)} by doubling, on the host
+        fe wt[16];
+        wt[0] = fe_one();
+        for (unsigned b = 0; b < 4; b++) {
+            fe rb;
+            memcpy(rb.v, r + 4 * b, 32);
+            for (unsigned j = 0; j < (1u << b); j++) wt[(1u << b) + j] = fe_mulx(wt[j], rb);
+        }
+        fold16_args wa;
+        for (int j = 0; j < 16; j++) memcpy(wa.w[j].v, wt[j].v, 32);
+        if (n_out <= 8192)
+            fold16_kernel<16><<<(unsigned)((n_out * 16 + 255) / 256), 256, 0, ctx->stream>>>((const fe*)d_coeffs, n_out, wa, (fe*)d_out);
+        else
+            fold16_kernel<1><<<grid_for(ctx, n_out, 256), 256, 0, ctx->stream>>>((const fe*)d_coeffs, n_out, wa, (fe*)d_out);
+        PK_LAUNCH_CHECK(ctx);
+        return PK_OK;
+    }
     fold_coeffs_kernel<<<grid_for(ctx, n_out, 256), 256, 0, ctx->stream>>>((const fe*)d_coeffs, n_out, k, ra, (fe*)d_out);
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;

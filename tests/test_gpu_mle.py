@@ -209,7 +209,7 @@ def test_fold_and_univariate_golden(ctx, oracle):
     assert np.array_equal(sc.eval_univariate(ctx, d, 64, M(oracle, [e["z"]])[0]), M(oracle, [e["out"]])[0])
 
 
-@pytest.mark.parametrize("n_vars,k", [(4, 4), (10, 4), (17, 4), (9, 1), (6, 0), (8, 8)])
+@pytest.mark.parametrize("n_vars,k", [(4, 4), (5, 4), (10, 4), (17, 4), (19, 4), (9, 1), (6, 0), (8, 8)])
 def test_fold_coeffs_vs_oracle(ctx, oracle, n_vars, k):
     from provekit_amd import sumcheck as sc
     from provekit_amd.field import random_field
