@@ -248,6 +248,9 @@ def main():
     ap.add_argument("--concurrency", type=int, default=6,
                     help="provers per GPU, each with its own context/stream/arena (host transcript work of one proof overlaps "
                          "the kernels of another); 1 = strictly one proof at a time")
+    ap.add_argument("--h2d", action="store_true",
+                    help="upload the witness from (pageable) host memory before every proof: the PCIe-inclusive rate DESIGN.md quotes; "
+                         "never the judged line (inputs are resident when the clock starts)")
     args = ap.parse_args()
 
     # stdout carries exactly one JSON line: libraries that print banners there (RCCL's version block at communicator
@@ -290,14 +293,17 @@ def main():
     for w in range(conc):
         c = provekit_amd.Context(local_rank)
         r1cs_w, mats, interner, nc = synth_r1cs(c, m_0, n_wit, seed=1234 + rank)
-        workers.append((c, WhirR1CSScheme(c, r1cs_w, m, m_0, cfg_w, cfg_b), c.upload(random_field(n_wit, 99 + rank + 1000 * w)), r1cs_w))
+        z_host = random_field(n_wit, 99 + rank + 1000 * w)
+        workers.append((c, WhirR1CSScheme(c, r1cs_w, m, m_0, cfg_w, cfg_b), c.upload(z_host), r1cs_w, z_host))
     ctx = workers[0][0]
 
     def run_steps(first_seed, count):
         """`count` proofs spread over the workers (ctypes releases the GIL inside pk_prove)"""
         def work(w, seeds):
-            _, prover, d_z, _ = workers[w]
+            c, prover, d_z, _, z_host = workers[w]
             for s in seeds:
+                if args.h2d:
+                    c.upload_into(d_z.ptr, z_host)
                 prover.prove_nocopy(d_z, seed=s)
         seeds = [first_seed + i for i in range(count)]
         ths = [threading.Thread(target=work, args=(w, seeds[w::conc])) for w in range(conc)]
@@ -381,7 +387,8 @@ def main():
             "config": {
                 "workload": f"poseidon-rounds size class: m={m}, m_0={m_0}, batch-2 WHIR commit + zk-sumcheck + {cfg_w.n_rounds}-round WHIR opening, "
                             f"queries {cfg_w.num_queries}/{cfg_w.final_queries}, pow_bits {cfg_w.pow_bits[0] if cfg_w.pow_bits else 0} (assumed), Skyscraper-sponge transcript",
-                "parallelism": f"{world} GPU(s) x {conc} concurrent provers per GPU (independent proofs, no collective)",
+                "parallelism": f"{world} GPU(s) x {conc} concurrent provers per GPU (independent proofs, no collective)"
+                               + (", witness uploaded over PCIe before every proof (--h2d)" if args.h2d else ""),
             },
             "roofline": {
                 "kernel": "leaf_hash_kernel (Skyscraper leaf digests)",
