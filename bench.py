@@ -370,6 +370,14 @@ def main():
         except Exception:
             pass
         iso_leaf_ms = prof_iso.get("leaf_hash", (1, 0.0))[1] / max(prof_iso.get("leaf_hash", (1, 0.0))[0], 1)
+        # hardware view of the same question (rocprofv3 --pmc VALUBusy, tools/pmc_valu.sh; committed summary of the same workload)
+        valu_busy = None
+        try:
+            pv = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_valu.json")))
+            if m == 21:
+                valu_busy = pv["kernels"]["leaf_hash_kernel<2, 1>"][str(1 << 18)]["VALUBusy"]
+        except Exception:
+            pass
         stage_ms = {k: round(v[1] / steps_w0, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
         line = {
             "metric": "proofs/sec (noir-r1cs prove hot path, WHIR commit + sumcheck + folding rounds)",
@@ -408,6 +416,7 @@ def main():
                     "peak": peak_modmul / 1e12,
                     "unit": "T modmul/s",
                     "frac": 14.0 * (compresses_step / launches_step) / max(iso_leaf_ms * 1e-3, 1e-12) / max(peak_modmul, 1.0),
+                    "valu_busy_pct_largest_launch": valu_busy,
                     "note": "isolated launches; achieved counts only the 14 Montgomery squarings of each compression (the 4 bars, "
                             "18 round-constant additions/reductions and the layout conversion are extra work on the same VALUs); peak = "
                             "pk_selftest_modmul_rate, register-resident squaring chains, best of 2/4/8 waves per SIMD x ILP 1/2",
