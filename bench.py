@@ -238,8 +238,8 @@ def emit(line):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=96)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--m", type=int, default=21, help="log2 of the committed polynomial size (poseidon-rounds: 21)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["prove", "commit"], default="prove",
@@ -364,7 +364,7 @@ def main():
         # command is used; null when it is missing or was taken on another workload size.
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01d_pmc_leaf_hash.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_leaf_hash.json")))
             if m == 21:
                 traffic = pmc["traffic_bytes_per_launch"]
         except Exception:
