@@ -240,7 +240,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=96)
     ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--m", type=int, default=21, help="log2 of the committed polynomial size (poseidon-rounds: 21)")
+    ap.add_argument("--m", "--log2-size", dest="m", type=int, default=21,
+                    help="log2 of the committed polynomial size (poseidon-rounds: 21).  Under torch.distributed.run spell it "
+                         "--log2-size: the launcher's own parser rejects --m as an ambiguous abbreviation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["prove", "commit"], default="prove",
                     help="prove = BASELINE configs[1] (default, the judged line); commit = one batch-2 WHIR commit of 2^m coefficients "
@@ -262,6 +264,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # development aid: PK_BENCH_ONE_GPU=1 runs a multi-rank launch with every rank on GPU 0 over gloo, to exercise the
+    # N>1 control flow (barriers, max-over-ranks, the sharded commit's collectives) on a single-GPU box; never a measurement
+    one_gpu = os.environ.get("PK_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
 
@@ -271,7 +278,10 @@ def main():
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
 

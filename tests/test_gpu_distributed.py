@@ -97,3 +97,45 @@ def test_sharded_open_matches_unsharded(ctx, oracle):
     finally:
         ctx.set_stream(None)
     ref.close()
+
+
+def test_bench_multirank_control_flow_on_one_gpu(ctx, oracle):
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), with
+    PK_BENCH_ONE_GPU=1 putting both ranks on GPU 0 over gloo: the sharded commit's root must be the unsharded root, and the
+    prove workload must aggregate over the ranks and print exactly one JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    from provekit_amd.whir import commit_batch
+
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PK_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+
+    def launch(extra, port):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+               str(port), os.path.join(root_dir, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, lines  # one JSON line on stdout, whatever the libraries print
+        return json.loads(lines[0])
+
+    m = 15
+    d = launch(["--workload", "commit", "--log2-size", str(m)], 29541)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
+    polys = []
+    for b in range(2):  # the seeded coefficients bench.py's commit workload generates
+        t = torch.randint(0, 2**62, (1 << m, 4), dtype=torch.int64, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(17 + b))
+        t[:, 3] &= (1 << 60) - 1
+        polys.append(t)
+    torch.cuda.synchronize()
+    ref = commit_batch(ctx, [int(t.data_ptr()) for t in polys], m)
+    assert d["config"]["root"] == ref.root.hex()
+    ref.close()
+    p = launch(["--workload", "prove", "--log2-size", "13", "--concurrency", "2", "--no-cpu-baseline"], 29542)
+    assert p["n_gpus"] == 2 and p["steps"] == 2 and p["scaling"] == "weak" and p["value"] > 0
+    assert abs(p["value"] - 2 * 2 / (p["ms_per_step"] * 2 * 1e-3)) / p["value"] < 1e-6  # whole-job aggregate: ranks x steps / time
