@@ -1,0 +1,264 @@
+// provekit_hip.hpp -- C++17 host side ABOVE the C ABI (provekit_hip.h), header only.
+//
+// The reference's prover is compiled code (Rust); its toolchain is absent here, so this is the host mirror a C++ caller
+// links instead of the Rust shim of INTEGRATION.md: the same type names, argument meaning and error behaviour as the
+// reference interfaces for this path, each member citing the one it mirrors.  Everything here is plumbing over pk_* calls;
+// no arithmetic lives in this file.
+//
+//   provekit::FieldElement        ark-ff Fp256<MontBackend> in memory: 4 x u64 little-endian, Montgomery (common/src/lib.rs:19)
+//   provekit::Error               anyhow::Error at the crate boundary: what() carries pk_last_error()
+//   provekit::SparseMatrix, R1CS  provekit_common::{SparseMatrix, R1CS} (common/src/sparse_matrix.rs:12-27, r1cs.rs)
+//   provekit::WhirConfig          the WhirConfig fields the prover consumes (tooling/provekit-gnark/src/gnark_config.rs:32-57)
+//   provekit::WhirR1CSScheme      {m, m_0, whir_witness, whir_for_hiding_spartan} + WhirR1CSProver::prove
+//                                 (common/src/whir_r1cs.rs:17-39, prover/src/whir_r1cs.rs:36-100)
+//   provekit::WhirR1CSProof       {transcript} (common/src/whir_r1cs.rs:43-46)
+//   provekit::SkyscraperPoW       spongefish_pow::PowStrategy {new, check, solve} (common/src/skyscraper/pow.rs:14-30)
+//   provekit::compress_many       skyscraper::CompressManyFn (skyscraper/core/src/lib.rs:26)
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "provekit_hip.h"
+
+namespace provekit {
+
+using FieldElement = std::array<uint64_t, 4>;
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+
+// one device, one stream; not thread-safe, one per prover thread (SURVEY 8b "Threading")
+class Context {
+   public:
+    explicit Context(int device = 0) {
+        int rc = pk_ctx_create(device, &ctx_);
+        if (rc) throw Error(rc, "pk_ctx_create failed: no HIP device / bad ordinal (libprovekit_hip has no CPU fallback)");
+    }
+    ~Context() {
+        if (ctx_) pk_ctx_destroy(ctx_);
+    }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    pk_ctx* get() const { return ctx_; }
+    void check(int rc) const {
+        if (rc) throw Error(rc, pk_last_error(ctx_));
+    }
+    void sync() const { check(pk_ctx_sync(ctx_)); }
+    void set_hash_version(int v) const { check(pk_ctx_set_hash_version(ctx_, v)); }
+
+   private:
+    pk_ctx* ctx_ = nullptr;
+};
+
+// Vec<FieldElement> resident in HBM
+class DeviceVec {
+   public:
+    DeviceVec(const Context& c, size_t n) : c_(&c), n_(n) { c.check(pk_malloc(c.get(), 32 * (n ? n : 1), &p_)); }
+    DeviceVec(const Context& c, const std::vector<FieldElement>& v) : DeviceVec(c, v.size()) {
+        if (!v.empty()) c.check(pk_memcpy_h2d(c.get(), p_, v.data(), 32 * v.size()));
+    }
+    ~DeviceVec() {
+        if (p_) pk_free(c_->get(), p_);
+    }
+    DeviceVec(DeviceVec&& o) noexcept : c_(o.c_), p_(o.p_), n_(o.n_) { o.p_ = nullptr; }
+    DeviceVec(const DeviceVec&) = delete;
+    DeviceVec& operator=(const DeviceVec&) = delete;
+    uint64_t* data() const { return static_cast<uint64_t*>(p_); }
+    size_t size() const { return n_; }
+    std::vector<FieldElement> to_host() const {
+        std::vector<FieldElement> v(n_);
+        if (n_) c_->check(pk_memcpy_d2h(c_->get(), v.data(), p_, 32 * n_));
+        return v;
+    }
+
+   private:
+    const Context* c_;
+    void* p_ = nullptr;
+    size_t n_;
+};
+
+// same fields as the reference struct; `values` index the interner (sparse_matrix.rs:12-27)
+struct SparseMatrix {
+    size_t num_rows = 0, num_cols = 0;
+    std::vector<uint32_t> new_row_indices, col_indices, values;
+};
+
+class R1CS {
+   public:
+    R1CS(const Context& c, const SparseMatrix& a, const SparseMatrix& b, const SparseMatrix& cc, const std::vector<FieldElement>& interner)
+        : c_(&c), num_constraints_(a.num_rows), num_witnesses_(a.num_cols) {
+        const SparseMatrix* ms[3] = {&a, &b, &cc};
+        pk_sparse_matrix mats[3];
+        for (int k = 0; k < 3; k++) {
+            if (ms[k]->num_rows != num_constraints_ || ms[k]->num_cols != num_witnesses_) throw Error(PK_ERR_BAD_ARG, "matrix shape mismatch");
+            mats[k] = {ms[k]->new_row_indices.data(), ms[k]->col_indices.data(), ms[k]->values.data(), ms[k]->col_indices.size()};
+        }
+        c.check(pk_r1cs_create(c.get(), num_constraints_, num_witnesses_, mats, interner.empty() ? nullptr : interner[0].data(), interner.size(), &h_));
+    }
+    ~R1CS() {
+        if (h_) pk_r1cs_destroy(c_->get(), h_);
+    }
+    R1CS(const R1CS&) = delete;
+    R1CS& operator=(const R1CS&) = delete;
+    size_t num_constraints() const { return num_constraints_; }
+    size_t num_witnesses() const { return num_witnesses_; }
+    pk_r1cs* get() const { return h_; }
+    // R1CSSolver::test_witness_satisfaction (prover/src/r1cs.rs:41-60): throws "Constraint {row} failed" / "Witness size does not match"
+    void test_witness_satisfaction(const DeviceVec& witness) const {
+        int64_t row = -1;
+        c_->check(pk_r1cs_test_witness_satisfaction(c_->get(), h_, witness.data(), witness.size(), &row));
+    }
+
+   private:
+    const Context* c_;
+    pk_r1cs* h_ = nullptr;
+    size_t num_constraints_, num_witnesses_;
+};
+
+struct WhirConfig {
+    unsigned n_vars = 0, batch_size = 2, folding_factor = 4, starting_log_inv_rate = 1;
+    std::vector<unsigned> num_queries, ood_samples;
+    std::vector<double> pow_bits;
+    unsigned final_queries = 0;
+    double final_pow_bits = 0.0;
+    unsigned commitment_ood_samples = 1;
+
+    // round count as the proof fixture and the Go verifier pin it: n/4 - 1 main rounds (whir.go:24-29); the per-round
+    // query counts of the n = 21 instance are the fixture's; pow_bits is a stated assumption
+    static WhirConfig for_size(unsigned n_vars, double pow = 16.0) {
+        static const unsigned q[] = {109, 28, 16, 11, 9, 8, 8};
+        WhirConfig c;
+        c.n_vars = n_vars;
+        const unsigned rounds = n_vars / 4 ? n_vars / 4 - 1 : 0;
+        for (unsigned r = 0; r < rounds && r < 7; r++) {
+            c.num_queries.push_back(q[r]);
+            c.ood_samples.push_back(1);
+            c.pow_bits.push_back(pow);
+        }
+        c.final_queries = 9;
+        c.final_pow_bits = pow;
+        return c;
+    }
+    // new_whir_config_for_size(next_power_of_two(4 m_0) + 1, 2) (r1cs-compiler/src/whir_r1cs.rs:31-34)
+    static WhirConfig for_hiding_spartan(unsigned m_0, double pow = 16.0) {
+        unsigned nb = 0;
+        while ((1u << nb) < 4 * m_0) nb++;
+        WhirConfig c = for_size(nb + 1, pow);
+        for (auto& x : c.num_queries) x = 32;
+        c.final_queries = 13;
+        return c;
+    }
+    pk_whir_config to_c() const {
+        if (num_queries.size() > PK_MAX_WHIR_ROUNDS || ood_samples.size() != num_queries.size() || pow_bits.size() != num_queries.size())
+            throw Error(PK_ERR_BAD_ARG, "WhirConfig: per-round vectors disagree");
+        pk_whir_config s{};
+        s.n_vars = n_vars;
+        s.batch_size = batch_size;
+        s.folding_factor = folding_factor;
+        s.starting_log_inv_rate = starting_log_inv_rate;
+        s.n_rounds = (unsigned)num_queries.size();
+        for (size_t i = 0; i < num_queries.size(); i++) {
+            s.num_queries[i] = num_queries[i];
+            s.ood_samples[i] = ood_samples[i];
+            s.pow_bits[i] = pow_bits[i];
+        }
+        s.final_queries = final_queries;
+        s.final_pow_bits = final_pow_bits;
+        s.commitment_ood_samples = commitment_ood_samples;
+        return s;
+    }
+};
+
+struct WhirR1CSProof {
+    std::vector<uint8_t> transcript;
+};
+
+class WhirR1CSScheme {
+   public:
+    unsigned m, m_0;
+    WhirConfig whir_witness, whir_for_hiding_spartan;
+
+    // binds the scheme to an uploaded R1CS; the ensure!() checks of prove (prover/src/whir_r1cs.rs:43-54) that depend only
+    // on the scheme and the R1CS fire here ("R1CS witness length exceeds scheme capacity", "... constraints exceed ...")
+    WhirR1CSScheme(const Context& c, const R1CS& r1cs, unsigned m_, unsigned m_0_, WhirConfig w, WhirConfig b)
+        : m(m_), m_0(m_0_), whir_witness(std::move(w)), whir_for_hiding_spartan(std::move(b)), c_(&c), n_witness_(r1cs.num_witnesses()) {
+        pk_whir_config cw = whir_witness.to_c(), cb = whir_for_hiding_spartan.to_c();
+        c.check(pk_scheme_create(c.get(), r1cs.get(), r1cs.num_constraints(), r1cs.num_witnesses(), m, m_0, &cw, &cb, &h_));
+    }
+    ~WhirR1CSScheme() {
+        if (h_) pk_scheme_destroy(c_->get(), h_);
+    }
+    WhirR1CSScheme(const WhirR1CSScheme&) = delete;
+    WhirR1CSScheme& operator=(const WhirR1CSScheme&) = delete;
+
+    // WhirR1CSProver::prove(&self, &R1CS, Vec<FieldElement>) -> Result<WhirR1CSProof>: the witness moves to the device and
+    // the proof string comes back; "Unexpected witness length for R1CS instance" is thrown for a wrong length.
+    WhirR1CSProof prove(const std::vector<FieldElement>& witness, uint64_t rng_seed) const {
+        DeviceVec d(*c_, witness);
+        return prove(d, rng_seed);
+    }
+    WhirR1CSProof prove(const DeviceVec& d_witness, uint64_t rng_seed) const {
+        WhirR1CSProof p;
+        p.transcript.resize((size_t)4 << 20);  // proofs of this scheme are a few hundred KiB (268,756 B at the poseidon size)
+        p.transcript.resize(prove_into(d_witness, rng_seed, p.transcript));
+        return p;
+    }
+    // proves into a caller buffer sized once (no size query): the steady-state form
+    size_t prove_into(const DeviceVec& d_witness, uint64_t rng_seed, std::vector<uint8_t>& buf) const {
+        size_t len = 0;
+        c_->check(pk_prove(c_->get(), h_, d_witness.data(), d_witness.size(), rng_seed, buf.data(), buf.size(), &len));
+        return len;
+    }
+    std::string domain_separator() const {
+        size_t n = 0;
+        pk_scheme_domain_separator(h_, nullptr, 0, &n);
+        std::string s(n, '\0');
+        pk_scheme_domain_separator(h_, s.data(), n, &n);
+        return s;
+    }
+
+   private:
+    const Context* c_;
+    pk_scheme* h_ = nullptr;
+    size_t n_witness_;
+};
+
+// spongefish_pow::PowStrategy for Skyscraper (common/src/skyscraper/pow.rs:14-30)
+class SkyscraperPoW {
+   public:
+    // new(challenge, bits): "bits must be smaller than 60" (pow.rs:16)
+    SkyscraperPoW(const Context& c, const std::array<uint8_t, 32>& challenge, double bits) : c_(&c), challenge_(challenge), bits_(bits) {
+        if (!(bits >= 0.0 && bits < 60.0)) throw Error(PK_ERR_BAD_ARG, "bits must be smaller than 60");
+    }
+    bool check(uint64_t nonce) const {
+        int ok = 0;
+        c_->check(pk_pow_check(c_->get(), challenge_.data(), bits_, nonce, &ok));
+        return ok != 0;
+    }
+    std::optional<uint64_t> solve() const {
+        uint64_t nonce = 0;
+        c_->check(pk_pow_solve(c_->get(), challenge_.data(), bits_, &nonce));
+        return nonce;
+    }
+
+   private:
+    const Context* c_;
+    std::array<uint8_t, 32> challenge_;
+    double bits_;
+};
+
+// skyscraper::CompressManyFn = fn(&[u8] /*64 n*/, &mut [u8] /*32 n*/); the reference panics on a length mismatch
+// (generic.rs:18-25), this throws
+inline void compress_many(const Context& c, const std::vector<uint8_t>& messages, std::vector<uint8_t>& hashes) {
+    c.check(pk_compress_many_host(c.get(), messages.data(), messages.size(), hashes.data(), hashes.size()));
+}
+
+}  // namespace provekit
