@@ -101,6 +101,19 @@ int main(int argc, char** argv) {
         } catch (const Error& e) {
             seen += std::string(e.what()).find("exceeds scheme capacity") != std::string::npos;
         }
+        // the Merkle plug-ins agree with each other: a 4-leaf tree's root == the two-level chain of CRH / TwoToOne calls
+        {
+            std::vector<FieldElement> lf(z.begin() + 1, z.begin() + 1 + 4 * 5);  // 4 leaves of width 5
+            DeviceVec d_lf(ctx, lf);
+            MerkleTree tree(ctx, d_lf, 4, 5);
+            Digest h[4];
+            for (int i = 0; i < 4; i++) h[i] = SkyscraperCRH::evaluate(ctx, std::vector<FieldElement>(lf.begin() + 5 * i, lf.begin() + 5 * i + 5));
+            Digest want = SkyscraperTwoToOne::compress(ctx, SkyscraperTwoToOne::compress(ctx, h[0], h[1]), SkyscraperTwoToOne::compress(ctx, h[2], h[3]));
+            if (want != tree.root()) throw Error(-102, "MerkleTree root != chained CRH / TwoToOne compressions");
+            std::vector<FieldElement> opened;
+            std::vector<uint8_t> mp = tree.generate_multi_proof({1, 2}, &opened);
+            if (opened.size() != 10 || mp.size() < 8 * 4 + 32 * 2) throw Error(-103, "generate_multi_proof shape");
+        }
         SkyscraperPoW pow(ctx, std::array<uint8_t, 32>{1, 2, 3}, 10.0);
         const uint64_t nonce = *pow.solve();
         seen += pow.check(nonce) ? 1 : 0;

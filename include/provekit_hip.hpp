@@ -12,6 +12,9 @@
 //   provekit::WhirR1CSScheme      {m, m_0, whir_witness, whir_for_hiding_spartan} + WhirR1CSProver::prove
 //                                 (common/src/whir_r1cs.rs:17-39, prover/src/whir_r1cs.rs:36-100)
 //   provekit::WhirR1CSProof       {transcript} (common/src/whir_r1cs.rs:43-46)
+//   provekit::SkyscraperCRH, SkyscraperTwoToOne, MerkleTree
+//                                 the ark CRHScheme / TwoToOneCRHScheme / MerkleTree<SkyscraperMerkleConfig> plug-ins
+//                                 (common/src/skyscraper/whir.rs:30-86); digests are canonical 32-byte values
 //   provekit::SkyscraperPoW       spongefish_pow::PowStrategy {new, check, solve} (common/src/skyscraper/pow.rs:14-30)
 //   provekit::compress_many       skyscraper::CompressManyFn (skyscraper/core/src/lib.rs:26)
 #pragma once
@@ -229,6 +232,67 @@ class WhirR1CSScheme {
     const Context* c_;
     pk_scheme* h_ = nullptr;
     size_t n_witness_;
+};
+
+using Digest = std::array<uint64_t, 4>;  // canonical little-endian limbs, as the transcript carries them (whir.rs:96-102)
+
+// SkyscraperCRH::evaluate (whir.rs:30-48): leaf.iter().copied().reduce(compress) over Montgomery field elements
+struct SkyscraperCRH {
+    static Digest evaluate(const Context& c, const std::vector<FieldElement>& leaf) {
+        if (leaf.empty()) throw Error(PK_ERR_BAD_ARG, "empty leaf");  // the reference unwraps the reduce() of an empty iterator
+        DeviceVec d(c, leaf), out(c, 1);
+        c.check(pk_leaf_hash(c.get(), d.data(), 1, leaf.size(), PK_LEAF_MAJOR, out.data()));
+        return out.to_host()[0];
+    }
+};
+// SkyscraperTwoToOne::{evaluate, compress} (whir.rs:53-74)
+struct SkyscraperTwoToOne {
+    static Digest compress(const Context& c, const Digest& left, const Digest& right) {
+        std::vector<uint8_t> msg(64), h(32);
+        std::memcpy(msg.data(), left.data(), 32);
+        std::memcpy(msg.data() + 32, right.data(), 32);
+        c.check(pk_compress_many_host(c.get(), msg.data(), 64, h.data(), 32));
+        Digest d;
+        std::memcpy(d.data(), h.data(), 32);
+        return d;
+    }
+};
+// ark MerkleTree::new over leaves already on the device + generate_multi_proof (wire form of types.go:17-22)
+class MerkleTree {
+   public:
+    // leaves: n_leaves x width field elements, leaf-major; n_leaves must be a power of two (ark asserts the same)
+    MerkleTree(const Context& c, const DeviceVec& leaves, size_t n_leaves, size_t width) : c_(&c), n_(n_leaves), width_(width) {
+        if (leaves.size() != n_leaves * width) throw Error(PK_ERR_BAD_ARG, "leaves.size() != n_leaves * width");
+        c.check(pk_tree_from_leaves(c.get(), leaves.data(), n_leaves, width, PK_LEAF_MAJOR, reinterpret_cast<uint8_t*>(root_.data()), &t_));
+    }
+    ~MerkleTree() {
+        if (t_) pk_tree_destroy(c_->get(), t_);
+    }
+    MerkleTree(const MerkleTree&) = delete;
+    MerkleTree& operator=(const MerkleTree&) = delete;
+    Digest root() const { return root_; }
+    // sorted, de-duplicated leaf indices -> ark-serialized MultiPath bytes (what the "merkle_proof" hint carries)
+    std::vector<uint8_t> generate_multi_proof(const std::vector<uint64_t>& indices, std::vector<FieldElement>* opened_leaves = nullptr) const {
+        const size_t k = indices.size();
+        size_t logn = 0;
+        while (((size_t)1 << logn) < n_) logn++;
+        const size_t plen = logn ? logn - 1 : 0;
+        std::vector<FieldElement> lv(k * width_), sib(k ? k : 1), paths((k && plen) ? k * plen : 1);
+        c_->check(pk_tree_open(c_->get(), t_, indices.data(), k, 1, lv.empty() ? nullptr : lv[0].data(), sib[0].data(), paths[0].data()));
+        size_t len = 0;
+        pk_multipath_serialize(indices.data(), k, plen, sib[0].data(), paths[0].data(), nullptr, 0, &len);
+        std::vector<uint8_t> out(len);
+        int rc = pk_multipath_serialize(indices.data(), k, plen, sib[0].data(), paths[0].data(), out.data(), out.size(), &len);
+        if (rc) throw Error(rc, "pk_multipath_serialize failed");
+        if (opened_leaves) *opened_leaves = std::move(lv);
+        return out;
+    }
+
+   private:
+    const Context* c_;
+    pk_tree* t_ = nullptr;
+    size_t n_, width_;
+    Digest root_{};
 };
 
 // spongefish_pow::PowStrategy for Skyscraper (common/src/skyscraper/pow.rs:14-30)
