@@ -20,9 +20,14 @@
  *     reference panics via expect() at prover/src/whir_r1cs.rs:206,434; the Rust
  *     shim maps a status to anyhow::Error instead).
  *   - A pk_ctx is bound to one device and one stream and is single-caller (not
- *     thread-safe); distinct contexts may be used from distinct threads.
+ *     thread-safe); distinct contexts may be used from distinct threads (every
+ *     entry point selects the context's device on the calling thread).
  *     Work is enqueued on the context's stream; calls that return values to the
- *     host synchronise that stream, all others are asynchronous.
+ *     host synchronise that stream, all others are asynchronous.  Small results
+ *     (sums, roots, nonces, openings) reach the host through pinned memory written
+ *     by the producing kernel, not through copy operations.
+ *   - Above this C ABI: include/provekit_hip.hpp (C++17, the reference's names) and
+ *     provekit_amd/ (Python/ctypes).
  *   - Ownership: the caller owns every host pointer for the duration of the call
  *     and every device buffer it allocated; the library owns only what is behind
  *     its opaque handles (pk_ctx, pk_tree, pk_r1cs) until the matching destroy.
