@@ -204,3 +204,47 @@ def test_prove_verify_bench_size(ctx, oracle):
         V.verify(bytes(bad), *args)
     scheme.close()
     r1cs.close()
+
+
+def test_concurrent_provers_are_deterministic(oracle):
+    """Four prover threads, each with its own context / stream / arena (the bench's throughput mode), proving the same
+    statement with the same seeds at the same time: every transcript must equal the one a lone prover produced -- no state
+    is shared between contexts."""
+    import threading
+
+    import provekit_amd
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS
+
+    m, m_0, nc, n_in = 12, 9, 500, 700
+    nw, z, coeffs, trips = satisfiable_r1cs(nc, n_in, 5)
+    zm = oracle.to_mont(oracle.ints_to_limbs(z))
+    interner = oracle.to_mont(oracle.ints_to_limbs(coeffs))
+
+    def make():
+        c = provekit_amd.Context(0)
+        r = R1CS(c, *(to_sparse(nc, nw, t) for t in trips), interner)
+        s = WhirR1CSScheme(c, r, m, m_0, WhirConfig.for_size(m, 6.0), blinding_config_for(m_0, 6.0))
+        return c, r, s, c.upload(zm)
+
+    seeds = [11, 12, 13, 14, 15]
+    c0, r0, s0, d0 = make()
+    want = [s0.prove(d0, seed=sd) for sd in seeds]
+    workers = [make() for _ in range(4)]
+    got = [None] * 4
+
+    def run(i):
+        _, _, s, d = workers[i]
+        got[i] = [s.prove(d, seed=sd) for sd in seeds]
+
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for i in range(4):
+        assert got[i] == want, f"prover thread {i} diverged"
+    for c, r, s, _ in workers + [(c0, r0, s0, d0)]:
+        s.close()
+        r.close()
+        c.close()
