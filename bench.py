@@ -376,7 +376,6 @@ def main():
         n_l, ms_l = prof.get("leaf_hash", (0, 0.0))
         avg_ms = ms_l / max(n_l, 1)
         achieved = (bytes_step / launches_step) / (avg_ms * 1e-3) / 1e9 if n_l else 0.0
-        steps_w0 = max(len(range(0, args.steps, conc)), 1)  # the profiled context (worker 0) ran this many proofs
         # HBM bytes per launch from the rocprofv3 PMC passes (tools/pmc.sh; FETCH_SIZE doubled as the microarch guide
         # prescribes for gfx950).  Counters cannot be read from inside this process, so the committed summary of the same
         # command is used; null when it is missing or was taken on another workload size.
@@ -396,7 +395,9 @@ def main():
                 valu_busy = pv["kernels"]["leaf_hash_kernel<2, 1>"][str(1 << 18)]["VALUBusy"]
         except Exception:
             pass
-        stage_ms = {k: round(v[1] / steps_w0, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}
+        # per-proof kernel time by stage, from the one-proof-at-a-time pass (in the timed region a prover's kernels share the
+        # chip with the other provers', so their elapsed times there say little about the work)
+        stage_ms = {k: round(v[1] / iso_steps, 4) for k, v in sorted(prof_iso.items(), key=lambda kv: -kv[1][1])}
         line = {
             "metric": "proofs/sec (noir-r1cs prove hot path, WHIR commit + sumcheck + folding rounds)",
             "value": world * args.steps / dt,
@@ -450,7 +451,7 @@ def main():
             # element (one logical read + write) over the measured time of all encode kernels of a proof
             "roofline_ntt": ntt_roofline(prof_iso, iso_steps, m, cfg_w, cfg_b),
             "single_stream": {"ms_per_proof": 1e3 * iso_dt, "proofs_per_s": 1.0 / iso_dt},
-            "stage_ms_per_step": stage_ms,
+            "stage_ms_per_proof_isolated": stage_ms,
         }
         if not args.no_cpu_baseline and world == 1:
             cdt, threads = cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg_w)
