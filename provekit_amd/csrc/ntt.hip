@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NTHREADS) void ntt_pass_kernel(PassParams p) {
 // Tile index I (11 bits) = r * BT + b.  Round j transforms digit D_j of r (digits are taken from the top of r: DIF),
 // leaving the frequency digit a_j in the same bit positions; the output frequency is the digit reversal
 // k = a_0 + 2^d0 a_1 + 2^(d0+d1) a_2.  In round j a lane's 8 registers are indexed by (digit bits | low 3-d_j bits of b).
-__device__ __forceinline__ fe29 red29(fe29 x) {  // lazy non-negative limbs, value < 4p -> normalized, < p(1+2^-18)
+__device__ __forceinline__ fe29 red29(fe29 x) {  // lazy non-negative limbs, value < 4p -> normalized, < p(1+2^-10)
     reduce_almost29(x);
     return x;
 }

@@ -2,7 +2,7 @@
 //
 // Semantics as skyscraper.hpp (skyscraper/core/src/reference.rs:41-98, generic.rs:77-102, v1.rs:19-32);
 // this is the fast path every hashing kernel uses.  State values are canonical-domain integers kept
-// "almost reduced" (< p(1 + 2^-18), limbs normalized) between rounds, the lazy-reduction idea of
+// "almost reduced" (< p(1 + 2^-10), limbs normalized) between rounds, the lazy-reduction idea of
 // skyscraper/core/src/reduce.rs:35-55 (table of multiples indexed by the top limb) restated for 29-bit
 // limbs: subtract floor(top/(p_top+1)) * p, one signed carry sweep.
 #pragma once

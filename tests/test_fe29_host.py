@@ -112,3 +112,40 @@ def test_wide_reduce(oracle):
     ys = [b for _ in edge for b in edge] + rand_fe(3000, 22)
     got = oracle.limbs_to_ints(run(14, oracle.ints_to_limbs(xs), oracle.ints_to_limbs(ys)))
     assert got == [(700 * x + 324 * y) % P for x, y in zip(xs, ys)]
+
+
+def test_lazy_reductions_at_their_limits(oracle):
+    """mirror of skyscraper/core/src/reduce.rs:76-126 (reduce / reduce_partial incl. the *_max cases): the 'almost reduced'
+    form of ANY 256-bit input is congruent to it and below p (1 + 2^-10); the exact conditional subtraction is exact"""
+    edge = [0, 1, P - 1, P, P + 1, 2 * P - 1, 2 * P, 3 * P + 7, 4 * P - 1, 5 * P, 5 * P + 123, (1 << 256) - 1, (1 << 256) - P, (1 << 255), (1 << 232) - 1]
+    xs = edge + rand_fe(4000, 31, 1 << 256)
+    out = oracle.limbs_to_ints(run(9, oracle.ints_to_limbs(xs)))  # pack29(unpack_reduce29(x))
+    bound = P + (P >> 10)
+    for x, r in zip(xs, out):
+        assert r % P == x % P and r < bound, hex(x)
+    ys = [v for v in edge if v < 2 * P] + rand_fe(2000, 32, 2 * P)
+    assert oracle.limbs_to_ints(run(12, oracle.ints_to_limbs(ys))) == [y % P for y in ys]  # cond_sub_p29
+
+
+def test_bar_every_sbox_input(oracle):
+    """bar (skyscraper/core/src/bar.rs:15-31, sbox :40-42) on canonical inputs whose bytes run through all 256 values (the
+    reference's proptest `test_sbox_ref`, exhaustively): the result is congruent to the restatement's bar and below 2.3 p"""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as pr
+
+    xs = []
+    for base in range(0, 256, 31):  # 31 free bytes per input; the top byte stays below 0x30 so the value is < p
+        b = bytes((base + i) % 256 for i in range(31)) + bytes([0x2F])
+        xs.append(int.from_bytes(b, "little"))
+    for top in (0x00, 0x30):  # p's own top byte with a smaller next byte is still < p
+        xs.append(int.from_bytes(bytes(range(200, 231)) + bytes([top]), "little") % P)
+    xs += rand_fe(3000, 33)
+    seen = set()
+    for x in xs:
+        seen.update(x.to_bytes(32, "little"))
+    assert len(seen) == 256
+    got = oracle.limbs_to_ints(run(13, oracle.ints_to_limbs(xs)))
+    for x, g in zip(xs, got):
+        assert g % P == pr.bar(x) and g < 2 * P + (3 * P) // 10, hex(x)
