@@ -141,3 +141,24 @@ def test_eq_accumulate_mailbox_many_points(ctx, oracle):
         sc.eq_accumulate(ctx, dd, nv, pt[None], s, overwrite=True)
         e = oracle.eq_accumulate_point(np.zeros((1 << nv, 4), dtype=np.uint64), nv, pt, s[0])
         assert np.array_equal(ctx.download_fe(dd, 1 << nv), e)
+
+
+def test_pow_reference_solve_verify_case(ctx, oracle):
+    """skyscraper/core/src/pow.rs:105-111 `test_solve_verify`: challenge = [u64::MAX; 4] (above p: the reduce_partial
+    path), difficulty 0 and pi"""
+    import math
+
+    from provekit_amd._lib import lib
+
+    ch = np.full(32, 0xFF, dtype=np.uint8)
+    chw = np.frombuffer(ch.tobytes(), dtype=np.uint64)
+    for bits in (0.0, math.pi):
+        nonce = C.c_uint64(123)
+        ctx._check(lib.pk_pow_solve(ctx.handle, ch.ctypes.data, bits, C.byref(nonce)))
+        ok = C.c_int()
+        ctx._check(lib.pk_pow_check(ctx.handle, ch.ctypes.data, bits, nonce.value, C.byref(ok)))
+        assert ok.value == 1 and oracle.pow_verify(chw, bits, nonce.value)
+        if bits == 0.0:
+            assert nonce.value == 0  # pow.rs:34-36
+        else:
+            assert nonce.value == oracle.pow_solve(chw, bits)  # both return the smallest nonce under the biased threshold
