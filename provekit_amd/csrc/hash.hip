@@ -39,9 +39,9 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const fe* __restrict__ l
     for (unsigned j = 1; j < width; j++) {
         fe29 x = from_mont29(nxt);
         if (j + 1 < width) nxt = fe_load(p + (size_t)(j + 1) * step);  // prefetch next column
-        h = compress29<VERSION>(h, x);
+        h = compress29<VERSION, false>(h, x);  // intermediate digests of the fold stay lazily reduced
     }
-    fe_store(digests + i, pack29(h));
+    fe_store(digests + i, pack29(cond_sub_p29(h)));  // h < 2p: exact canonical form once per leaf (also for width 1)
 }
 
 // `levels` consecutive levels of ark MerkleTree::new in one launch: nodes[i] = C(nodes[2i], nodes[2i+1]).  A workgroup

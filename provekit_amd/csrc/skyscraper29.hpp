@@ -49,8 +49,10 @@ PK_HD void sky_round29(fe29& l, fe29& r) {
     l = s;
 }
 
-// l, r: normalized, almost reduced.  Returns the canonical digest (< p, normalized).
-template <int VERSION>
+// l, r: normalized, almost reduced.  CANONICAL = true returns the canonical digest (< p, normalized); false returns it
+// almost reduced only -- enough when the digest feeds the next compression of a leaf's left fold, and cheaper by three exact
+// conditional subtractions.
+template <int VERSION, bool CANONICAL = true>
 PK_HD fe29 compress29(const fe29& l_in, const fe29& r_in) {
     fe29 l = l_in, r = r_in;
     if (VERSION == 2) {  // generic.rs:77-102
@@ -83,6 +85,11 @@ PK_HD fe29 compress29(const fe29& l_in, const fe29& r_in) {
         sky_round29<7, true>(l, r);
         sky_round29<8, false>(l, r);
         sky_round29<0, false>(l, r);
+    }
+    if (!CANONICAL) {  // l + l_in < 2.01 p: one lazy step
+        fe29 s = add29(l, l_in);
+        reduce_almost29(s);
+        return s;
     }
     // out = l + l_in mod p, exactly
     fe29 a = cond_sub_p29(l), b = cond_sub_p29(l_in);
