@@ -134,10 +134,11 @@ struct WhirConfig {
     double final_pow_bits = 0.0;
     unsigned commitment_ood_samples = 1;
 
-    // round count as the proof fixture and the Go verifier pin it: n/4 - 1 main rounds (whir.go:24-29); the per-round
-    // query counts of the n = 21 instance are the fixture's; pow_bits is a stated assumption
+    // round count as the proof fixture and the Go verifier pin it: n/4 - 1 main rounds (whir.go:24-29); the STIR query
+    // counts follow the rate of each round's code as the fixture shows them (2^-1: 109, 2^-4: 28, 2^-7: 16, 2^-10: 11,
+    // 2^-13: 9) for the witness and the blinding WHIR alike; pow_bits is a stated assumption
     static WhirConfig for_size(unsigned n_vars, double pow = 16.0) {
-        static const unsigned q[] = {109, 28, 16, 11, 9, 8, 8};
+        static const unsigned q[] = {109, 28, 16, 11, 9, 8, 8, 8};
         WhirConfig c;
         c.n_vars = n_vars;
         const unsigned rounds = n_vars / 4 ? n_vars / 4 - 1 : 0;
@@ -146,7 +147,7 @@ struct WhirConfig {
             c.ood_samples.push_back(1);
             c.pow_bits.push_back(pow);
         }
-        c.final_queries = 9;
+        c.final_queries = q[rounds < 7 ? rounds : 7];
         c.final_pow_bits = pow;
         return c;
     }
@@ -154,10 +155,7 @@ struct WhirConfig {
     static WhirConfig for_hiding_spartan(unsigned m_0, double pow = 16.0) {
         unsigned nb = 0;
         while ((1u << nb) < 4 * m_0) nb++;
-        WhirConfig c = for_size(nb + 1, pow);
-        for (auto& x : c.num_queries) x = 32;
-        c.final_queries = 13;
-        return c;
+        return for_size(nb + 1, pow);
     }
     pk_whir_config to_c() const {
         if (num_queries.size() > PK_MAX_WHIR_ROUNDS || ood_samples.size() != num_queries.size() || pow_bits.size() != num_queries.size())

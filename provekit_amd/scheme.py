@@ -37,15 +37,21 @@ class WhirConfig:
 
     @staticmethod
     def poseidon_blinding(pow_bits: float = 16.0) -> "WhirConfig":
-        return WhirConfig(8, num_queries=[32], ood_samples=[1], pow_bits=[pow_bits], final_queries=13, final_pow_bits=pow_bits)
+        return blinding_config_for(20, pow_bits)
+
+    # STIR queries per round as the reference's proof fixture shows them: they follow the rate of the
+    # round's code -- 2^-1: 109, 2^-4: 28, 2^-7: 16, 2^-10: 11, 2^-13: 9 -- for the witness WHIR (4 rounds + final 9) and for
+    # the blinding WHIR alike (its 32-leaf tree is opened at all 32 leaves and its 16-leaf round tree at 13: what 109 and
+    # 28 uniform queries give, not 32 and 13)
+    QUERIES_BY_ROUND = [109, 28, 16, 11, 9, 8, 8, 8]
 
     @staticmethod
     def for_size(n_vars: int, pow_bits: float = 16.0) -> "WhirConfig":
         """size-class configs.  Round count as the fixture and the Go verifier pin it:
         n_rounds = n/4 - 1 main rounds, final polynomial on n mod 4 variables (whir.go:24-29)."""
         rounds = max(n_vars // 4 - 1, 0)
-        q = [109, 28, 16, 11, 9, 8, 8][:rounds]
-        return WhirConfig(n_vars, num_queries=q, ood_samples=[1] * rounds, pow_bits=[pow_bits] * rounds, final_queries=9,
+        q = WhirConfig.QUERIES_BY_ROUND
+        return WhirConfig(n_vars, num_queries=q[:rounds], ood_samples=[1] * rounds, pow_bits=[pow_bits] * rounds, final_queries=q[rounds],
                           final_pow_bits=pow_bits)
 
 
@@ -62,10 +68,7 @@ def _cfg_struct(cfg: WhirConfig) -> WhirConfigStruct:
 def blinding_config_for(m_0: int, pow_bits: float = 16.0) -> WhirConfig:
     """new_whir_config_for_size(next_power_of_two(4*m_0) + 1, 2) (provekit/r1cs-compiler/src/whir_r1cs.rs:31-34)"""
     nb = max((4 * m_0 - 1).bit_length(), 0)
-    cfg = WhirConfig.for_size(nb + 1, pow_bits)
-    cfg.num_queries = [32] * cfg.n_rounds
-    cfg.final_queries = 13
-    return cfg
+    return WhirConfig.for_size(nb + 1, pow_bits)
 
 
 class WhirR1CSScheme:

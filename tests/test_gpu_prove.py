@@ -198,6 +198,17 @@ def test_prove_verify_bench_size(ctx, oracle):
 
     args = (scheme.domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
     assert V.verify(proof, *args)
+    # same wire layout as the reference's proof of this size class (decoded from poseidon-1000.np):
+    # 3304 bytes of scalars -- root, 2 OOD answers, blinding root, 2 OOD answers, sum G, 20 x 4 sumcheck coefficients,
+    # 2 polynomial sums, 4 x 3 sumcheck evaluations, round root, OOD answer, 8-byte nonce -- then the first hint,
+    # `stir_answers`: u32 length | u64 count | count x (u64 width = 32 | 32 canonical field elements)
+    import struct
+
+    ln = struct.unpack_from("<I", proof, 3304)[0]
+    k = struct.unpack_from("<Q", proof, 3308)[0]
+    assert 1 <= k <= 32 and ln == 8 + k * (8 + 32 * 32)
+    assert all(struct.unpack_from("<Q", proof, 3316 + q * (8 + 1024))[0] == 32 for q in range(k))
+    assert 260_000 < len(proof) < 277_000  # the reference's proof of this shape is 268,756 bytes (query de-duplication varies)
     bad = bytearray(proof)
     bad[len(bad) // 2] ^= 1
     with pytest.raises((V.VerifyError, Exception)):
