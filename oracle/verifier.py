@@ -23,7 +23,15 @@ class VerifyError(Exception):
     pass
 
 
-def ensure(cond, msg):
+# structure_only: walk a transcript in the verifier's read order checking framing only (lengths, counts, hint shapes,
+# Merkle openings under `hash_version`) and none of the Fiat-Shamir-dependent relations -- used to replay the REFERENCE's
+# own proof fixture, whose domain-separator labels (hence challenges) this restatement cannot reproduce.
+_MODE = {"structure_only": False, "hash_version": 2}
+
+
+def ensure(cond, msg, structural=False):
+    if _MODE["structure_only"] and not structural:
+        return
     if not cond:
         raise VerifyError(msg)
 
@@ -96,7 +104,7 @@ class Arthur:
         return self.st[0]
 
     def _read(self, n):
-        ensure(self.i + n <= len(self.t), "transcript too short")
+        ensure(self.i + n <= len(self.t), "transcript too short", True)
         b = self.t[self.i : self.i + n]
         self.i += n
         return b
@@ -105,7 +113,7 @@ class Arthur:
         out = []
         for _ in range(n):
             v = int.from_bytes(self._read(32), "little")
-            ensure(v < P, "non-canonical scalar")
+            ensure(v < P, "non-canonical scalar", True)
             self._absorb(v)
             out.append(v)
         return out
@@ -182,7 +190,7 @@ class Rd:
 def parse_vec_vec(payload):
     rd = Rd(payload)
     out = [[rd.fe() for _ in range(rd.u64())] for _ in range(rd.u64())]
-    ensure(rd.end(), "trailing bytes in stir_answers")
+    ensure(rd.end(), "trailing bytes in stir_answers", True)
     return out
 
 
@@ -196,7 +204,7 @@ def parse_multipath(payload):
     pre = [rd.u64() for _ in range(rd.u64())]
     suf = [[rd.fe() for _ in range(rd.u64())] for _ in range(rd.u64())]
     idx = [rd.u64() for _ in range(rd.u64())]
-    ensure(rd.end(), "trailing bytes in merkle_proof")
+    ensure(rd.end(), "trailing bytes in merkle_proof", True)
     paths, prev = [], []
     for p, s in zip(pre, suf):  # utilities.go:71-82
         cur = prev[:p] + s
@@ -206,15 +214,17 @@ def parse_multipath(payload):
 
 
 def verify_merkle(leaves, sib, paths, idx, root):  # whir_utilities.go:13-46
-    ensure(len(leaves) == len(sib) == len(paths) == len(idx), "opening count mismatch")
+    ensure(len(leaves) == len(sib) == len(paths) == len(idx), "opening count mismatch", True)
+    ver = _MODE["hash_version"]
+    c = pr.compress if ver == 2 else pr.compress_v1
     for leaf, s, path, i in zip(leaves, sib, paths, idx):
-        h = pr.leaf_hash(leaf)
-        h = pr.compress(s, h) if i & 1 else pr.compress(h, s)
+        h = pr.leaf_hash(leaf, ver)
+        h = c(s, h) if i & 1 else c(h, s)
         i >>= 1
         for node in reversed(path):
-            h = pr.compress(node, h) if i & 1 else pr.compress(h, node)
+            h = c(node, h) if i & 1 else c(h, node)
             i >>= 1
-        ensure(h == root, "Merkle opening does not reach the root")
+        ensure(h == root, "Merkle opening does not reach the root", True)  # independent of the transcript: always checked
 
 
 @dataclass
@@ -325,7 +335,7 @@ def whir_verify(A: Arthur, com, cfg: WhirConfig, claimed_sums):
     if claimed_sums:
         rd = Rd(A.hint())
         deferred = parse_vec(rd)
-        ensure(rd.end() and len(deferred) == len(claimed_sums), "bad deferred_weight_evaluations hint")
+        ensure(rd.end() and len(deferred) == len(claimed_sums), "bad deferred_weight_evaluations hint", True)
     rev = total[::-1]
     # computeWPoly (whir_utilities.go:127-157)
     value = 0
@@ -352,9 +362,19 @@ def mle_eval_table(table, point):
     return v[0]
 
 
-def verify(transcript: bytes, domain_separator: bytes, m: int, m_0: int, cfg_w: WhirConfig, cfg_b: WhirConfig, r1cs=None):
+def verify(transcript: bytes, domain_separator: bytes, m: int, m_0: int, cfg_w: WhirConfig, cfg_b: WhirConfig, r1cs=None,
+           structure_only: bool = False, hash_version: int = 2):
     """WhirR1CSVerifier::verify.  r1cs = (num_constraints, num_witnesses, [(rows, cols, vals)]*3 canonical) enables the
-    matrix-evaluation check of the deferred weights."""
+    matrix-evaluation check of the deferred weights.  structure_only / hash_version: see _MODE."""
+    old = dict(_MODE)
+    _MODE.update(structure_only=structure_only, hash_version=hash_version)
+    try:
+        return _verify(transcript, domain_separator, m, m_0, cfg_w, cfg_b, r1cs)
+    finally:
+        _MODE.update(old)
+
+
+def _verify(transcript, domain_separator, m, m_0, cfg_w, cfg_b, r1cs):
     A = Arthur(domain_separator, transcript)
     wcom = parse_commitment(A, cfg_w)
     r = A.challenge_scalars(m_0)
@@ -380,10 +400,10 @@ def verify(transcript: bytes, domain_separator: bytes, m: int, m_0: int, cfg_w: 
     f_at_alpha = (saved - rho * bsums[0]) % P
     rd = Rd(A.hint())  # claimed_evaluations
     f_sums, g_sums = parse_vec(rd), parse_vec(rd)
-    ensure(rd.end() and len(f_sums) == 3 and len(g_sums) == 3, "bad claimed_evaluations hint")
+    ensure(rd.end() and len(f_sums) == 3 and len(g_sums) == 3, "bad claimed_evaluations hint", True)
     claims = [(f + wcom["beta"] * g) % P for f, g in zip(f_sums, g_sums)]
     wrev, wdef = whir_verify(A, wcom, cfg_w, claims)
-    ensure(A.done(), "trailing bytes after the proof")
+    ensure(A.done(), "trailing bytes after the proof", True)
     # the Spartan relation (whir_r1cs.rs:78-86)
     ensure(f_at_alpha == (f_sums[0] * f_sums[1] - f_sums[2]) * eq_poly(r, alpha) % P, "last sumcheck value does not match")
     if r1cs is not None:  # matrix_evaluation.go: deferred_k == MLE(eq(alpha)^T M_k zero-extended)(wrev)
