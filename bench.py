@@ -174,6 +174,39 @@ def cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg):
     return dt, o.L.pko_num_threads()
 
 
+def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3):
+    """BASELINE configs[4] on this GPU, as a secondary figure of the default line: one batch-2 WHIR commit of 2^26 seeded
+    coefficients (RS-encode of 2 x 16 NTTs of 2^23 + 2^23 leaf hashes of width 32 + the tree), buffers allocated once,
+    timed with hipEvents on the context's stream.  Algorithmic bytes as BASELINE.md 4."""
+    import ctypes as C
+
+    from provekit_amd._lib import PK_COL_MAJOR, lib
+
+    n, rows, width = 1 << n_vars, 1 << (n_vars + 1 - 4), 32
+    polys = []
+    for b in range(2):
+        t = torch.randint(0, 2**62, (n, 4), dtype=torch.int64, device=f"cuda:{local_rank}", generator=torch.Generator(device=f"cuda:{local_rank}").manual_seed(17 + b))
+        t[:, 3] &= (1 << 60) - 1
+        polys.append(t)
+    torch.cuda.synchronize()
+    ptrs = (C.c_void_p * 2)(*[int(t.data_ptr()) for t in polys])
+    leaves, nodes, scratch = ctx.alloc_fe(rows * width), ctx.alloc_fe(2 * rows), ctx.alloc_fe(2 * rows * width)
+    ms = []
+    for i in range(reps + 1):
+        ctx.timer_start()
+        ctx._check(lib.pk_rs_encode(ctx.handle, ptrs, 2, n_vars, 1, 4, leaves.ptr, scratch.ptr))
+        ctx._check(lib.pk_merkle_commit(ctx.handle, leaves.ptr, rows, width, PK_COL_MAJOR, nodes.ptr))
+        t = ctx.timer_stop()
+        if i:
+            ms.append(t)
+    root = ctx.download_fe(nodes.view_fe(1), 1)[0].tobytes().hex()
+    alg = 32 * 2 * n + 32 * 2 * 2 * n + 64 * rows
+    best = min(ms)
+    return {"workload": f"batch-2 WHIR commit of 2^{n_vars} coefficients (rate 1/2, fold 16): {rows * 31 + rows - 1} compressions, 32 NTTs of 2^{n_vars - 3}",
+            "ms_per_commit": best, "algorithmic_GB": alg / 1e9, "achieved_GBps": alg / (best * 1e-3) / 1e9,
+            "frac_of_hbm_peak": alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "root": root}
+
+
 def commit_workload(args, rank, local_rank, world, dist, torch):
     """configs[4]: one batch-2 commit of 2^m coefficients (default m as given; 26 for the BASELINE config), sharded by
     leaf index over the ranks (provekit_amd/distributed.py): strong scaling, one all-gather of leaf digests per commit."""
@@ -260,6 +293,7 @@ def main():
                     help="log2 of the committed polynomial size (poseidon-rounds: 21).  Under torch.distributed.run spell it "
                          "--log2-size: the launcher's own parser rejects --m as an ambiguous abbreviation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-commit-probe", action="store_true", help="skip the secondary 2^26 commit figure (configs[4]) of the default line")
     ap.add_argument("--workload", choices=["prove", "commit"], default="prove",
                     help="prove = BASELINE configs[1] (default, the judged line); commit = one batch-2 WHIR commit of 2^m coefficients "
                          "(configs[4] with --m 26), SHARDED over the ranks with an all-gather of leaf digests (strong scaling)")
@@ -469,6 +503,11 @@ def main():
             "single_stream": {"ms_per_proof": 1e3 * iso_dt, "proofs_per_s": 1.0 / iso_dt},
             "stage_ms_per_proof_isolated": stage_ms,
         }
+        if world == 1 and m == 21 and not args.no_commit_probe:
+            try:  # secondary figure; never allowed to break the line
+                line["commit_2p26"] = commit_probe(ctx, torch, local_rank)
+            except Exception as e:  # e.g. a GPU with less memory
+                line["commit_2p26"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             cdt, threads = cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg_w)
             line["cpu_baseline"] = {
