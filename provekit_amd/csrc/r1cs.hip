@@ -71,6 +71,19 @@ __global__ __launch_bounds__(256) void satisfaction_kernel(const uint32_t* pa, c
     if (!fe_eq(fe_mulx(ra, rb), rc)) atomicMin(first_bad, (unsigned long long)i);
 }
 
+// eq^T A, eq^T B, eq^T C in one launch: lane j walks column j of all three matrices.  Column degrees vary (lanes of a
+// wavefront wait for the longest column), and the sum of three degrees varies relatively less than each one alone.
+struct csc3 {
+    const uint32_t *ptr[3], *idx[3], *val[3];
+};
+__global__ __launch_bounds__(256) void sparse_gather3_kernel(csc3 m, const fe* __restrict__ interner, const fe* __restrict__ x, size_t n_out,
+                                                             fe* __restrict__ y) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+#pragma unroll 1
+    for (int k = 0; k < 3; k++) fe_store(y + (size_t)k * n_out + i, sparse_row_dot(m.ptr[k], m.idx[k], m.val[k], interner, x, i));
+}
+
 int upload_u32(pk_ctx* ctx, const std::vector<uint32_t>& v, uint32_t** out) {
     PK_HIP(ctx, hipMalloc((void**)out, (v.size() ? v.size() : 1) * 4));
     if (!v.empty()) PK_HIP(ctx, hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
@@ -212,10 +225,17 @@ int pk_r1cs_test_witness_satisfaction(pk_ctx* ctx, const pk_r1cs* r, const uint6
 int pk_r1cs_external_row(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_eq_alpha, uint64_t* d_out) {
     PK_ENTER(ctx);
     PK_REQUIRE(ctx, r && d_eq_alpha && d_out, "null pointer");
-    for (int m = 0; m < 3; m++) {
-        int rc = pk_r1cs_matvec(ctx, r, m, 1, d_eq_alpha, d_out + 4 * (size_t)m * r->num_witnesses);
-        if (rc) return rc;
+    if (!r->num_witnesses) return PK_OK;
+    csc3 m;
+    for (int k = 0; k < 3; k++) {
+        m.ptr[k] = r->csc_ptr[k];
+        m.idx[k] = r->csc_idx[k];
+        m.val[k] = r->csc_val[k];
     }
+    ProfScope prof(ctx, "sparse_matvec");
+    sparse_gather3_kernel<<<(unsigned)((r->num_witnesses + 255) / 256), 256, 0, ctx->stream>>>(m, r->d_interner, (const fe*)d_eq_alpha, r->num_witnesses,
+                                                                                             (fe*)d_out);
+    PK_LAUNCH_CHECK(ctx);
     return PK_OK;
 }
 
