@@ -112,8 +112,15 @@ def test_bench_multirank_control_flow_on_one_gpu(ctx, oracle):
 
     from provekit_amd.whir import commit_batch
 
+    import socket
+
     root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PK_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+
+    def free_port():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            return sk.getsockname()[1]
 
     def launch(extra, port):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
@@ -125,7 +132,7 @@ def test_bench_multirank_control_flow_on_one_gpu(ctx, oracle):
         return json.loads(lines[0])
 
     m = 15
-    d = launch(["--workload", "commit", "--log2-size", str(m)], 29541)
+    d = launch(["--workload", "commit", "--log2-size", str(m)], free_port())
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     polys = []
     for b in range(2):  # the seeded coefficients bench.py's commit workload generates
@@ -136,6 +143,6 @@ def test_bench_multirank_control_flow_on_one_gpu(ctx, oracle):
     ref = commit_batch(ctx, [int(t.data_ptr()) for t in polys], m)
     assert d["config"]["root"] == ref.root.hex()
     ref.close()
-    p = launch(["--workload", "prove", "--log2-size", "13", "--concurrency", "2", "--no-cpu-baseline"], 29542)
+    p = launch(["--workload", "prove", "--log2-size", "13", "--concurrency", "2", "--no-cpu-baseline"], free_port())
     assert p["n_gpus"] == 2 and p["steps"] == 2 and p["scaling"] == "weak" and p["value"] > 0
     assert abs(p["value"] - 2 * 2 / (p["ms_per_step"] * 2 * 1e-3)) / p["value"] < 1e-6  # whole-job aggregate: ranks x steps / time
