@@ -76,15 +76,18 @@ int main(int argc, char** argv) {
         r1cs.test_witness_satisfaction(d_z);
 
         WhirR1CSScheme scheme(ctx, r1cs, m, m_0, WhirConfig::for_size(m, 8.0), WhirConfig::for_hiding_spartan(m_0, 8.0));
-        WhirR1CSProof proof = scheme.prove(d_z, 42);
-        WhirR1CSProof again = scheme.prove(d_z, 42);
+        const auto seed = WhirR1CSScheme::test_seed(42);  // test hook: reproducible transcript
+        WhirR1CSProof proof = scheme.prove(d_z, &seed);
+        WhirR1CSProof again = scheme.prove(d_z, &seed);
         if (proof.transcript != again.transcript) throw Error(-100, "same witness and seed gave different transcripts");
+        WhirR1CSProof fresh = scheme.prove(d_z);  // production form: masks from the OS CSPRNG, a different transcript every time
+        if (fresh.transcript == proof.transcript) throw Error(-101, "fresh randomness reproduced the seeded transcript");
 
         // error behaviour of the reference's ensure!() / test_witness_satisfaction
         int seen = 0;
         try {
             DeviceVec shorter(ctx, nw - 1);
-            scheme.prove(shorter, 1);
+            scheme.prove(shorter);
         } catch (const Error& e) {
             seen += std::string(e.what()).find("Unexpected witness length") != std::string::npos;
         }

@@ -277,8 +277,12 @@ int pk_multipath_serialize(const uint64_t *indices, size_t k, size_t path_len, c
  * bound to an uploaded R1CS; it owns a device arena sized for one proof, so pk_prove allocates nothing.
  * pk_prove = WhirR1CSProver::prove(&self, &R1CS, Vec<FieldElement>) -> WhirR1CSProof{transcript}
  * (provekit/prover/src/whir_r1cs.rs:36-100): d_witness = n_witness Montgomery FEs on the device; the proof string is
- * written to transcript_out (capacity cap; *len receives its length).  rng_seed seeds the three random draws the
- * reference takes from thread_rng (mask, random polynomial, blinding univariates). */
+ * written to transcript_out (capacity cap; *len receives its length).
+ * Randomness: the reference takes the ZK mask, the random polynomial and the blinding univariates from thread_rng
+ * (provekit/common/src/utils/zk_utils.rs:13-22, provekit/prover/src/whir_r1cs.rs:197,212-221).  With
+ * rng_seed32 == NULL (production) pk_prove draws a fresh 256-bit key from the OS CSPRNG (getrandom) for every proof
+ * and expands it on the device with ChaCha20 + rejection sampling; a non-NULL rng_seed32 (32 bytes) injects the key
+ * instead -- a TEST HOOK for reproducible transcripts, never to be used with a fixed value in deployment. */
 #define PK_MAX_WHIR_ROUNDS 16
 typedef struct pk_whir_config {
     unsigned n_vars;
@@ -292,11 +296,23 @@ typedef struct pk_whir_config {
     unsigned final_queries;
     double final_pow_bits;
     unsigned commitment_ood_samples;
+    double final_folding_pow_bits; /* PoW after the final sumcheck when > 0 (recursive-verifier/app/circuit/whir.go:196-201;
+                                      exported at tooling/provekit-gnark/src/gnark_config.rs:52,91) */
 } pk_whir_config;
+/* WhirConfig::new as provekit calls it (provekit/r1cs-compiler/src/whir_r1cs.rs:38-53): ConjectureList soundness,
+ * security_level bits, the given folding factor / starting rate / batch size, and pow_bits < 0 meaning
+ * default_max_pow(n_vars, starting_log_inv_rate).  WhirConfig::new itself lives in the external `whir` crate (rev 3e7f8c2,
+ * not in the reference tree): this is its published derivation restated -- round count (n/k - 1 rounds, n mod k final
+ * variables), queries = ceil((security - pow)/log_inv_rate) against the OLD rate, 1 OOD sample while
+ * 2*list_size + n < field_bits, pow_bits[r] = max(0, security - min(queries*log_inv_rate, combination error)) -- and it is
+ * pinned by the reference's proof fixture: for n = 21 it yields queries 109/28/16/11, final 9, one OOD sample per round,
+ * and a nonce in every round, exactly the shape SURVEY Appendix A decodes (tests/test_host_only.py).  Host only. */
+int pk_whir_config_derive(unsigned n_vars, unsigned batch_size, unsigned folding_factor, unsigned starting_log_inv_rate,
+                          unsigned security_level, int pow_bits, pk_whir_config *out);
 int pk_scheme_create(pk_ctx *ctx, const pk_r1cs *r1cs, size_t num_constraints, size_t num_witnesses, unsigned m, unsigned m_0,
                      const pk_whir_config *whir_witness, const pk_whir_config *whir_for_hiding_spartan, pk_scheme **out);
 int pk_scheme_destroy(pk_ctx *ctx, pk_scheme *scheme);
-int pk_prove(pk_ctx *ctx, pk_scheme *scheme, const uint64_t *d_witness, size_t n_witness, uint64_t rng_seed,
+int pk_prove(pk_ctx *ctx, pk_scheme *scheme, const uint64_t *d_witness, size_t n_witness, const uint8_t *rng_seed32,
              uint8_t *transcript_out, size_t cap, size_t *len);
 /* the spongefish-style domain separator the transcript IV is derived from (labels are this library's) */
 int pk_scheme_domain_separator(const pk_scheme *scheme, char *buf, size_t cap, size_t *len);
@@ -309,6 +325,11 @@ int pk_scheme_domain_separator(const pk_scheme *scheme, char *buf, size_t cap, s
 int pk_selftest_keccak_tag(const uint8_t *data, size_t len, uint8_t tag[32]);
 int pk_selftest_permute(uint64_t l[4], uint64_t r[4]);
 int pk_selftest_arith(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
+/* the proof RNG: one ChaCha20 block (host; RFC 8439 state layout, words 12-13 = counter, 14-15 = nonce) and the device
+ * draw of n uniform field elements for (seed32, stream) -- element i = first candidate < p of blocks (counter i, nonce
+ * {stream, attempt}), two 254-bit candidates per block */
+int pk_selftest_chacha20(const uint8_t key[32], uint64_t counter, uint32_t n0, uint32_t n1, uint8_t out[64]);
+int pk_selftest_random_fe(pk_ctx *ctx, const uint8_t seed32[32], uint32_t stream, uint64_t *d_out, size_t n);
 /* the same ops run by a kernel on device buffers (device-vs-host codegen diff in the GPU suite) */
 int pk_selftest_arith_device(pk_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n);
 /* measurement aid (SURVEY 8d "measured_peak_modmul_per_s"): rate of register-resident 9x29-bit Montgomery squarings,

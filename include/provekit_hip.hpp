@@ -134,29 +134,38 @@ struct WhirConfig {
     double final_pow_bits = 0.0;
     unsigned commitment_ood_samples = 1;
 
-    // round count as the proof fixture and the Go verifier pin it: n/4 - 1 main rounds (whir.go:24-29); the STIR query
-    // counts follow the rate of each round's code as the fixture shows them (2^-1: 109, 2^-4: 28, 2^-7: 16, 2^-10: 11,
-    // 2^-13: 9) for the witness and the blinding WHIR alike; pow_bits is a stated assumption
-    static WhirConfig for_size(unsigned n_vars, double pow = 16.0) {
-        static const unsigned q[] = {109, 28, 16, 11, 9, 8, 8, 8};
+    double final_folding_pow_bits = 0.0;
+
+    // new_whir_config_for_size(num_variables, batch_size) (provekit/r1cs-compiler/src/whir_r1cs.rs:38-53): WhirConfig::new
+    // with security 128, ConjectureList, fold 4, rate 1/2, pow_bits = default_max_pow(n, 1), through the library's
+    // restatement of whir's derivation (pk_whir_config_derive).  test_pow >= 0 (TESTS ONLY) flattens every grinding
+    // difficulty to a cheaper value.
+    static WhirConfig for_size(unsigned n_vars, double test_pow = -1.0, unsigned batch = 2) {
+        pk_whir_config s{};
+        if (int rc = pk_whir_config_derive(n_vars, batch, 4, 1, 128, -1, &s)) throw Error(rc, "pk_whir_config_derive failed");
         WhirConfig c;
-        c.n_vars = n_vars;
-        const unsigned rounds = n_vars / 4 ? n_vars / 4 - 1 : 0;
-        for (unsigned r = 0; r < rounds && r < 7; r++) {
-            c.num_queries.push_back(q[r]);
-            c.ood_samples.push_back(1);
-            c.pow_bits.push_back(pow);
+        c.n_vars = s.n_vars;
+        c.batch_size = s.batch_size;
+        c.folding_factor = s.folding_factor;
+        c.starting_log_inv_rate = s.starting_log_inv_rate;
+        for (unsigned r = 0; r < s.n_rounds; r++) {
+            c.num_queries.push_back(s.num_queries[r]);
+            c.ood_samples.push_back(s.ood_samples[r]);
+            c.pow_bits.push_back(test_pow >= 0.0 ? test_pow : s.pow_bits[r]);
         }
-        c.final_queries = q[rounds < 7 ? rounds : 7];
-        c.final_pow_bits = pow;
+        c.final_queries = s.final_queries;
+        c.final_pow_bits = test_pow >= 0.0 ? test_pow : s.final_pow_bits;
+        c.commitment_ood_samples = s.commitment_ood_samples;
+        c.final_folding_pow_bits = s.final_folding_pow_bits;
         return c;
     }
     // new_whir_config_for_size(next_power_of_two(4 m_0) + 1, 2) (r1cs-compiler/src/whir_r1cs.rs:31-34)
-    static WhirConfig for_hiding_spartan(unsigned m_0, double pow = 16.0) {
+    static WhirConfig for_hiding_spartan(unsigned m_0, double test_pow = -1.0) {
         unsigned nb = 0;
         while ((1u << nb) < 4 * m_0) nb++;
-        return for_size(nb + 1, pow);
+        return for_size(nb + 1, test_pow);
     }
+
     pk_whir_config to_c() const {
         if (num_queries.size() > PK_MAX_WHIR_ROUNDS || ood_samples.size() != num_queries.size() || pow_bits.size() != num_queries.size())
             throw Error(PK_ERR_BAD_ARG, "WhirConfig: per-round vectors disagree");
@@ -174,6 +183,7 @@ struct WhirConfig {
         s.final_queries = final_queries;
         s.final_pow_bits = final_pow_bits;
         s.commitment_ood_samples = commitment_ood_samples;
+        s.final_folding_pow_bits = final_folding_pow_bits;
         return s;
     }
 };
@@ -202,20 +212,28 @@ class WhirR1CSScheme {
 
     // WhirR1CSProver::prove(&self, &R1CS, Vec<FieldElement>) -> Result<WhirR1CSProof>: the witness moves to the device and
     // the proof string comes back; "Unexpected witness length for R1CS instance" is thrown for a wrong length.
-    WhirR1CSProof prove(const std::vector<FieldElement>& witness, uint64_t rng_seed) const {
-        DeviceVec d(*c_, witness);
-        return prove(d, rng_seed);
+    // Randomness: like the reference (thread_rng) every proof draws fresh masks from the OS CSPRNG.  The overloads taking a
+    // TestSeed inject the 256-bit key instead: a test hook for reproducible transcripts only.
+    using TestSeed = std::array<uint8_t, 32>;
+    static TestSeed test_seed(uint64_t v) {
+        TestSeed s{};
+        for (int i = 0; i < 8; i++) s[i] = (uint8_t)(v >> (8 * i));
+        return s;
     }
-    WhirR1CSProof prove(const DeviceVec& d_witness, uint64_t rng_seed) const {
+    WhirR1CSProof prove(const std::vector<FieldElement>& witness, const TestSeed* seed = nullptr) const {
+        DeviceVec d(*c_, witness);
+        return prove(d, seed);
+    }
+    WhirR1CSProof prove(const DeviceVec& d_witness, const TestSeed* seed = nullptr) const {
         WhirR1CSProof p;
         p.transcript.resize((size_t)4 << 20);  // proofs of this scheme are a few hundred KiB (268,756 B at the poseidon size)
-        p.transcript.resize(prove_into(d_witness, rng_seed, p.transcript));
+        p.transcript.resize(prove_into(d_witness, seed, p.transcript));
         return p;
     }
     // proves into a caller buffer sized once (no size query): the steady-state form
-    size_t prove_into(const DeviceVec& d_witness, uint64_t rng_seed, std::vector<uint8_t>& buf) const {
+    size_t prove_into(const DeviceVec& d_witness, const TestSeed* seed, std::vector<uint8_t>& buf) const {
         size_t len = 0;
-        c_->check(pk_prove(c_->get(), h_, d_witness.data(), d_witness.size(), rng_seed, buf.data(), buf.size(), &len));
+        c_->check(pk_prove(c_->get(), h_, d_witness.data(), d_witness.size(), seed ? seed->data() : nullptr, buf.data(), buf.size(), &len));
         return len;
     }
     std::string domain_separator() const {

@@ -239,6 +239,7 @@ class WhirConfig:
     final_queries: int = 0
     final_pow_bits: float = 0.0
     commitment_ood_samples: int = 1
+    final_folding_pow_bits: float = 0.0
 
 
 def check_pow(A: Arthur, bits: float):  # utilities.go:84-101; pow.rs:24-26
@@ -331,6 +332,7 @@ def whir_verify(A: Arthur, com, cfg: WhirConfig, claimed_sums):
         ensure(pr.multivar_poly(l, rs) == pr.eval_univariate(final_coeffs, pow(exp_gen, i, P)), "final polynomial mismatch at a STIR point")
     rs_final, last = sumcheck(final_vars, last)
     total += rs_final
+    check_pow(A, cfg.final_folding_pow_bits)  # whir.go:196-201
     deferred = []
     if claimed_sums:
         rd = Rd(A.hint())

@@ -107,13 +107,16 @@ SIGNATURES = {
     "pk_tree_destroy": (C.c_int, [vp, vp]),
     "pk_gather_leaves": (C.c_int, [vp, vp, sz, sz, C.c_int, vp, sz, C.c_int, vp]),
     "pk_multipath_serialize": (C.c_int, [vp, sz, sz, vp, vp, vp, sz, C.POINTER(sz)]),
+    "pk_whir_config_derive": (C.c_int, [C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_int, vp]),
     "pk_scheme_create": (C.c_int, [vp, vp, sz, sz, C.c_uint, C.c_uint, vp, vp, C.POINTER(vp)]),
     "pk_scheme_destroy": (C.c_int, [vp, vp]),
-    "pk_prove": (C.c_int, [vp, vp, vp, sz, C.c_uint64, vp, sz, C.POINTER(sz)]),
+    "pk_prove": (C.c_int, [vp, vp, vp, sz, vp, vp, sz, C.POINTER(sz)]),
     "pk_scheme_domain_separator": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
     "pk_selftest_keccak_tag": (C.c_int, [vp, sz, vp]),
     "pk_selftest_permute": (C.c_int, [vp, vp]),
     "pk_selftest_arith": (C.c_int, [C.c_int, vp, vp, vp, sz]),
+    "pk_selftest_chacha20": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
+    "pk_selftest_random_fe": (C.c_int, [vp, vp, C.c_uint32, vp, sz]),
     "pk_selftest_arith_device": (C.c_int, [vp, C.c_int, vp, vp, vp, sz]),
     "pk_selftest_modmul_rate": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),
 }
@@ -122,7 +125,8 @@ SIGNATURES = {
 class WhirConfigStruct(C.Structure):
     _fields_ = [("n_vars", C.c_uint), ("batch_size", C.c_uint), ("folding_factor", C.c_uint), ("starting_log_inv_rate", C.c_uint),
                 ("n_rounds", C.c_uint), ("num_queries", C.c_uint * 16), ("ood_samples", C.c_uint * 16), ("pow_bits", C.c_double * 16),
-                ("final_queries", C.c_uint), ("final_pow_bits", C.c_double), ("commitment_ood_samples", C.c_uint)]
+                ("final_queries", C.c_uint), ("final_pow_bits", C.c_double), ("commitment_ood_samples", C.c_uint),
+                ("final_folding_pow_bits", C.c_double)]
 
 
 class SparseMatrixStruct(C.Structure):

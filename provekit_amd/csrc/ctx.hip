@@ -7,7 +7,7 @@ using namespace pk;
 
 extern "C" {
 
-int pk_abi_version(void) { return 1; }
+int pk_abi_version(void) { return 2; }
 
 int pk_device_count(int* n) {
     if (!n) return PK_ERR_BAD_ARG;

@@ -10,7 +10,11 @@
 //    |                                          small WHIR proof of the blinding polynomial
 //    +- external rows, weighted sums, claimed_evaluations hint (whir_r1cs.rs:81-91)
 //    +- whir_prove (whir::Prover::prove; structure pinned by recursive-verifier/app/circuit/whir.go:51-220)
+#include <sys/random.h>
+
 #include <algorithm>
+#include <cerrno>
+#include <cmath>
 #include <chrono>
 #include <cstdlib>
 #include <string>
@@ -42,40 +46,70 @@ struct pk_scheme {
 
 namespace {
 
-// ------------------------------------------------------------------ device RNG (the reference uses thread_rng: F4)
-__device__ __forceinline__ u64 splitmix64(u64 x) {
-    x += 0x9e3779b97f4a7c15ULL;
-    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
-    x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
-    return x ^ (x >> 31);
+// ------------------------------------------------------------------ device CSPRNG
+// The reference draws the ZK mask, the random polynomial g and the Spartan blinding univariates from thread_rng, a
+// ChaCha-based CSPRNG seeded from the OS (provekit/common/src/utils/zk_utils.rs:13-22, provekit/prover/src/whir_r1cs.rs:197,
+// 212-221).  Here: one 256-bit key per proof (getrandom(2) inside pk_prove unless the caller injects a seed -- a test hook),
+// expanded on the device with the ChaCha20 block function (RFC 8439 quarter rounds, 20 rounds): element i of draw `stream`
+// takes block (counter = i, nonce = {stream, attempt}); a block yields two 254-bit candidates, accepted iff < p -- the same
+// rejection sampling ark-ff's Fp::rand does, so every element is uniform on [0, p).
+struct RngKey {
+    u32 k[8];
+};
+#define PK_QR(a, b, c, d)                    \
+    a += b; d ^= a; d = (d << 16) | (d >> 16); \
+    c += d; b ^= c; b = (b << 12) | (b >> 20); \
+    a += b; d ^= a; d = (d << 8) | (d >> 24);  \
+    c += d; b ^= c; b = (b << 7) | (b >> 25)
+__host__ __device__ __forceinline__ void chacha20_block(const RngKey& key, u64 counter, u32 n0, u32 n1, u32 (&out)[16]) {
+    u32 s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3],
+                 key.k[4],    key.k[5],    key.k[6],    key.k[7],    (u32)counter, (u32)(counter >> 32), n0, n1};
+    u32 x[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] = s[i];
+#pragma unroll 1
+    for (int r = 0; r < 10; r++) {
+        PK_QR(x[0], x[4], x[8], x[12]);
+        PK_QR(x[1], x[5], x[9], x[13]);
+        PK_QR(x[2], x[6], x[10], x[14]);
+        PK_QR(x[3], x[7], x[11], x[15]);
+        PK_QR(x[0], x[5], x[10], x[15]);
+        PK_QR(x[1], x[6], x[11], x[12]);
+        PK_QR(x[2], x[7], x[8], x[13]);
+        PK_QR(x[3], x[4], x[9], x[14]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
 }
-// uniform field elements by rejection (accept probability p / 2^254 = 0.76); any value < p is a valid Montgomery image
-__global__ __launch_bounds__(256) void random_fe_kernel(fe* __restrict__ out, size_t n, u64 seed) {
+#undef PK_QR
+// uniform field elements by rejection (accept probability p / 2^254 = 0.76 per candidate); any value < p is a valid Montgomery image
+__global__ __launch_bounds__(256) void random_fe_kernel(fe* __restrict__ out, size_t n, RngKey key, u32 stream) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         fe x;
-        for (u64 attempt = 0;; attempt++) {
-            u64 base = splitmix64(seed ^ splitmix64(i * 0x100000001b3ULL + attempt));
+        bool done = false;
+        for (u32 attempt = 0; !done; attempt++) {
+            u32 blk[16];
+            chacha20_block(key, (u64)i, stream, attempt, blk);
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
-                u64 r = splitmix64(base + w);
-                x.v[2 * w] = (u32)r;
-                x.v[2 * w + 1] = (u32)(r >> 32);
-            }
-            x.v[7] &= 0x3fffffffu;  // < 2^254
-            fe d;
-            u32 borrow = 0;
+            for (int half = 0; half < 2 && !done; half++) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                u64 t = (u64)x.v[k] - kPlimb(k) - borrow;
-                d.v[k] = (u32)t;
-                borrow = (u32)(t >> 32) & 1u;
+                for (int w = 0; w < 8; w++) x.v[w] = blk[8 * half + w];
+                x.v[7] &= 0x3fffffffu;  // < 2^254
+                u32 borrow = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    u64 t = (u64)x.v[k] - kPlimb(k) - borrow;
+                    borrow = (u32)(t >> 32) & 1u;
+                }
+                done = borrow != 0;  // x < p
             }
-            if (borrow) break;  // x < p
         }
         fe_store(out + i, x);
     }
 }
+// draws of one proof (the `stream` word of the nonce)
+enum { RNG_MASK = 1, RNG_G = 2, RNG_BLIND = 3, RNG_MASK_B = 4, RNG_G_B = 5 };
 
 struct Arena {
     char* base;
@@ -434,6 +468,9 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
         std::vector<uint64_t> idx = stir_queries(T, domain_size, k, cfg.final_queries);
         CK(emit_opening_hints(ctx, T, prev_leaves, prev_nodes, prev_rows, prev_width, idx));
         CK(sumcheck_rounds(nv, rs));
+        prc = PK_OK;
+        pow_round(ctx, T, cfg.final_folding_pow_bits, &prc);  // whir.go:196-201
+        CK(prc);
     }
     // deferred_weight_evaluations hint (common.go:63-73): each linear weight's MLE at the full folding point.
     // Round t folds index bit t (LSB first), so the point in eval_eq's MSB-first order is reverse(all_r).
@@ -463,8 +500,8 @@ struct BatchCommit {
     fe* f_evals = nullptr;  // masked polynomial, evaluation form (2^m)
     fe* g_evals = nullptr;  // random polynomial, evaluation form (2^m)
 };
-int batch_commit(pk_ctx* ctx, Arena& A, unsigned m, const pk_whir_config& cfg, const fe* d_evals, size_t n_evals, u64 seed, Transcript& T,
-                 BatchCommit& out) {
+int batch_commit(pk_ctx* ctx, Arena& A, unsigned m, const pk_whir_config& cfg, const fe* d_evals, size_t n_evals, const RngKey& key,
+                 u32 stream_mask, u32 stream_g, Transcript& T, BatchCommit& out) {
     const size_t half = (size_t)1 << (m - 1), N = 2 * half;
     ALLOC(f, N);
     ALLOC(g, N);
@@ -473,8 +510,8 @@ int batch_commit(pk_ctx* ctx, Arena& A, unsigned m, const pk_whir_config& cfg, c
     // f = [witness (zero padded) || mask]   (zk_utils.rs:3-22)
     CK(pk_memset_zero(ctx, f, 32 * half));
     CK(pk_memcpy_d2d(ctx, f, d_evals, 32 * n_evals));
-    random_fe_kernel<<<grid_for(ctx, half, 256), 256, 0, ctx->stream>>>(f + half, half, seed);
-    random_fe_kernel<<<grid_for(ctx, N, 256), 256, 0, ctx->stream>>>(g, N, seed ^ 0xa5a5a5a5a5a5a5a5ULL);
+    random_fe_kernel<<<grid_for(ctx, half, 256), 256, 0, ctx->stream>>>(f + half, half, key, stream_mask);
+    random_fe_kernel<<<grid_for(ctx, N, 256), 256, 0, ctx->stream>>>(g, N, key, stream_g);
     PK_LAUNCH_CHECK(ctx);
     // f, g hold the evaluation forms (kept for the weighted sums); the coefficient forms go to fc, gc
     CK(pk_to_coeffs_into(ctx, U(f), U(fe_), m));
@@ -526,7 +563,7 @@ int pk_scheme_create(pk_ctx* ctx, const pk_r1cs* r1cs, size_t num_constraints, s
     PK_ENTER(ctx);
     *out = nullptr;
     PK_REQUIRE(ctx, r1cs && whir_witness && whir_for_hiding_spartan, "null pointer");
-    PK_REQUIRE(ctx, m >= 1 && m <= 27 && m_0 <= 27, "scheme size out of range");
+    PK_REQUIRE(ctx, m >= 1 && m <= 27 && m_0 >= 1 && m_0 <= 27, "scheme size out of range (1 <= m, m_0 <= 27)");
     // ensure!(...) of provekit/prover/src/whir_r1cs.rs:43-54
     PK_REQUIRE(ctx, num_witnesses <= ((size_t)1 << (m - 1)), "R1CS witness length exceeds scheme capacity");
     PK_REQUIRE(ctx, num_constraints <= ((size_t)1 << m_0), "R1CS constraints exceed scheme capacity");
@@ -535,6 +572,11 @@ int pk_scheme_create(pk_ctx* ctx, const pk_r1cs* r1cs, size_t num_constraints, s
         PK_REQUIRE(ctx, c->folding_factor >= 1 && c->folding_factor <= 8 && c->n_rounds <= PK_MAX_WHIR_ROUNDS, "bad WHIR config");
         PK_REQUIRE(ctx, c->n_vars >= c->folding_factor * (c->n_rounds + 1), "WHIR rounds exceed the number of variables");
         PK_REQUIRE(ctx, c->commitment_ood_samples <= 4, "too many OOD samples");
+        PK_REQUIRE(ctx, c->batch_size >= 1 && c->batch_size <= 4, "batch size out of range");
+        // the evaluation domain must exist in BN254-Fr (two-adicity 28) and the codeword must fit pk_rs_encode's bound
+        PK_REQUIRE(ctx, c->starting_log_inv_rate >= 1 && c->n_vars + c->starting_log_inv_rate <= 28, "n_vars + starting_log_inv_rate exceeds 28");
+        PK_REQUIRE(ctx, c->n_vars + c->starting_log_inv_rate - c->folding_factor <= 27, "codeword has more than 2^27 rows");
+        for (unsigned r = 0; r < c->n_rounds; r++) PK_REQUIRE(ctx, c->ood_samples[r] <= 4, "too many OOD samples");
     }
     unsigned nb = 0;
     while (((size_t)1 << nb) < 4 * (size_t)m_0) nb++;
@@ -549,8 +591,18 @@ int pk_scheme_create(pk_ctx* ctx, const pk_r1cs* r1cs, size_t num_constraints, s
     s->whir_witness = *whir_witness;
     s->whir_hiding = *whir_for_hiding_spartan;
     s->domain_separator = domain_separator_for(*s);
-    // arena: f,g + eval copies (4N), commit (4.25N), a,b,c,eq (2N), rows+weights (4.5N+), whir working set (~5N), rounds (~1.2N)
-    s->arena_bytes = (size_t)26 * 32 * ((size_t)1 << m) + ((size_t)64 << 20);
+    // arena = the sum of pk_prove's allocations (nothing is freed inside a proof).  With N = 2^m, R = 2^starting_log_inv_rate,
+    // F = 2^folding_factor: f, g in both forms 4N; initial codeword batch*R*N and its tree 2R/F N; working polynomial and the
+    // sumcheck ping-pong 4N; round codewords (domain halves each round) < R N, their trees < 2R/F N, folded polynomials
+    // < 2/F N; deferred eq table N; a, b, c, eq and the second eq table 5*2^m_0; external rows 3*num_witnesses.  The small
+    // blinding scheme (2^(nb+1) <= 2^9 elements) and alignment are covered by the constant.
+    {
+        const pk_whir_config& w = s->whir_witness;
+        const double N = (double)((size_t)1 << m), R = (double)((size_t)1 << w.starting_log_inv_rate), F = (double)((size_t)1 << w.folding_factor);
+        const double units = 4.0 + w.batch_size * R + 2.0 * R / F + 4.0 + R + 2.0 * R / F + 2.0 / F + 1.0;
+        const double fes = units * N + 5.0 * (double)((size_t)1 << m_0) + 3.0 * (double)num_witnesses;
+        s->arena_bytes = (size_t)(1.05 * 32.0 * fes) + ((size_t)64 << 20);
+    }
     if (hipMalloc((void**)&s->arena, s->arena_bytes) != hipSuccess) {
         delete s;
         return set_err(ctx, PK_ERR_OOM, "hipMalloc of the %zu MiB prover arena failed", s->arena_bytes >> 20);
@@ -559,11 +611,26 @@ int pk_scheme_create(pk_ctx* ctx, const pk_r1cs* r1cs, size_t num_constraints, s
     return PK_OK;
 }
 
-int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witness, uint64_t rng_seed, uint8_t* transcript_out,
+int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witness, const uint8_t* rng_seed32, uint8_t* transcript_out,
              size_t cap, size_t* len) {
     PK_ENTER(ctx);
     PK_REQUIRE(ctx, s && d_witness && len, "null pointer");
     PK_REQUIRE(ctx, n_witness == s->num_witnesses, "Unexpected witness length for R1CS instance");  // whir_r1cs.rs:43-46
+    // 256-bit key of this proof's random draws: fresh from the OS CSPRNG (the reference's thread_rng) unless injected
+    RngKey key;
+    if (rng_seed32) {
+        memcpy(key.k, rng_seed32, 32);
+    } else {
+        size_t got = 0;
+        while (got < 32) {
+            ssize_t r = getrandom((char*)key.k + got, 32 - got, 0);
+            if (r < 0) {
+                if (errno == EINTR) continue;
+                return set_err(ctx, PK_ERR_HIP, "getrandom failed: %s", strerror(errno));
+            }
+            got += (size_t)r;
+        }
+    }
     Arena A{s->arena, s->arena_bytes};
     Transcript T(s->domain_separator);
     const bool timing = getenv("PK_PROVE_TIMING") != nullptr;
@@ -581,7 +648,7 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
 
     // --- commit to the masked witness polynomial (whir_r1cs.rs:57-69)
     BatchCommit W;
-    CK(batch_commit(ctx, A, m, s->whir_witness, (const fe*)d_witness, n_witness, rng_seed * 0x9e3779b97f4a7c15ULL + 1, T, W));
+    CK(batch_commit(ctx, A, m, s->whir_witness, (const fe*)d_witness, n_witness, key, RNG_MASK, RNG_G, T, W));
 
     lap("witness commit");
     // --- run_zk_sumcheck_prover (whir_r1cs.rs:228-369)
@@ -600,12 +667,12 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     const size_t NB = (size_t)1 << nb;
     ALLOC(d_blind, NB);
     CK(pk_memset_zero(ctx, d_blind, 32 * NB));
-    random_fe_kernel<<<1, 256, 0, ctx->stream>>>(d_blind, 4 * (size_t)m_0, rng_seed * 0x9e3779b97f4a7c15ULL + 7);
+    random_fe_kernel<<<1, 256, 0, ctx->stream>>>(d_blind, 4 * (size_t)m_0, key, RNG_BLIND);
     PK_LAUNCH_CHECK(ctx);
     std::vector<fe> g_univ(4 * (size_t)m_0);
     CK(pk_memcpy_d2h(ctx, g_univ.data(), d_blind, 32 * g_univ.size()));
     BatchCommit B;
-    CK(batch_commit(ctx, A, nb + 1, s->whir_hiding, d_blind, NB, rng_seed * 0x9e3779b97f4a7c15ULL + 11, T, B));
+    CK(batch_commit(ctx, A, nb + 1, s->whir_hiding, d_blind, NB, key, RNG_MASK_B, RNG_G_B, T, B));
     lap("bounds+eq+blinding commit");
     // sum_over_hypercube (whir_r1cs.rs:172-180)
     fe sum_g;
@@ -709,6 +776,77 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     if (!transcript_out) return PK_OK;  // size query
     PK_REQUIRE(ctx, cap >= T.narg.size(), "transcript buffer too small");
     memcpy(transcript_out, T.narg.data(), T.narg.size());
+    return PK_OK;
+}
+
+// WhirConfig::new for provekit's parameters (provekit/r1cs-compiler/src/whir_r1cs.rs:38-53); see include/provekit_hip.h
+int pk_whir_config_derive(unsigned n_vars, unsigned batch_size, unsigned folding_factor, unsigned starting_log_inv_rate,
+                          unsigned security_level, int pow_bits, pk_whir_config* out) {
+    if (!out || folding_factor < 1 || folding_factor > 8 || n_vars < folding_factor || starting_log_inv_rate < 1 || batch_size < 1) return PK_ERR_BAD_ARG;
+    const unsigned k = folding_factor;
+    const double field_bits = 254.0, sec = (double)security_level;
+    // default_max_pow(num_variables, log_inv_rate) = num_variables + log_inv_rate - 3 (whir::parameters)
+    const double pow_param = pow_bits >= 0 ? (double)pow_bits : (double)(n_vars + starting_log_inv_rate) - 3.0;
+    const double protocol_sec = sec > pow_param ? sec - pow_param : 0.0;
+    // ConjectureList: log_eta = -(log_inv_rate + 1); list_size_bits = (nv + log_inv_rate) - log_eta
+    auto list_size_bits = [](unsigned nv, unsigned rate) { return (double)(nv + rate) + (double)(rate + 1); };
+    auto ood_for = [&](unsigned nv, unsigned rate) -> unsigned {
+        for (unsigned s = 1; s < 64; s++) {
+            double err = 2.0 * list_size_bits(nv, rate) + (double)nv * s;
+            if ((double)s * field_bits + 1.0 - err >= sec) return s;
+        }
+        return 64;
+    };
+    auto queries_for = [&](unsigned rate) { return (unsigned)ceil(protocol_sec / (double)rate); };
+    pk_whir_config c;
+    memset(&c, 0, sizeof c);
+    c.n_vars = n_vars;
+    c.batch_size = batch_size;
+    c.folding_factor = k;
+    c.starting_log_inv_rate = starting_log_inv_rate;
+    const unsigned final_vars = n_vars % k;
+    c.n_rounds = (n_vars - final_vars) / k - 1;
+    if (c.n_rounds > PK_MAX_WHIR_ROUNDS) return PK_ERR_BAD_ARG;
+    c.commitment_ood_samples = ood_for(n_vars, starting_log_inv_rate);
+    unsigned nv = n_vars - k, rate = starting_log_inv_rate;
+    for (unsigned r = 0; r < c.n_rounds; r++) {
+        const unsigned next_rate = rate + (k - 1);
+        c.num_queries[r] = queries_for(rate);  // queries against the OLD rate, the rest against the new one
+        c.ood_samples[r] = ood_for(nv, next_rate);
+        const double query_error = (double)c.num_queries[r] * rate;
+        const double combination_error = field_bits - (log2((double)(c.ood_samples[r] + c.num_queries[r])) + list_size_bits(nv, next_rate) + 1.0);
+        const double e = query_error < combination_error ? query_error : combination_error;
+        c.pow_bits[r] = sec > e ? sec - e : 0.0;
+        nv -= k;
+        rate = next_rate;
+    }
+    c.final_queries = queries_for(rate);
+    const double fq = (double)c.final_queries * rate;
+    c.final_pow_bits = sec > fq ? sec - fq : 0.0;
+    c.final_folding_pow_bits = sec > field_bits - 1.0 ? sec - (field_bits - 1.0) : 0.0;
+    *out = c;
+    return PK_OK;
+}
+
+// host-only: one ChaCha20 block of the proof RNG (RFC 8439 layout: words 12,13 = counter, 14,15 = nonce)
+int pk_selftest_chacha20(const uint8_t key[32], uint64_t counter, uint32_t n0, uint32_t n1, uint8_t out[64]) {
+    if (!key || !out) return PK_ERR_BAD_ARG;
+    RngKey k;
+    memcpy(k.k, key, 32);
+    u32 blk[16];
+    chacha20_block(k, counter, n0, n1, blk);
+    memcpy(out, blk, 64);
+    return PK_OK;
+}
+// the device draw itself: n uniform field elements of stream `stream` under `seed32` (what pk_prove fills the mask with)
+int pk_selftest_random_fe(pk_ctx* ctx, const uint8_t seed32[32], uint32_t stream, uint64_t* d_out, size_t n) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, seed32 && (n == 0 || d_out), "null pointer");
+    if (!n) return PK_OK;
+    RngKey k;
+    memcpy(k.k, seed32, 32);
+    random_fe_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_out, n, k, stream);
+    PK_LAUNCH_CHECK(ctx);
     return PK_OK;
 }
 

@@ -12,9 +12,7 @@ from .sparse_matrix import R1CS
 
 @dataclass
 class WhirConfig:
-    """The WhirConfig fields the prover consumes (enumerated by tooling/provekit-gnark/src/gnark_config.rs:32-57).
-    Per-round values for n=21 / n=8 are read off the reference's proof fixture; pow_bits is not
-    recoverable from it and is a stated assumption."""
+    """The WhirConfig fields the prover consumes (enumerated by tooling/provekit-gnark/src/gnark_config.rs:32-57)."""
     n_vars: int
     batch_size: int = 2
     folding_factor: int = 4
@@ -25,34 +23,45 @@ class WhirConfig:
     final_queries: int = 0
     final_pow_bits: float = 0.0
     commitment_ood_samples: int = 1
+    final_folding_pow_bits: float = 0.0
 
     @property
     def n_rounds(self):
         return len(self.num_queries)
 
     @staticmethod
-    def poseidon_witness(pow_bits: float = 16.0) -> "WhirConfig":
-        return WhirConfig(21, num_queries=[109, 28, 16, 11], ood_samples=[1, 1, 1, 1], pow_bits=[pow_bits] * 4,
-                          final_queries=9, final_pow_bits=pow_bits)
+    def derive(n_vars: int, batch_size: int = 2, security_level: int = 128, pow_bits: int | None = None, folding_factor: int = 4,
+               starting_log_inv_rate: int = 1) -> "WhirConfig":
+        """new_whir_config_for_size (provekit/r1cs-compiler/src/whir_r1cs.rs:38-53): WhirConfig::new with ConjectureList
+        soundness, security 128, fold 4, rate 1/2, pow_bits = default_max_pow(n, 1) -- through pk_whir_config_derive, the
+        library's restatement of whir's derivation (pinned by the proof fixture: n = 21 gives 109/28/16/11 queries, final 9)."""
+        st = WhirConfigStruct()
+        rc = lib.pk_whir_config_derive(n_vars, batch_size, folding_factor, starting_log_inv_rate, security_level,
+                                       -1 if pow_bits is None else int(pow_bits), C.byref(st))
+        if rc:
+            raise ValueError(f"pk_whir_config_derive({n_vars}) failed: {rc}")
+        r = st.n_rounds
+        return WhirConfig(n_vars, batch_size, folding_factor, starting_log_inv_rate, list(st.num_queries[:r]), list(st.ood_samples[:r]),
+                          list(st.pow_bits[:r]), st.final_queries, st.final_pow_bits, st.commitment_ood_samples, st.final_folding_pow_bits)
 
     @staticmethod
-    def poseidon_blinding(pow_bits: float = 16.0) -> "WhirConfig":
-        return blinding_config_for(20, pow_bits)
-
-    # STIR queries per round as the reference's proof fixture shows them: they follow the rate of the
-    # round's code -- 2^-1: 109, 2^-4: 28, 2^-7: 16, 2^-10: 11, 2^-13: 9 -- for the witness WHIR (4 rounds + final 9) and for
-    # the blinding WHIR alike (its 32-leaf tree is opened at all 32 leaves and its 16-leaf round tree at 13: what 109 and
-    # 28 uniform queries give, not 32 and 13)
-    QUERIES_BY_ROUND = [109, 28, 16, 11, 9, 8, 8, 8]
+    def poseidon_witness() -> "WhirConfig":
+        return WhirConfig.derive(21)
 
     @staticmethod
-    def for_size(n_vars: int, pow_bits: float = 16.0) -> "WhirConfig":
-        """size-class configs.  Round count as the fixture and the Go verifier pin it:
-        n_rounds = n/4 - 1 main rounds, final polynomial on n mod 4 variables (whir.go:24-29)."""
-        rounds = max(n_vars // 4 - 1, 0)
-        q = WhirConfig.QUERIES_BY_ROUND
-        return WhirConfig(n_vars, num_queries=q[:rounds], ood_samples=[1] * rounds, pow_bits=[pow_bits] * rounds, final_queries=q[rounds],
-                          final_pow_bits=pow_bits)
+    def poseidon_blinding() -> "WhirConfig":
+        return blinding_config_for(20)
+
+    @staticmethod
+    def for_size(n_vars: int, test_pow_bits: float | None = None) -> "WhirConfig":
+        """The reference's config for this size.  test_pow_bits (TESTS ONLY) overrides every grinding difficulty with a flat
+        cheaper value so that small cases and the pure-Python verifier stay fast; it weakens soundness and is never used by
+        bench.py."""
+        c = WhirConfig.derive(n_vars)
+        if test_pow_bits is not None:
+            c.pow_bits = [float(test_pow_bits)] * c.n_rounds
+            c.final_pow_bits = float(test_pow_bits)
+        return c
 
 
 def _cfg_struct(cfg: WhirConfig) -> WhirConfigStruct:
@@ -62,13 +71,14 @@ def _cfg_struct(cfg: WhirConfig) -> WhirConfigStruct:
     for i in range(cfg.n_rounds):
         s.num_queries[i], s.ood_samples[i], s.pow_bits[i] = cfg.num_queries[i], cfg.ood_samples[i], cfg.pow_bits[i]
     s.final_queries, s.final_pow_bits, s.commitment_ood_samples = cfg.final_queries, cfg.final_pow_bits, cfg.commitment_ood_samples
+    s.final_folding_pow_bits = cfg.final_folding_pow_bits
     return s
 
 
-def blinding_config_for(m_0: int, pow_bits: float = 16.0) -> WhirConfig:
+def blinding_config_for(m_0: int, test_pow_bits: float | None = None) -> WhirConfig:
     """new_whir_config_for_size(next_power_of_two(4*m_0) + 1, 2) (provekit/r1cs-compiler/src/whir_r1cs.rs:31-34)"""
     nb = max((4 * m_0 - 1).bit_length(), 0)
-    return WhirConfig.for_size(nb + 1, pow_bits)
+    return WhirConfig.for_size(nb + 1, test_pow_bits)
 
 
 class WhirR1CSScheme:
@@ -98,16 +108,27 @@ class WhirR1CSScheme:
         except Exception:
             pass
 
-    def prove(self, d_witness, seed: int = 1) -> bytes:
-        """-> WhirR1CSProof.transcript"""
-        n = C.c_size_t()
-        ptr = d_witness.ptr if isinstance(d_witness, DeviceBuffer) else d_witness
-        self.ctx._check(lib.pk_prove(self.ctx.handle, self.handle, ptr, self.r1cs.num_witnesses, seed, self._buf, len(self._buf), C.byref(n)))
-        return bytes(self._buf[: n.value])
+    @staticmethod
+    def _seed_arg(seed):
+        """None -> NULL (pk_prove draws a fresh key from the OS CSPRNG: the production path); an int or 32 bytes injects
+        the key -- a TEST HOOK for reproducible transcripts (never a fixed value in deployment: the masks would repeat)."""
+        if seed is None:
+            return None
+        if isinstance(seed, int):
+            seed = seed.to_bytes(32, "little")
+        if len(seed) != 32:
+            raise ValueError("rng seed must be 32 bytes")
+        return (C.c_uint8 * 32).from_buffer_copy(bytes(seed))
 
-    def prove_nocopy(self, d_witness, seed: int = 1) -> int:
+    def prove(self, d_witness, seed=None) -> bytes:
+        """-> WhirR1CSProof.transcript.  seed=None: fresh OS randomness per proof (as the reference's thread_rng)."""
+        n = self.prove_nocopy(d_witness, seed)
+        return bytes(self._buf[:n])
+
+    def prove_nocopy(self, d_witness, seed=None) -> int:
         """prove and return only the transcript length (bench loop: no Python-side copy)"""
         n = C.c_size_t()
         ptr = d_witness.ptr if isinstance(d_witness, DeviceBuffer) else d_witness
-        self.ctx._check(lib.pk_prove(self.ctx.handle, self.handle, ptr, self.r1cs.num_witnesses, seed, self._buf, len(self._buf), C.byref(n)))
+        self.ctx._check(lib.pk_prove(self.ctx.handle, self.handle, ptr, self.r1cs.num_witnesses, self._seed_arg(seed), self._buf, len(self._buf),
+                                     C.byref(n)))
         return n.value

@@ -20,6 +20,28 @@ class SparseMatrix:
     col_indices: np.ndarray
     values: np.ndarray
 
+    def __post_init__(self):
+        # The C ABI takes bare pointers and reads new_row_indices[0..num_rows) and col_indices/values[0..nnz): the array
+        # lengths (which C cannot see) and the u32 ranges are checked here, the contents again in pk_r1cs_create.
+        for name in ("new_row_indices", "col_indices", "values"):
+            a = np.asarray(getattr(self, name))
+            if a.ndim != 1 or (a.size and (a.min() < 0 or a.max() >= 1 << 32)):
+                raise ValueError(f"SparseMatrix.{name} must be a 1-D array of u32 values")
+            setattr(self, name, np.ascontiguousarray(a, dtype=np.uint32))
+        if self.new_row_indices.shape[0] != self.num_rows:
+            raise ValueError(f"new_row_indices has {self.new_row_indices.shape[0]} entries for {self.num_rows} rows")
+        if self.values.shape[0] != self.col_indices.shape[0]:
+            raise ValueError("values and col_indices differ in length")
+        nnz = self.col_indices.shape[0]
+        if self.num_rows and (np.any(np.diff(self.new_row_indices.astype(np.int64)) < 0) or int(self.new_row_indices[-1]) > nnz):
+            raise ValueError("new_row_indices must be non-decreasing offsets into the entry arrays")
+        if nnz and int(self.col_indices.max()) >= self.num_cols:
+            raise ValueError("column index out of bounds")
+
+    @property
+    def nnz(self) -> int:
+        return int(self.col_indices.shape[0])
+
 
 class R1CS:
     """Device-resident R1CS {A, B, C} + interner (uploaded once per proof scheme)."""

@@ -50,7 +50,7 @@ def test_cpp_host_proves_and_the_proof_verifies(tmp_path):
 
     def vcfg(c):
         return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
-                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples)
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
 
     args = (ds, m, m_0, vcfg(WhirConfig.for_size(m, 8.0)), vcfg(blinding_config_for(m_0, 8.0)))
     assert V.verify(proof, *args, r1cs=(nc, nw, mats))

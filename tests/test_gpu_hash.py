@@ -18,7 +18,7 @@ def H(h):
 def test_library_is_the_hip_build(ctx):
     from provekit_amd import _lib
 
-    assert os.path.exists(_lib.LIB_PATH) and _lib.lib.pk_abi_version() == 1
+    assert os.path.exists(_lib.LIB_PATH) and _lib.lib.pk_abi_version() == 2
 
 
 def test_field_ops_vs_oracle(ctx, oracle):

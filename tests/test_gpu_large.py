@@ -1,0 +1,95 @@
+"""GPU parity at BASELINE.json's full sizes (configs[4]: the 2^26-coefficient batch-2 WHIR commit, and the 3-pass NTT shapes it
+and the m >= 23 proofs use), through the C ABI:
+  * pk_ntt at 2^21 .. 2^23 against the oracle's transform (the 3-pass tilings; test_gpu_ntt.py stops at 2^20);
+  * the 2^26 commit: opened leaves equal the DEFINITION leaf_i[b*16+j] = f_{b,j}(w^i) evaluated by the oracle on the downloaded
+    coefficients, their auth paths chain to the root under the oracle's Skyscraper, and the root equals the one the G = 8
+    sharded encode (pk_rs_encode_shard, the multi-GPU path, all shards on this GPU) interleaves to."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("log_n", [21, 22, 23])
+def test_ntt_three_pass_shapes_vs_oracle(ctx, oracle, log_n):
+    from provekit_amd.field import random_field
+    from provekit_amd.rs import ntt
+
+    x = random_field(1 << log_n, 900 + log_n).reshape(1, 1 << log_n, 4)
+    got = ntt(x, ctx=ctx)
+    assert np.array_equal(got[0], oracle.ntt(x[0], log_n))
+
+
+def test_commit_2p26_batch2_against_definition_and_sharded_root(ctx, oracle):
+    from provekit_amd._lib import PK_COL_MAJOR, lib
+
+    n_vars, batch, fold, rate = 26, 2, 4, 1
+    n = 1 << n_vars
+    log_rows = n_vars + rate - fold
+    rows, width, fw = 1 << log_rows, batch << fold, 1 << fold
+    # seeded uniform coefficients generated on the device by the library's own RNG kernel
+    polys = [ctx.alloc_fe(n) for _ in range(batch)]
+    seed = bytes(range(32))
+    for b, p in enumerate(polys):
+        ctx._check(lib.pk_selftest_random_fe(ctx.handle, seed, 100 + b, p.ptr, n))
+    ptrs = (C.c_void_p * batch)(*[p.ptr for p in polys])
+    root = (C.c_uint8 * 32)()
+    tree = C.c_void_p()
+    ctx._check(lib.pk_commit(ctx.handle, ptrs, batch, n_vars, rate, fold, root, C.byref(tree)))
+    root = np.frombuffer(bytes(root), dtype=np.uint64)
+    try:
+        idx = np.array([0, 5, 12345678 % rows, rows - 1], dtype=np.uint64)
+        k, plen = len(idx), log_rows - 1
+        leaves = np.zeros((k, width, 4), np.uint64)
+        sib = np.zeros((k, 4), np.uint64)
+        paths = np.zeros((k, plen, 4), np.uint64)
+        ctx._check(lib.pk_tree_open(ctx.handle, tree, idx.ctypes.data, k, 0, leaves.ctypes.data, sib.ctypes.data, paths.ctypes.data))
+        # (1) the definition: leaf_i[b*16 + j] = sum_t c_b[16 t + j] w^(i t), w of order `rows`  
+        w = oracle.from_mont(oracle.root_of_unity(log_rows).reshape(1, 4))
+        w_int = oracle.limbs_to_ints(w)[0]
+        host = [ctx.download_fe(p, n) for p in polys]
+        for q in (1, 2):  # two leaves x 32 columns x 2^22-term Horner evaluations in the oracle
+            pt = oracle.to_mont(oracle.ints_to_limbs([pow(w_int, int(idx[q]), oracle.P)]))[0]
+            for b in range(batch):
+                for j in range(fw):
+                    want = oracle.eval_univariate(np.ascontiguousarray(host[b][j::fw]), pt)
+                    assert np.array_equal(leaves[q, b * fw + j], want), (q, b, j)
+        # leaf 0 is the evaluation at w^0 = 1: the plain sum of each sub-sequence
+        one = oracle.to_mont(oracle.ints_to_limbs([1]))[0]
+        for b in range(batch):
+            assert np.array_equal(leaves[0, b * fw + 3], oracle.eval_univariate(np.ascontiguousarray(host[b][3::fw]), one))
+        del host
+        # (2) every opened leaf chains to the root under the oracle's Skyscraper (leaf fold, then the auth path)
+        dig = oracle.leaf_hash(leaves)
+        for q in range(k):
+            h, i = dig[q], int(idx[q])
+            sibs = [sib[q]] + [paths[q, d] for d in range(plen - 1, -1, -1)]  # leaf level upward (paths are root -> leaf)
+            for s in sibs:
+                pair = np.concatenate([s, h]) if i & 1 else np.concatenate([h, s])
+                h = np.frombuffer(oracle.compress_many(pair.tobytes()), dtype=np.uint64)
+                i >>= 1
+            assert np.array_equal(h, root), q
+        # (3) the multi-GPU path: 8 leaf-index shards encoded and hashed independently, digests interleaved, inner tree on top
+        G = 8
+        loc = rows // G
+        d_loc, d_dig = ctx.alloc_fe(width * loc), ctx.alloc_fe(loc)
+        d_scr = ctx.alloc_fe(width * (rows + 2 * loc))
+        all_dig = np.zeros((rows, 4), np.uint64)
+        t_leaves = C.c_void_p()
+        ctx._check(lib.pk_tree_info(tree, None, None, C.byref(t_leaves), None))
+        for g in range(G):
+            ctx._check(lib.pk_rs_encode_shard(ctx.handle, ptrs, batch, n_vars, rate, fold, g, G, d_loc.ptr, d_scr.ptr))
+            ctx._check(lib.pk_leaf_hash(ctx.handle, d_loc.ptr, loc, width, PK_COL_MAJOR, d_dig.ptr))
+            all_dig[g::G] = ctx.download_fe(d_dig, loc)
+            # shard row t is codeword row g + G t: compare one column segment with the unsharded matrix
+            got = ctx.download_fe(d_loc.view_fe(7 * loc), 64)
+            full = ctx.download_fe(t_leaves.value + 32 * (7 * rows), 64 * G)
+            assert np.array_equal(got, full[g::G])
+        d_nodes = ctx.alloc_fe(2 * rows)
+        ctx.upload_into(d_nodes.view_fe(rows), all_dig)
+        ctx._check(lib.pk_merkle_inner(ctx.handle, d_nodes.ptr, rows))
+        assert np.array_equal(ctx.download_fe(d_nodes.view_fe(1), 1)[0], root)
+    finally:
+        lib.pk_tree_destroy(ctx.handle, tree)

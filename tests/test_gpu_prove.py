@@ -68,7 +68,7 @@ def run_case(ctx, oracle, m, m_0, nc, n_in, seed, pow_bits):
 
     def vcfg(c):
         return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
-                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples)
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
 
     mats = [(t[0], t[1], [coeffs[v] for v in t[2]]) for t in trips]
     args = (scheme.domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
@@ -115,7 +115,7 @@ def test_prove_rejects_wrong_witness_length(ctx, oracle):
     d = ctx.upload(oracle.to_mont(oracle.ints_to_limbs(z)))
     n = C.c_size_t()
     with pytest.raises(ProveKitHipError):  # "Unexpected witness length for R1CS instance" (whir_r1cs.rs:43-46)
-        ctx._check(lib.pk_prove(ctx.handle, scheme.handle, d.ptr, nw - 1, 1, scheme._buf, len(scheme._buf), C.byref(n)))
+        ctx._check(lib.pk_prove(ctx.handle, scheme.handle, d.ptr, nw - 1, None, scheme._buf, len(scheme._buf), C.byref(n)))
     with pytest.raises(ProveKitHipError):  # scheme capacity (whir_r1cs.rs:47-54)
         WhirR1CSScheme(ctx, r1cs, 5, 5, WhirConfig.for_size(5, 0.0), blinding_config_for(5, 0.0))
 
@@ -161,19 +161,20 @@ def test_prove_verify_midsize(ctx, oracle):
     run_case(ctx, oracle, m=17, m_0=16, nc=60000, n_in=5000, seed=17, pow_bits=10.0)
 
 
-def test_prove_verify_bench_size(ctx, oracle):
-    """The bench's own statement size and WHIR schedule (m = 21, m_0 = 20, queries 109/28/16/11, final 9) on a SATISFIABLE
-    instance: the proof must pass every check of the independent verifier (transcript, 2^18-leaf Merkle openings, both
-    sumchecks, folds, PoW); the O(nnz) matrix evaluation of the deferred weights is left to the smaller cases above."""
+def prove_verify_size_class(ctx, oracle, m, check_layout=False):
+    """A SATISFIABLE instance of the size class (m, m_0 = m - 1) under the reference's own WHIR schedule
+    (WhirConfig.derive: queries, OOD samples and grinding difficulties of new_whir_config_for_size): the proof must pass every
+    check of the independent verifier (transcript, Merkle openings of the 2^(m-3)-leaf tree, both sumchecks, folds, PoW); the
+    O(nnz) matrix evaluation of the deferred weights is left to the smaller cases above."""
     import verifier as V
     from provekit_amd.field import random_field
     from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
     from provekit_amd.sparse_matrix import R1CS, SparseMatrix
 
-    m, m_0 = 21, 20
-    nc, n_in = 1 << 19, (1 << 19) - 8
+    m_0 = m - 1
+    nc, n_in = 1 << (m - 2), (1 << (m - 2)) - 8
     nw = 1 + n_in + nc
-    rng = np.random.default_rng(21)
+    rng = np.random.default_rng(m)
     coeffs = [1, 2, 3, 5, oracle.P - 1, 7, oracle.P - 2, 11]
     interner = oracle.to_mont(oracle.ints_to_limbs(coeffs))
     one = oracle.to_mont(oracle.ints_to_limbs([1]))
@@ -188,16 +189,38 @@ def test_prove_verify_bench_size(ctx, oracle):
     r1cs = R1CS(ctx, *(SparseMatrix(nc, nw, *t) for t in mats), interner)
     d_z = ctx.upload(z)
     r1cs.test_witness_satisfaction(d_z)
-    cfg_w, cfg_b = WhirConfig.poseidon_witness(), blinding_config_for(m_0)
+    cfg_w, cfg_b = WhirConfig.derive(m), blinding_config_for(m_0)
     scheme = WhirR1CSScheme(ctx, r1cs, m, m_0, cfg_w, cfg_b)
     proof = scheme.prove(d_z, seed=1)
+    assert scheme.prove(d_z, seed=1) == proof
 
     def vcfg(c):
         return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
-                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples)
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
 
     args = (scheme.domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
     assert V.verify(proof, *args)
+    fresh = scheme.prove(d_z)  # production randomness (OS CSPRNG): another transcript, equally valid
+    assert fresh != proof and V.verify(fresh, *args)
+    bad = bytearray(proof)
+    bad[len(bad) // 2] ^= 1
+    with pytest.raises((V.VerifyError, Exception)):
+        V.verify(bytes(bad), *args)
+    # an unsatisfying witness of the right length must not verify
+    z_bad = z.copy()
+    z_bad[nw - 1, 0] ^= np.uint64(1)
+    d_bad = ctx.upload(z_bad)
+    with pytest.raises((V.VerifyError, Exception)):
+        assert V.verify(scheme.prove(d_bad, seed=1), *args)
+    scheme.close()
+    r1cs.close()
+    return proof
+
+
+def test_prove_verify_bench_size(ctx, oracle):
+    """BASELINE configs[1]: the bench's own statement size and WHIR schedule (m = 21, m_0 = 20, queries 109/28/16/11, final 9,
+    pow_bits 19/16/16/18, final 11)."""
+    proof = prove_verify_size_class(ctx, oracle, 21)
     # same wire layout as the reference's proof of this size class (SURVEY Appendix A, decoded from poseidon-1000.np):
     # 3304 bytes of scalars -- root, 2 OOD answers, blinding root, 2 OOD answers, sum G, 20 x 4 sumcheck coefficients,
     # 2 polynomial sums, 4 x 3 sumcheck evaluations, round root, OOD answer, 8-byte nonce -- then the first hint,
@@ -209,12 +232,16 @@ def test_prove_verify_bench_size(ctx, oracle):
     assert 1 <= k <= 32 and ln == 8 + k * (8 + 32 * 32)
     assert all(struct.unpack_from("<Q", proof, 3316 + q * (8 + 1024))[0] == 32 for q in range(k))
     assert 260_000 < len(proof) < 277_000  # the reference's proof of this shape is 268,756 bytes (query de-duplication varies)
-    bad = bytearray(proof)
-    bad[len(bad) // 2] ^= 1
-    with pytest.raises((V.VerifyError, Exception)):
-        V.verify(bytes(bad), *args)
-    scheme.close()
-    r1cs.close()
+
+
+def test_prove_verify_sha256_size_class(ctx, oracle):
+    """BASELINE configs[2] (noir-native-sha256 is a size class): m = 23, m_0 = 22, 2^20-leaf initial tree, 3-pass NTTs"""
+    prove_verify_size_class(ctx, oracle, 23)
+
+
+def test_prove_verify_p256_size_class(ctx, oracle):
+    """BASELINE configs[3]'s size class on one GPU: m = 25, m_0 = 24 (2^22-leaf initial tree, 2^26-point codewords)"""
+    prove_verify_size_class(ctx, oracle, 25)
 
 
 def test_concurrent_provers_are_deterministic(oracle):

@@ -41,3 +41,101 @@ def test_multipath_serialization_matches_fixture_bytes():
     assert multipath_serialize(idx, sib, paths).hex() == raw["serialized_hex"]
 
 
+
+
+def test_whir_config_derivation_matches_the_fixture_shape():
+    """pk_whir_config_derive restates WhirConfig::new for provekit's parameters (provekit/r1cs-compiler/src/whir_r1cs.rs:38-53).
+    The whir crate is not in the reference tree; what pins the derivation is the reference's proof fixture:
+    for n = 21 the prover opened 109 / 28 / 16 / 11 leaves in the four rounds and 9 in the final one, sent one OOD answer per
+    round and a PoW nonce in every round; the blinding WHIR (n = 8) has one round + final with nonces in both."""
+    from provekit_amd.scheme import WhirConfig, blinding_config_for
+
+    c = WhirConfig.derive(21)
+    assert c.num_queries == [109, 28, 16, 11] and c.final_queries == 9
+    assert c.ood_samples == [1, 1, 1, 1] and c.commitment_ood_samples == 1
+    # pow_bits = 128 - queries * log_inv_rate (rates 1, 4, 7, 10, 13): every round grinds, as the fixture's nonces show
+    assert c.pow_bits == [19.0, 16.0, 16.0, 18.0] and c.final_pow_bits == 11.0
+    assert c.final_folding_pow_bits == 0.0  # 128 < field_bits - 1: whir.go:196-201 does not run
+    b = blinding_config_for(20)
+    assert b.n_vars == 8 and b.n_rounds == 1  # next_power_of_two(4 * 20) + 1 variables
+    # default_max_pow(8, 1) = 6 -> 122 queries into the 32-leaf tree (all 32 opened in the fixture), ceil(122/4) = 31 into
+    # the 16-leaf round tree (13 distinct in the fixture)
+    assert b.num_queries == [122] and b.final_queries == 31 and b.pow_bits == [6.0] and b.final_pow_bits == 4.0
+    # round count / final polynomial size as recursive-verifier/app/circuit/whir.go:24-29 reads them
+    for n in (4, 8, 12, 17, 23, 25, 26):
+        c = WhirConfig.derive(n)
+        assert c.n_rounds == n // 4 - 1 and n - 4 * (c.n_rounds + 1) == n % 4
+        assert all(q * r + p >= 128 - 1e-9 for q, r, p in zip(c.num_queries, range(1, 40, 3), c.pow_bits))
+
+
+def _chacha20_block_py(key: bytes, counter: int, n0: int, n1: int) -> bytes:
+    """RFC 8439 section 2.3, restated independently (state words 12, 13 = 64-bit counter, 14, 15 = nonce)"""
+    import struct
+
+    M = 0xFFFFFFFF
+    rotl = lambda v, n: ((v << n) | (v >> (32 - n))) & M
+    s = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(struct.unpack("<8I", key)) + [counter & M, counter >> 32, n0, n1]
+    x = list(s)
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & M; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & M; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & M; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & M; x[b] = rotl(x[b] ^ x[c], 7)
+
+    for _ in range(10):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return struct.pack("<16I", *[(a + b) & M for a, b in zip(x, s)])
+
+
+def random_fe_py(seed32: bytes, stream: int, i: int) -> int:
+    """element i of the proof RNG's draw `stream`: first candidate < p (two 254-bit candidates per block)"""
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    attempt = 0
+    while True:
+        blk = _chacha20_block_py(seed32, i, stream, attempt)
+        for half in range(2):
+            v = int.from_bytes(blk[32 * half : 32 * half + 32], "little") & ((1 << 254) - 1)
+            if v < P:
+                return v
+        attempt += 1
+
+
+def test_chacha20_block_rfc8439_vector():
+    """the proof RNG's block function against RFC 8439 section 2.3.2 (key 00..1f, nonce 00:00:00:09:00:00:00:4a:00:00:00:00,
+    block counter 1) and against the independent Python restatement on random inputs"""
+    import ctypes as C
+
+    from provekit_amd._lib import lib
+
+    key = bytes(range(32))
+    out = (C.c_uint8 * 64)()
+    assert lib.pk_selftest_chacha20(key, 1 | (0x09000000 << 32), 0x4A000000, 0, out) == 0
+    want = bytes.fromhex("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+                         "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+    assert bytes(out) == want
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        k = rng.bytes(32)
+        ctr, n0, n1 = int(rng.integers(0, 2**63)), int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32))
+        assert lib.pk_selftest_chacha20(k, ctr, n0, n1, out) == 0
+        assert bytes(out) == _chacha20_block_py(k, ctr, n0, n1)
+
+
+def test_sparse_matrix_rejects_malformed_arrays():
+    """R1CS upload reads new_row_indices[0..rows) and values[0..nnz) on the C side: lengths and ranges are checked first"""
+    from provekit_amd.sparse_matrix import SparseMatrix
+
+    ok = SparseMatrix(3, 4, np.array([0, 1, 2], np.uint32), np.array([0, 1, 3], np.uint32), np.array([0, 0, 1], np.uint32))
+    assert ok.nnz == 3
+    with pytest.raises(ValueError):
+        SparseMatrix(3, 4, np.array([0, 1], np.uint32), np.array([0, 1, 3], np.uint32), np.array([0, 0, 1], np.uint32))
+    with pytest.raises(ValueError):
+        SparseMatrix(3, 4, np.array([0, 1, 2], np.uint32), np.array([0, 1, 3], np.uint32), np.array([0, 0], np.uint32))
+    with pytest.raises(ValueError):
+        SparseMatrix(3, 4, np.array([0, 1, 2], np.uint32), np.array([0, 1, 4], np.uint32), np.array([0, 0, 1], np.uint32))  # column out of range
+    with pytest.raises(ValueError):
+        SparseMatrix(3, 4, np.array([0, 2, 1], np.uint32), np.array([0, 1, 3], np.uint32), np.array([0, 0, 1], np.uint32))  # offsets not sorted
+    with pytest.raises(ValueError):
+        SparseMatrix(3, 4, np.array([0, 1, 5], np.uint32), np.array([0, 1, 3], np.uint32), np.array([0, 0, 1], np.uint32))  # offset beyond nnz

@@ -28,7 +28,7 @@ def test_reference_proof_walks_in_our_read_order():
 
     def vcfg(c):
         return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
-                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples)
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
 
     cfg_w, cfg_b = vcfg(WhirConfig.for_size(m)), vcfg(blinding_config_for(m_0))
     assert cfg_b.n_vars == 8 and len(cfg_b.num_queries) == 1  # next_power_of_two(4 * 20) + 1 variables, one round + final

@@ -15,7 +15,7 @@ from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
 from provekit_amd.sparse_matrix import R1CS
 ctx = provekit_amd.Context(0)
 def vcfg(c):
-    return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits, c.final_queries, c.final_pow_bits, c.commitment_ood_samples)
+    return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits, c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
 t0 = time.time(); n_ok = 0
 for case, (m, m_0, nc, n_in, pb) in enumerate([(9, 7, 100, 60, 5.0), (10, 8, 200, 100, 7.3), (12, 9, 500, 700, 3.0), (13, 11, 2000, 1000, 9.9), (8, 6, 60, 40, 0.0), (11, 10, 1000, 20, 12.0)]):
     nw, z, coeffs, trips = satisfiable_r1cs(nc, n_in, 100 + case)

@@ -69,7 +69,7 @@ print("all", T, "threads agree on all", len(SEEDS), "seeds")
 
 
 def vcfg(c):
-    return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits, c.final_queries, c.final_pow_bits, c.commitment_ood_samples)
+    return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits, c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
 
 
 ds = workers[0][2].domain_separator
