@@ -287,8 +287,8 @@ def emit(line):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=192)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=12, help="timed steps; one step = one wave of --concurrency proofs per GPU")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up steps (waves)")
     ap.add_argument("--m", "--log2-size", dest="m", type=int, default=21,
                     help="log2 of the committed polynomial size (poseidon-rounds: 21).  Under torch.distributed.run spell it "
                          "--log2-size: the launcher's own parser rejects --m as an ambiguous abbreviation")
@@ -351,7 +351,7 @@ def main():
 
     m, m_0 = args.m, args.m - 1
     n_wit = (1 << (m - 1)) - 5
-    cfg_w = WhirConfig.poseidon_witness() if m == 21 else WhirConfig.for_size(m)
+    cfg_w = WhirConfig.derive(m)  # the reference's own schedule (new_whir_config_for_size): queries, OOD samples, pow_bits
     cfg_b = blinding_config_for(m_0)
     conc = max(1, args.concurrency)
     # every prover owns an arena of 26 x 32 B x 2^m (+ workspace, R1CS copy): keep the provers within half of the HBM
@@ -365,16 +365,27 @@ def main():
         workers.append((c, WhirR1CSScheme(c, r1cs_w, m, m_0, cfg_w, cfg_b), c.upload(z_host), r1cs_w, z_host))
     ctx = workers[0][0]
 
-    def run_steps(first_seed, count):
-        """`count` proofs spread over the workers (ctypes releases the GIL inside pk_prove)"""
-        def work(w, seeds):
+    def run_proofs(first_seed, count):
+        """`count` proofs through the `conc` provers of this GPU.  Work is handed out dynamically (each prover thread takes the
+        next proof when it finishes one), so the chip stays full until the last wave whatever the count; ctypes releases the
+        GIL inside pk_prove.  Seeds are injected (test hook) only to make runs comparable; production passes none."""
+        import itertools
+
+        nxt = itertools.count()
+        lock = threading.Lock()
+
+        def work(w):
             c, prover, d_z, _, z_host = workers[w]
-            for s in seeds:
+            while True:
+                with lock:
+                    i = next(nxt)
+                if i >= count:
+                    return
                 if args.h2d:
                     c.upload_into(d_z.ptr, z_host)
-                prover.prove_nocopy(d_z, seed=s)
-        seeds = [first_seed + i for i in range(count)]
-        ths = [threading.Thread(target=work, args=(w, seeds[w::conc])) for w in range(conc)]
+                prover.prove_nocopy(d_z, seed=first_seed + i)
+
+        ths = [threading.Thread(target=work, args=(w,)) for w in range(conc)]
         for t in ths:
             t.start()
         for t in ths:
@@ -386,12 +397,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_steps(1000, max(args.warmup, conc if args.warmup else 0))
+    # one step = one wave of `conc` proofs (a batch of synthetic statements through the hot path), so any --steps the driver
+    # passes measures the steady state of a full chip rather than a ragged tail
+    run_proofs(100000, args.warmup * conc)
     ctx.profile(True)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    run_steps(1, args.steps)
+    run_proofs(1, args.steps * conc)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -426,31 +439,30 @@ def main():
         n_l, ms_l = prof.get("leaf_hash", (0, 0.0))
         avg_ms = ms_l / max(n_l, 1)
         achieved = (bytes_step / launches_step) / (avg_ms * 1e-3) / 1e9 if n_l else 0.0
-        # HBM bytes per launch from the rocprofv3 PMC passes (tools/pmc.sh; FETCH_SIZE doubled as the microarch guide
-        # prescribes for gfx950).  Counters cannot be read from inside this process, so the committed summary of the same
-        # command is used; null when it is missing or was taken on another workload size.
-        traffic = None
+        # HBM bytes per launch come from rocprofv3 PMC passes (tools/pmc.sh: separate FETCH_SIZE / WRITE_SIZE runs, FETCH doubled
+        # for gfx950 as the microarch guide prescribes); counters cannot be read from inside this process.  A committed summary is
+        # used ONLY if it was taken with this very binary (sha256 of libprovekit_hip.so recorded by the tool) on this workload
+        # size; otherwise the field is null rather than a stale number.
+        traffic, valu_busy = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_leaf_hash.json")))
-            if m == 21:
-                traffic = pmc["traffic_bytes_per_launch"]
+            import glob
+            import hashlib
+
+            lib_sha = hashlib.sha256(open(provekit_amd.LIB_PATH, "rb").read()).hexdigest()[:16]
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_leaf_hash.json"))):
+                pmc = json.load(open(fn))
+                if pmc.get("lib_sha16") == lib_sha and pmc.get("m") == m:
+                    traffic = pmc["traffic_bytes_per_launch"]
+                    valu_busy = pmc.get("valu_busy_pct_largest_launch")
         except Exception:
             pass
         iso_leaf_ms = prof_iso.get("leaf_hash", (1, 0.0))[1] / max(prof_iso.get("leaf_hash", (1, 0.0))[0], 1)
-        # hardware view of the same question (rocprofv3 --pmc VALUBusy, tools/pmc_valu.sh; committed summary of the same workload)
-        valu_busy = None
-        try:
-            pv = json.load(open(os.path.join(ROOT, "profiles", "r01e_pmc_valu.json")))
-            if m == 21:
-                valu_busy = pv["kernels"]["leaf_hash_kernel<2, 1>"][str(1 << 18)]["VALUBusy"]
-        except Exception:
-            pass
         # per-proof kernel time by stage, from the one-proof-at-a-time pass (in the timed region a prover's kernels share the
         # chip with the other provers', so their elapsed times there say little about the work)
         stage_ms = {k: round(v[1] / iso_steps, 4) for k, v in sorted(prof_iso.items(), key=lambda kv: -kv[1][1])}
         line = {
             "metric": "proofs/sec (noir-r1cs prove hot path, WHIR commit + sumcheck + folding rounds)",
-            "value": world * args.steps / dt,
+            "value": world * args.steps * conc / dt,
             "unit": "proofs/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -463,8 +475,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"poseidon-rounds size class: m={m}, m_0={m_0}, batch-2 WHIR commit + zk-sumcheck + {cfg_w.n_rounds}-round WHIR opening, "
-                            f"queries {cfg_w.num_queries}/{cfg_w.final_queries}, pow_bits {cfg_w.pow_bits[0] if cfg_w.pow_bits else 0} (assumed), Skyscraper-sponge transcript",
-                "parallelism": f"{world} GPU(s) x {conc} concurrent provers per GPU (independent proofs, no collective; "
+                            f"queries {cfg_w.num_queries}/{cfg_w.final_queries}, pow_bits {cfg_w.pow_bits}/{cfg_w.final_pow_bits} (WhirConfig::new derivation, security 128, "
+                            f"ConjectureList), blinding WHIR n={cfg_b.n_vars} queries {cfg_b.num_queries}/{cfg_b.final_queries}, Skyscraper-sponge transcript, ChaCha20 masks",
+                "proofs_per_step": conc * world,
+                "parallelism": f"one step = one wave of {conc} proofs per GPU; {world} GPU(s) x {conc} concurrent provers per GPU, work handed out "
+                               f"dynamically (independent proofs, no collective; "
                                f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')})"
                                + (", witness uploaded over PCIe before every proof (--h2d)" if args.h2d else ""),
             },

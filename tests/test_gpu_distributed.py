@@ -145,4 +145,6 @@ def test_bench_multirank_control_flow_on_one_gpu(ctx, oracle):
     ref.close()
     p = launch(["--workload", "prove", "--log2-size", "13", "--concurrency", "2", "--no-cpu-baseline"], free_port())
     assert p["n_gpus"] == 2 and p["steps"] == 2 and p["scaling"] == "weak" and p["value"] > 0
-    assert abs(p["value"] - 2 * 2 / (p["ms_per_step"] * 2 * 1e-3)) / p["value"] < 1e-6  # whole-job aggregate: ranks x steps / time
+    # whole-job aggregate: one step = one wave of `concurrency` proofs per GPU -> ranks x concurrency x steps proofs / time
+    assert p["config"]["proofs_per_step"] == 2 * 2
+    assert abs(p["value"] - 2 * 2 * 2 / (p["ms_per_step"] * 2 * 1e-3)) / p["value"] < 1e-6

@@ -61,7 +61,10 @@ def test_r1cs_rejects_bad_input(ctx):
     from provekit_amd.sparse_matrix import R1CS, SparseMatrix
 
     good = SparseMatrix(2, 2, np.array([0, 1], np.uint32), np.array([0, 1], np.uint32), np.array([0, 0], np.uint32))
-    bad_col = SparseMatrix(2, 2, np.array([0, 1], np.uint32), np.array([0, 5], np.uint32), np.array([0, 0], np.uint32))
+    with pytest.raises(ValueError):  # caught by the Python mirror before the C ABI is reached
+        SparseMatrix(2, 2, np.array([0, 1], np.uint32), np.array([0, 5], np.uint32), np.array([0, 0], np.uint32))
+    bad_col = SparseMatrix(2, 2, np.array([0, 1], np.uint32), np.array([0, 1], np.uint32), np.array([0, 0], np.uint32))
+    bad_col.col_indices = np.array([0, 5], np.uint32)  # past the Python check: pk_r1cs_create validates the contents itself
     bad_val = SparseMatrix(2, 2, np.array([0, 1], np.uint32), np.array([0, 1], np.uint32), np.array([0, 9], np.uint32))
     it = random_field(2, 1)
     with pytest.raises(ProveKitHipError):
