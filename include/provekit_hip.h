@@ -73,6 +73,36 @@ int pk_ctx_sync(pk_ctx *ctx);
  * only to replay the reference's stale proof fixture). */
 int pk_ctx_set_hash_version(pk_ctx *ctx, int version);
 
+/* ------------------------------------------------------------------ device sets: one commit sharded over the GPUs of a node
+ * SURVEY 8b/8e.  The reference is one process on one host, so there is no interface to mirror; the path needs one collective
+ * per commit (all-gather of the 32-byte leaf digests) and one per opening (the opened rows, each owned by one rank).  A context
+ * that carries a communicator makes pk_commit / pk_tree_open / pk_prove shard every large commit by leaf index: rank g of G
+ * encodes and hashes the codeword rows i = g (mod G), the digests are all-gathered (RCCL over xGMI) and the inner tree is
+ * built on every rank; every rank holds the full polynomials and produces the same transcript.
+ *   pk_ctx_create_set   one process, n GPUs: n contexts joined by ncclCommInitAll (drive them from n host threads: a
+ *                       collective blocks until every rank has entered it).  A device listed more than once gets the
+ *                       in-process transport instead of RCCL (which refuses two ranks per device).
+ *   pk_comm_unique_id / pk_comm_init_rank   one process per GPU (torch.distributed.run, MPI, ...): rank 0 makes the id,
+ *                       the launcher broadcasts its 128 bytes, every rank joins.
+ *   pk_comm_init_local  the in-process transport on existing contexts (any devices, also all on one device): copies between
+ *                       the ranks' buffers and a host barrier; what a single-GPU box can run.
+ * PK_ERR_RCCL: librccl could not be loaded (it is resolved with dlopen at first use) or one of its calls failed. */
+#define PK_MAX_RANKS 16
+#define PK_COMM_ID_BYTES 128
+#define PK_COMM_NONE 0
+#define PK_COMM_LOCAL 1
+#define PK_COMM_RCCL 2
+int pk_ctx_create_set(const int *devices, int n, pk_ctx **out /* n entries */);
+int pk_comm_unique_id(uint8_t id[PK_COMM_ID_BYTES]);
+int pk_comm_init_rank(pk_ctx *ctx, const uint8_t id[PK_COMM_ID_BYTES], int world, int rank);
+int pk_comm_init_local(pk_ctx *const *ctxs, int n);
+int pk_comm_info(const pk_ctx *ctx, int *rank, int *world, int *kind);
+int pk_comm_destroy(pk_ctx *ctx);
+/* the two collectives, on the context's stream (exposed for tests and for callers that shard their own steps):
+ * d_recv[r*bytes_per_rank ...] = rank r's d_send;  d_buf[i] = sum over ranks of d_buf[i] (wrapping u64) */
+int pk_comm_all_gather(pk_ctx *ctx, const void *d_send, void *d_recv, size_t bytes_per_rank);
+int pk_comm_all_reduce_sum_u64(pk_ctx *ctx, uint64_t *d_buf, size_t count);
+
 /* ------------------------------------------------------------------ device memory + timing */
 int pk_malloc(pk_ctx *ctx, size_t bytes, void **d_ptr);
 int pk_free(pk_ctx *ctx, void *d_ptr);

@@ -51,6 +51,14 @@ SIGNATURES = {
     "pk_ctx_set_stream": (C.c_int, [vp, vp]),
     "pk_ctx_sync": (C.c_int, [vp]),
     "pk_ctx_set_hash_version": (C.c_int, [vp, C.c_int]),
+    "pk_ctx_create_set": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]),
+    "pk_comm_unique_id": (C.c_int, [vp]),
+    "pk_comm_init_rank": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "pk_comm_init_local": (C.c_int, [C.POINTER(vp), C.c_int]),
+    "pk_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pk_comm_destroy": (C.c_int, [vp]),
+    "pk_comm_all_gather": (C.c_int, [vp, vp, vp, sz]),
+    "pk_comm_all_reduce_sum_u64": (C.c_int, [vp, vp, sz]),
     "pk_malloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
     "pk_free": (C.c_int, [vp, vp]),
     "pk_memcpy_h2d": (C.c_int, [vp, vp, vp, sz]),

@@ -1,0 +1,346 @@
+// comm.hip -- the exchange step of a commit sharded over the GPUs of a node, behind the C ABI.
+//
+// The reference is a single process on one host: there is nothing to mirror.  What the path needs is ONE
+// collective per commit -- an all-gather of the 32-byte leaf digests -- and one per opening (the opened rows, each held by
+// exactly one rank).  A pk_ctx optionally carries a communicator with two operations:
+//     all_gather(send, recv, bytes_per_rank)            recv[r*bytes .. (r+1)*bytes) = rank r's send
+//     all_reduce_sum_u64(buf, count)                    element-wise wrapping sum over ranks (used where exactly one rank
+//                                                       contributes a non-zero value, so the "sum" is a gather)
+// and three transports:
+//   RCCL   one rank per GPU over xGMI: ncclAllGather / ncclAllReduce on the context's stream, in-order with the kernels that
+//          produce / consume the buffers (no host synchronisation).  librccl is resolved at run time (dlopen + dlsym), so the
+//          library has no link-time dependency on it; a missing or failing RCCL is reported as PK_ERR_RCCL.
+//          Multi-process: pk_comm_unique_id on rank 0, broadcast the 128 bytes out of band, pk_comm_init_rank everywhere.
+//          Single process: pk_ctx_create_set(devices, n) -> n contexts joined by ncclCommInitAll, one host thread per rank.
+//   LOCAL  ranks = contexts of ONE process (any devices, the same device allowed): device-to-device copies between the ranks'
+//          buffers with a host barrier.  This is what a one-GPU box can run, so it is the transport the GPU test-suite drives
+//          the sharded prover with; RCCL refuses two ranks on one device.
+//   (world == 1: no communicator, every call degenerates to a copy.)
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <condition_variable>
+#include <mutex>
+
+#include "ctx.hpp"
+
+using namespace pk;
+
+namespace {
+
+// ------------------------------------------------------------------ RCCL, resolved at run time
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+RcclApi* rccl() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy already in the process (e.g. the one a PyTorch wheel bundles) is preferred: one RCCL per process
+        const char* names[] = {"librccl.so.1", "librccl.so"};
+        for (int pass = 0; pass < 2 && !api.handle; pass++)
+            for (const char* n : names) {
+                api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (api.handle) break;
+            }
+        if (!api.handle) {
+            api.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+            return;
+        }
+#define PK_SYM(field, name)                                                  \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.handle, name)); \
+    if (!api.field) api.error = std::string("librccl lacks ") + name
+        PK_SYM(GetUniqueId, "ncclGetUniqueId");
+        PK_SYM(CommInitRank, "ncclCommInitRank");
+        PK_SYM(CommInitAll, "ncclCommInitAll");
+        PK_SYM(CommDestroy, "ncclCommDestroy");
+        PK_SYM(AllGather, "ncclAllGather");
+        PK_SYM(AllReduce, "ncclAllReduce");
+        PK_SYM(GetErrorString, "ncclGetErrorString");
+#undef PK_SYM
+    });
+    return &api;
+}
+
+int rccl_fail(pk_ctx* ctx, const char* what, ncclResult_t r) {
+    RcclApi* a = rccl();
+    return set_err(ctx, PK_ERR_RCCL, "%s failed: %s", what, a->GetErrorString ? a->GetErrorString(r) : "rccl error");
+}
+#define PK_RCCL(ctx, expr)                                   \
+    do {                                                     \
+        ncclResult_t _r = (expr);                            \
+        if (_r != ncclSuccess) return rccl_fail(ctx, #expr, _r); \
+    } while (0)
+
+// ------------------------------------------------------------------ LOCAL transport
+struct LocalGroup {
+    int world = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long generation = 0;
+    const void* send[PK_MAX_RANKS] = {};
+    hipEvent_t ready[PK_MAX_RANKS] = {};
+    int refs = 0;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        const unsigned long long gen = generation;
+        if (++arrived == world) {
+            arrived = 0;
+            generation++;
+            cv.notify_all();
+        } else {
+            cv.wait(lk, [&] { return generation != gen; });
+        }
+    }
+};
+
+__global__ __launch_bounds__(256) void sum_ranks_u64_kernel(const unsigned long long* __restrict__ parts, unsigned long long* __restrict__ out,
+                                                            size_t count, unsigned world) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        unsigned long long s = 0;
+        for (unsigned r = 0; r < world; r++) s += parts[(size_t)r * count + i];
+        out[i] = s;
+    }
+}
+
+}  // namespace
+
+struct pk_comm {
+    int kind = PK_COMM_NONE;
+    int rank = 0, world = 1;
+    ncclComm_t nccl = nullptr;
+    LocalGroup* grp = nullptr;
+    void* d_tmp = nullptr;  // LOCAL all-reduce staging, grow-only
+    size_t tmp_bytes = 0;
+};
+
+namespace pk {
+
+int comm_rank(const pk_ctx* ctx) { return ctx->comm ? ctx->comm->rank : 0; }
+int comm_world(const pk_ctx* ctx) { return ctx->comm ? ctx->comm->world : 1; }
+
+int comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes) {
+    pk_comm* c = ctx->comm;
+    if (!c) {  // no communicator = one rank
+        if (d_send != d_recv && bytes) PK_HIP(ctx, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return PK_OK;
+    }
+    ProfScope prof(ctx, "comm_all_gather");
+    if (c->kind == PK_COMM_RCCL) {
+        PK_RCCL(ctx, rccl()->AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, ctx->stream));
+        return PK_OK;
+    }
+    LocalGroup* g = c->grp;
+    PK_HIP(ctx, hipEventRecord(g->ready[c->rank], ctx->stream));  // the send buffer is complete at this point of the stream
+    g->send[c->rank] = d_send;
+    g->barrier();
+    for (int p = 0; p < c->world; p++) {
+        PK_HIP(ctx, hipStreamWaitEvent(ctx->stream, g->ready[p], 0));
+        PK_HIP(ctx, hipMemcpyAsync((char*)d_recv + (size_t)p * bytes, g->send[p], bytes, hipMemcpyDefault, ctx->stream));
+    }
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    g->barrier();  // every rank has read every send buffer: they may be reused
+    return PK_OK;
+}
+
+int comm_all_reduce_sum_u64(pk_ctx* ctx, uint64_t* d_buf, size_t count) {
+    pk_comm* c = ctx->comm;
+    if (!c || !count) return PK_OK;
+    ProfScope prof(ctx, "comm_all_reduce");
+    if (c->kind == PK_COMM_RCCL) {
+        PK_RCCL(ctx, rccl()->AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, c->nccl, ctx->stream));
+        return PK_OK;
+    }
+    const size_t need = (size_t)c->world * count * 8;
+    if (c->tmp_bytes < need) {
+        if (c->d_tmp) {
+            PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            PK_HIP(ctx, hipFree(c->d_tmp));
+            c->d_tmp = nullptr;
+            c->tmp_bytes = 0;
+        }
+        PK_HIP(ctx, hipMalloc(&c->d_tmp, need));
+        c->tmp_bytes = need;
+    }
+    int rc = comm_all_gather(ctx, d_buf, c->d_tmp, count * 8);
+    if (rc) return rc;
+    sum_ranks_u64_kernel<<<grid_for(ctx, count, 256), 256, 0, ctx->stream>>>((const unsigned long long*)c->d_tmp, (unsigned long long*)d_buf, count,
+                                                                             (unsigned)c->world);
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+void comm_release(pk_ctx* ctx) {
+    pk_comm* c = ctx->comm;
+    if (!c) return;
+    if (c->kind == PK_COMM_RCCL && c->nccl && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->nccl);
+    if (c->kind == PK_COMM_LOCAL && c->grp) {
+        LocalGroup* g = c->grp;
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            if (g->ready[c->rank]) (void)hipEventDestroy(g->ready[c->rank]);
+            g->ready[c->rank] = nullptr;
+            last = --g->refs == 0;
+        }
+        if (last) delete g;
+    }
+    if (c->d_tmp) (void)hipFree(c->d_tmp);
+    delete c;
+    ctx->comm = nullptr;
+}
+
+}  // namespace pk
+
+extern "C" {
+
+int pk_comm_unique_id(uint8_t id[PK_COMM_ID_BYTES]) {
+    if (!id) return PK_ERR_BAD_ARG;
+    RcclApi* a = rccl();
+    if (!a->error.empty()) return PK_ERR_RCCL;
+    static_assert(PK_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId u;
+    if (a->GetUniqueId(&u) != ncclSuccess) return PK_ERR_RCCL;
+    memcpy(id, u.internal, PK_COMM_ID_BYTES);
+    return PK_OK;
+}
+
+int pk_comm_init_rank(pk_ctx* ctx, const uint8_t id[PK_COMM_ID_BYTES], int world, int rank) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, id && world >= 1 && world <= PK_MAX_RANKS && rank >= 0 && rank < world, "bad rank / world");
+    PK_REQUIRE(ctx, is_pow2((size_t)world), "the number of ranks must be a power of two (leaf-index sharding)");
+    PK_REQUIRE(ctx, !ctx->comm, "context already has a communicator");
+    RcclApi* a = rccl();
+    if (!a->error.empty()) return set_err(ctx, PK_ERR_RCCL, "%s", a->error.c_str());
+    pk_comm* c = new (std::nothrow) pk_comm();
+    if (!c) return PK_ERR_OOM;
+    c->kind = PK_COMM_RCCL;
+    c->rank = rank;
+    c->world = world;
+    ncclUniqueId u;
+    memcpy(u.internal, id, PK_COMM_ID_BYTES);
+    ncclResult_t r = a->CommInitRank(&c->nccl, world, u, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return rccl_fail(ctx, "ncclCommInitRank", r);
+    }
+    ctx->comm = c;
+    return PK_OK;
+}
+
+int pk_comm_init_local(pk_ctx* const* ctxs, int n) {
+    if (!ctxs || n < 1 || n > PK_MAX_RANKS || !is_pow2((size_t)n)) return PK_ERR_BAD_ARG;
+    for (int i = 0; i < n; i++)
+        if (!ctxs[i] || ctxs[i]->comm) return PK_ERR_BAD_ARG;
+    LocalGroup* g = new (std::nothrow) LocalGroup();
+    if (!g) return PK_ERR_OOM;
+    g->world = n;
+    g->refs = n;
+    pk_comm* cs[PK_MAX_RANKS] = {};
+    bool ok = true;
+    for (int i = 0; i < n && ok; i++) {
+        cs[i] = new (std::nothrow) pk_comm();
+        ok = cs[i] && hipSetDevice(ctxs[i]->device) == hipSuccess && hipEventCreateWithFlags(&g->ready[i], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
+        for (int i = 0; i < n; i++) {
+            delete cs[i];
+            if (g->ready[i]) (void)hipEventDestroy(g->ready[i]);
+        }
+        delete g;
+        return PK_ERR_HIP;
+    }
+    for (int i = 0; i < n; i++) {
+        cs[i]->kind = PK_COMM_LOCAL;
+        cs[i]->rank = i;
+        cs[i]->world = n;
+        cs[i]->grp = g;
+        ctxs[i]->comm = cs[i];
+    }
+    return PK_OK;
+}
+
+int pk_ctx_create_set(const int* devices, int n, pk_ctx** out) {
+    if (!devices || !out || n < 1 || n > PK_MAX_RANKS || !is_pow2((size_t)n)) return PK_ERR_BAD_ARG;
+    for (int i = 0; i < n; i++) out[i] = nullptr;
+    int rc = PK_OK;
+    bool distinct = true;
+    for (int i = 0; i < n && !rc; i++) {
+        rc = pk_ctx_create(devices[i], &out[i]);
+        for (int j = 0; j < i; j++) distinct = distinct && devices[i] != devices[j];
+    }
+    if (!rc && n > 1) {
+        if (!distinct) {
+            rc = pk_comm_init_local(out, n);  // several ranks on one device: RCCL cannot, the in-process transport can
+        } else {
+            RcclApi* a = rccl();
+            ncclComm_t comms[PK_MAX_RANKS];
+            if (!a->error.empty()) {
+                rc = set_err(out[0], PK_ERR_RCCL, "%s", a->error.c_str());
+            } else {
+                ncclResult_t r = a->CommInitAll(comms, n, devices);
+                if (r != ncclSuccess) rc = rccl_fail(out[0], "ncclCommInitAll", r);
+            }
+            for (int i = 0; i < n && !rc; i++) {
+                pk_comm* c = new (std::nothrow) pk_comm();
+                if (!c) {
+                    rc = PK_ERR_OOM;
+                    break;
+                }
+                c->kind = PK_COMM_RCCL;
+                c->rank = i;
+                c->world = n;
+                c->nccl = comms[i];
+                out[i]->comm = c;
+            }
+        }
+    }
+    if (rc) {
+        for (int i = 0; i < n; i++)
+            if (out[i]) {
+                pk_ctx_destroy(out[i]);
+                out[i] = nullptr;
+            }
+    }
+    return rc;
+}
+
+int pk_comm_info(const pk_ctx* ctx, int* rank, int* world, int* kind) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    if (rank) *rank = pk::comm_rank(ctx);
+    if (world) *world = pk::comm_world(ctx);
+    if (kind) *kind = ctx->comm ? ctx->comm->kind : PK_COMM_NONE;
+    return PK_OK;
+}
+
+int pk_comm_destroy(pk_ctx* ctx) {
+    PK_ENTER(ctx);
+    (void)hipStreamSynchronize(ctx->stream);
+    pk::comm_release(ctx);
+    return PK_OK;
+}
+
+int pk_comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, bytes_per_rank == 0 || (d_send && d_recv), "null pointer");
+    return pk::comm_all_gather(ctx, d_send, d_recv, bytes_per_rank);
+}
+
+int pk_comm_all_reduce_sum_u64(pk_ctx* ctx, uint64_t* d_buf, size_t count) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, count == 0 || d_buf, "null pointer");
+    return pk::comm_all_reduce_sum_u64(ctx, d_buf, count);
+}
+
+}  // extern "C"

@@ -47,6 +47,7 @@ int pk_ctx_destroy(pk_ctx* ctx) {
     PK_ENTER(ctx);
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    pk::comm_release(ctx);
     pk::ntt_release_ctx(ctx);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);

@@ -16,8 +16,11 @@ struct pk_prof_rec {
     hipEvent_t e0, e1;
 };
 
+struct pk_comm;  // comm.hip
+
 struct pk_ctx {
     int device = 0;
+    pk_comm* comm = nullptr;  // optional: this context's rank in a sharded commit (comm.hip); null = single GPU
     // optional per-kernel timing (pk_profile_*): hipEvent pairs recorded on the work stream
     bool prof_on = false;
     std::vector<pk_prof_rec> prof;
@@ -135,6 +138,12 @@ int sync_stream(pk_ctx* ctx);                                 // hipStreamSynchr
 int mail_alloc(pk_ctx* ctx, size_t bytes, void** out);        // 64-B aligned; valid until the next sync_stream
 int read_root(pk_ctx* ctx, const uint64_t* d_nodes, size_t n_leaves, uint64_t root[4]);  // hash.hip: after pk_merkle_*
 int ensure_ws(pk_ctx* ctx, size_t bytes);
+// comm.hip: rank / size of the context's communicator (0 / 1 without one) and its two collectives, enqueued on ctx->stream
+int comm_rank(const pk_ctx* ctx);
+int comm_world(const pk_ctx* ctx);
+int comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
+int comm_all_reduce_sum_u64(pk_ctx* ctx, uint64_t* d_buf, size_t count);
+void comm_release(pk_ctx* ctx);
 void ntt_release_ctx(pk_ctx* ctx);  // ntt.hip: frees the per-context twiddle tables
 
 }  // namespace pk

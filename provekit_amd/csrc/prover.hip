@@ -30,6 +30,8 @@ int commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, un
                 uint64_t* d_leaves, uint64_t* d_nodes, uint64_t* d_scratch);
 int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, size_t n_leaves, size_t width, const uint64_t* indices,
              size_t k, int canonical_leaves, uint64_t* leaves_out, uint64_t* sibling_digests, uint64_t* auth_paths);
+unsigned shard_factor(const pk_ctx* ctx, size_t rows);
+size_t commit_scratch_fes(const pk_ctx* ctx, size_t rows, size_t width);
 int lincomb2(pk_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* beta, const uint64_t* d_b, size_t n);
 int fold_pairs2(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint64_t* d_v1, uint64_t* d_out1, size_t len, const uint64_t* r);
 }
@@ -256,11 +258,11 @@ int whir_commit(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, fe* const* pol
     C.rows = (size_t)1 << (cfg.n_vars + cfg.starting_log_inv_rate - k);
     C.width = (size_t)batch << k;
     for (unsigned b = 0; b < batch; b++) C.polys[b] = polys[b];
-    ALLOC(leaves, C.rows * C.width);
+    ALLOC(leaves, C.rows * C.width / shard_factor(ctx, C.rows));  // a rank of a device set keeps only its rows (tree.hip)
     ALLOC(nodes, 2 * C.rows);
     C.leaves = leaves;
     C.nodes = nodes;
-    CK(ensure_ws(ctx, 2 * C.rows * C.width * 32));
+    CK(ensure_ws(ctx, commit_scratch_fes(ctx, C.rows, C.width) * 32));
     const uint64_t* ptrs[4];
     for (unsigned b = 0; b < batch; b++) ptrs[b] = U(polys[b]);
     CK(commit_into(ctx, ptrs, batch, cfg.n_vars, cfg.starting_log_inv_rate, k, U(leaves), U(nodes), (uint64_t*)ctx->d_ws));
@@ -401,9 +403,9 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
         log_inv_rate += k - 1;  // the domain halves while the polynomial shrinks 2^k-fold
         // N1+N2+M1+M2: re-commit
         const size_t rows = (size_t)1 << (nv + log_inv_rate - k), width = (size_t)1 << k;
-        ALLOC(leaves, rows * width);
+        ALLOC(leaves, rows * width / shard_factor(ctx, rows));
         ALLOC(nodes, 2 * rows);
-        CK(ensure_ws(ctx, 2 * rows * width * 32));
+        CK(ensure_ws(ctx, commit_scratch_fes(ctx, rows, width) * 32));
         const uint64_t* ptr = U(d_c);
         CK(commit_into(ctx, &ptr, 1, nv, log_inv_rate, k, U(leaves), U(nodes), (uint64_t*)ctx->d_ws));
         fe root;

@@ -18,11 +18,13 @@
 using namespace pk;
 
 struct pk_tree {
-    fe* d_leaves = nullptr;  // column-major [width][n_leaves], Montgomery; owned unless borrowed
-    fe* d_nodes = nullptr;   // heap of 2*n_leaves canonical digests
+    fe* d_leaves = nullptr;  // column-major [width][n_leaves / n_shards], Montgomery; owned unless borrowed
+    fe* d_nodes = nullptr;   // heap of 2*n_leaves canonical digests (replicated on every rank of a sharded commit)
     size_t n_leaves = 0, width = 0;
     bool owns_leaves = true;
     int layout = PK_COL_MAJOR;
+    // sharded commit: this rank holds the codeword rows i = shard (mod n_shards), local row t = i / n_shards
+    unsigned shard = 0, n_shards = 1;
 };
 
 namespace {
@@ -58,18 +60,68 @@ __global__ __launch_bounds__(256) void gather_opening_kernel(const fe* __restric
     }
 }
 
+// the all-gather delivers rank g's digests as one block: leaf i = g + G t is gathered[g*loc + t]; the heap wants it at rows + i
+__global__ __launch_bounds__(256) void interleave_digests_kernel(const fe* __restrict__ gathered, fe* __restrict__ nodes, size_t rows, unsigned G) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const size_t loc = rows / G;
+    fe_store(nodes + rows + i, fe_load(gathered + (i % G) * loc + i / G));
+}
+
+// the opened rows this rank owns, gathered leaf-major into a ZEROED device buffer (the rest stays zero: the all-reduce that
+// follows is then a gather); canonical = the ark-serialize form
+__global__ __launch_bounds__(256) void gather_owned_rows_kernel(const fe* __restrict__ leaves_local, size_t loc, unsigned width, unsigned shard,
+                                                                unsigned G, const unsigned long long* __restrict__ idx, size_t k, int canonical,
+                                                                fe* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k * width) return;
+    const size_t q = t / width, j = t % width;
+    const size_t i = idx[q];
+    if (i % G != shard) return;
+    fe x = fe_load(leaves_local + j * loc + i / G);
+    fe_store(out + t, canonical ? fe_from_montx(x) : x);
+}
+
 }  // namespace
 
 namespace pk {
-// RS-encode + Merkle commit into caller-owned device buffers (no allocation): leaves = width*rows FEs
-// (column-major), nodes = 2*rows FEs, scratch = 2*width*rows FEs.
+// 1 = this commit is computed whole on every rank; G = it is sharded by leaf index over the context's G ranks.  A pure
+// function of (communicator size, rows): every rank and every later opening of the tree take the same decision.
+unsigned shard_factor(const pk_ctx* ctx, size_t rows) {
+    const unsigned G = (unsigned)comm_world(ctx);
+    return (G > 1 && rows >= (size_t)64 * G) ? G : 1;
+}
+// device scratch (in FEs) commit_into needs for a codeword of `rows` x `width`
+size_t commit_scratch_fes(const pk_ctx* ctx, size_t rows, size_t width) {
+    const unsigned G = shard_factor(ctx, rows);
+    if (G == 1) return 2 * width * rows;
+    const size_t loc = rows / G;
+    return width * (rows + 2 * loc) + loc + rows;  // encode-shard scratch + local digests + gathered digests
+}
+// RS-encode + Merkle commit into caller-owned device buffers (no allocation): leaves = width*rows/shard_factor FEs
+// (column-major; the local shard when sharded), nodes = 2*rows FEs, scratch = commit_scratch_fes FEs.
 int commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
                 uint64_t* d_leaves, uint64_t* d_nodes, uint64_t* d_scratch) {
     const size_t rows = (size_t)1 << (n_vars + log_inv_rate - fold);
     const size_t width = (size_t)batch << fold;
-    int rc = pk_rs_encode(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, d_leaves, d_scratch);
-    if (!rc) rc = pk_merkle_commit(ctx, d_leaves, rows, width, PK_COL_MAJOR, d_nodes);
-    return rc;
+    const unsigned G = shard_factor(ctx, rows);
+    if (G == 1) {
+        int rc = pk_rs_encode(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, d_leaves, d_scratch);
+        if (!rc) rc = pk_merkle_commit(ctx, d_leaves, rows, width, PK_COL_MAJOR, d_nodes);
+        return rc;
+    }
+    // rank g encodes and hashes the rows i = g (mod G) with no communication; ONE all-gather of the 32-byte leaf
+    // digests (32*rows bytes in total: 8 MiB at the poseidon size, 256 MiB at 2^26); the inner tree is built on every rank
+    const size_t loc = rows / G;
+    fe* dig_local = (fe*)d_scratch + width * (rows + 2 * loc);
+    fe* gathered = dig_local + loc;
+    int rc = pk_rs_encode_shard(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, (unsigned)comm_rank(ctx), G, d_leaves, d_scratch);
+    if (!rc) rc = pk_leaf_hash(ctx, d_leaves, loc, width, PK_COL_MAJOR, (uint64_t*)dig_local);
+    if (!rc) rc = comm_all_gather(ctx, dig_local, gathered, loc * 32);
+    if (rc) return rc;
+    interleave_digests_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, ctx->stream>>>(gathered, (fe*)d_nodes, rows, G);
+    PK_LAUNCH_CHECK(ctx);
+    return pk_merkle_inner(ctx, d_nodes, rows);
 }
 // open k leaves of a tree described by raw buffers (same outputs as pk_tree_open)
 int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, size_t n_leaves, size_t width, const uint64_t* indices,
@@ -81,6 +133,8 @@ int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, siz
     t.width = width;
     t.owns_leaves = false;
     t.layout = PK_COL_MAJOR;
+    t.n_shards = shard_factor(ctx, n_leaves);  // the decision commit_into took for this tree
+    t.shard = t.n_shards > 1 ? (unsigned)comm_rank(ctx) : 0;
     return pk_tree_open(ctx, &t, indices, k, canonical_leaves, leaves_out, sibling_digests, auth_paths);
 }
 }  // namespace pk
@@ -112,14 +166,15 @@ int pk_commit(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsi
     if (!t) return PK_ERR_OOM;
     t->n_leaves = rows;
     t->width = width;
+    t->n_shards = shard_factor(ctx, rows);  // > 1: this context is one rank of a device set and keeps only its rows
+    t->shard = t->n_shards > 1 ? (unsigned)comm_rank(ctx) : 0;
     int rc = PK_OK;
-    if (hipMalloc((void**)&t->d_leaves, rows * width * 32) != hipSuccess || hipMalloc((void**)&t->d_nodes, 2 * rows * 32) != hipSuccess) {
+    if (hipMalloc((void**)&t->d_leaves, rows / t->n_shards * width * 32) != hipSuccess || hipMalloc((void**)&t->d_nodes, 2 * rows * 32) != hipSuccess) {
         pk_tree_destroy(ctx, t);
         return set_err(ctx, PK_ERR_OOM, "hipMalloc of the codeword matrix failed");
     }
-    rc = ensure_ws(ctx, 2 * rows * width * 32);
-    if (!rc) rc = pk_rs_encode(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, (uint64_t*)t->d_leaves, (uint64_t*)ctx->d_ws);
-    if (!rc) rc = pk_merkle_commit(ctx, (const uint64_t*)t->d_leaves, rows, width, PK_COL_MAJOR, (uint64_t*)t->d_nodes);
+    rc = ensure_ws(ctx, commit_scratch_fes(ctx, rows, width) * 32);
+    if (!rc) rc = commit_into(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, (uint64_t*)t->d_leaves, (uint64_t*)t->d_nodes, (uint64_t*)ctx->d_ws);
     if (!rc && root_out) rc = read_root(ctx, (const uint64_t*)t->d_nodes, rows, (uint64_t*)root_out);
     if (rc) {
         pk_tree_destroy(ctx, t);
@@ -192,8 +247,27 @@ int pk_tree_open(pk_ctx* ctx, const pk_tree* t, const uint64_t* indices, size_t 
     fe* m_sib = m_leaves + n1;
     fe* m_path = m_sib + k;
     memcpy(m_idx, indices, k * 8);
-    gather_opening_kernel<<<(unsigned)((n1 + n2 + 255) / 256), 256, 0, ctx->stream>>>(t->d_leaves, t->d_nodes, t->n_leaves, (unsigned)t->width, t->layout,
-                                                                                      logn, m_idx, k, canonical_leaves, m_leaves, m_sib, m_path);
+    if (t->n_shards > 1) {
+        // SURVEY 8e "Openings": leaf i is served by rank i mod G.  Every rank gathers the rows it owns into a zeroed buffer;
+        // one all-reduce (k*width*32 bytes, ~100 KiB; each element is non-zero on exactly one rank) hands all of them to
+        // everybody; sibling digests and auth paths come from the replicated inner tree.
+        PK_REQUIRE(ctx, t->layout == PK_COL_MAJOR, "sharded trees are column-major");
+        rc = ensure_scratch(ctx, ((size_t)1 << 20) + 32 * n1);
+        if (rc) return rc;
+        fe* d_rows = (fe*)((char*)ctx->d_scratch + ((size_t)1 << 19));  // clear of the reduction area (head) and the PoW words (tail)
+        PK_HIP(ctx, hipMemsetAsync(d_rows, 0, 32 * n1, ctx->stream));
+        gather_owned_rows_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, ctx->stream>>>(t->d_leaves, t->n_leaves / t->n_shards, (unsigned)t->width, t->shard,
+                                                                                     t->n_shards, m_idx, k, canonical_leaves, d_rows);
+        PK_LAUNCH_CHECK(ctx);
+        rc = comm_all_reduce_sum_u64(ctx, (uint64_t*)d_rows, 4 * n1);
+        if (rc) return rc;
+        PK_HIP(ctx, hipMemcpyAsync(m_leaves, d_rows, 32 * n1, hipMemcpyDeviceToHost, ctx->stream));
+        if (n2) gather_opening_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, ctx->stream>>>(nullptr, t->d_nodes, t->n_leaves, 0, t->layout, logn, m_idx, k, 0,
+                                                                                          m_leaves, m_sib, m_path);
+    } else {
+        gather_opening_kernel<<<(unsigned)((n1 + n2 + 255) / 256), 256, 0, ctx->stream>>>(t->d_leaves, t->d_nodes, t->n_leaves, (unsigned)t->width, t->layout,
+                                                                                          logn, m_idx, k, canonical_leaves, m_leaves, m_sib, m_path);
+    }
     PK_LAUNCH_CHECK(ctx);
     PK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // not sync_stream: the mailbox is read below
     memcpy(leaves_out, m_leaves, 32 * n1);

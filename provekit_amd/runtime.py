@@ -58,6 +58,44 @@ class Context:
             lib.pk_ctx_destroy(self.handle)
             self.handle = None
 
+    # -- device sets (include/provekit_hip.h "device sets"): sharded commits ----------------------------------------
+    @classmethod
+    def _wrap(cls, handle: int, device: int) -> "Context":
+        c = cls.__new__(cls)
+        c.handle, c.device = handle, device
+        return c
+
+    @classmethod
+    def create_set(cls, devices) -> list:
+        """pk_ctx_create_set: one context per listed device, joined by RCCL (distinct devices) or by the in-process
+        transport (a device listed more than once).  Drive the contexts from one host thread each."""
+        devs = (C.c_int * len(devices))(*devices)
+        out = (C.c_void_p * len(devices))()
+        rc = lib.pk_ctx_create_set(devs, len(devices), out)
+        if rc != 0:
+            raise ProveKitHipError(rc, f"pk_ctx_create_set({list(devices)}) failed")
+        return [cls._wrap(out[i], devices[i]) for i in range(len(devices))]
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        rc = lib.pk_comm_unique_id(buf)
+        if rc != 0:
+            raise ProveKitHipError(rc, "pk_comm_unique_id failed (librccl not loadable?)")
+        return bytes(buf)
+
+    def comm_init_rank(self, unique_id: bytes, world: int, rank: int):
+        """join an RCCL communicator of `world` single-GPU processes (rank 0 made unique_id; the launcher broadcast it)"""
+        self._check(lib.pk_comm_init_rank(self.handle, (C.c_uint8 * 128).from_buffer_copy(unique_id), world, rank))
+
+    def comm_info(self):
+        r, w, k = C.c_int(), C.c_int(), C.c_int()
+        self._check(lib.pk_comm_info(self.handle, C.byref(r), C.byref(w), C.byref(k)))
+        return r.value, w.value, k.value
+
+    def comm_destroy(self):
+        self._check(lib.pk_comm_destroy(self.handle))
+
     def __del__(self):
         try:
             self.close()

@@ -161,17 +161,11 @@ def test_prove_verify_midsize(ctx, oracle):
     run_case(ctx, oracle, m=17, m_0=16, nc=60000, n_in=5000, seed=17, pow_bits=10.0)
 
 
-def prove_verify_size_class(ctx, oracle, m, check_layout=False):
-    """A SATISFIABLE instance of the size class (m, m_0 = m - 1) under the reference's own WHIR schedule
-    (WhirConfig.derive: queries, OOD samples and grinding difficulties of new_whir_config_for_size): the proof must pass every
-    check of the independent verifier (transcript, Merkle openings of the 2^(m-3)-leaf tree, both sumchecks, folds, PoW); the
-    O(nnz) matrix evaluation of the deferred weights is left to the smaller cases above."""
-    import verifier as V
+def size_class_instance(oracle, m):
+    """satisfiable synthetic R1CS of the size class (m, m_0 = m - 1), built vectorised: 2^(m-2) constraints with 3 entries per
+    row in A and B over the inputs, C selecting a fresh output per row -> (nc, nw, [(nri, cols, vals)]*3, interner, z)"""
     from provekit_amd.field import random_field
-    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
-    from provekit_amd.sparse_matrix import R1CS, SparseMatrix
 
-    m_0 = m - 1
     nc, n_in = 1 << (m - 2), (1 << (m - 2)) - 8
     nw = 1 + n_in + nc
     rng = np.random.default_rng(m)
@@ -186,6 +180,21 @@ def prove_verify_size_class(ctx, oracle, m, check_layout=False):
     az, bz = (oracle.spmv(nc, nw, nri, ci, v, interner, z) for nri, ci, v in mats)
     z[1 + n_in :] = oracle.hadamard(az, bz)
     mats.append((np.arange(nc, dtype=np.uint32), (1 + n_in + np.arange(nc)).astype(np.uint32), np.zeros(nc, dtype=np.uint32)))
+    return nc, nw, mats, interner, z
+
+
+def prove_verify_size_class(ctx, oracle, m, check_layout=False):
+    """A SATISFIABLE instance of the size class (m, m_0 = m - 1) under the reference's own WHIR schedule
+    (WhirConfig.derive: queries, OOD samples and grinding difficulties of new_whir_config_for_size): the proof must pass every
+    check of the independent verifier (transcript, Merkle openings of the 2^(m-3)-leaf tree, both sumchecks, folds, PoW); the
+    O(nnz) matrix evaluation of the deferred weights is left to the smaller cases above."""
+    import verifier as V
+    from provekit_amd.field import random_field
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS, SparseMatrix
+
+    m_0 = m - 1
+    nc, nw, mats, interner, z = size_class_instance(oracle, m)
     r1cs = R1CS(ctx, *(SparseMatrix(nc, nw, *t) for t in mats), interner)
     d_z = ctx.upload(z)
     r1cs.test_witness_satisfaction(d_z)

@@ -1,0 +1,200 @@
+"""GPU: the multi-GPU path behind the C ABI (include/provekit_hip.h "device sets") on ONE GPU.
+
+RCCL refuses two ranks on one device, so the G ranks of these tests are G contexts of this process on GPU 0 joined by the
+library's in-process transport (pk_ctx_create_set with a repeated device), one host thread per rank -- the same
+commit_into / pk_tree_open / pk_prove code the RCCL transport drives on a real node; only the two collectives differ.
+Checks: collectives; sharded pk_commit root == unsharded root and sharded openings == unsharded openings; sharded pk_prove
+transcripts byte-identical to the lone prover's for the same seed (m = 17 and the bench size m = 21), accepted by the
+verifier; RCCL itself is exercised at world size 1 (library loads, communicator forms, both collectives run)."""
+import ctypes as C
+import threading
+
+import numpy as np
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+
+
+def run_ranks(ctxs, fn):
+    """fn(rank, ctx) on one thread per rank; re-raises the first failure"""
+    out, err = [None] * len(ctxs), []
+
+    def go(r):
+        try:
+            out[r] = fn(r, ctxs[r])
+        except BaseException as e:  # noqa: BLE001
+            err.append(e)
+
+    ths = [threading.Thread(target=go, args=(r,)) for r in range(len(ctxs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=600)
+    if err:
+        raise err[0]
+    return out
+
+
+@pytest.fixture()
+def rank_sets():
+    import torch
+
+    torch.cuda.is_available()
+    import provekit_amd
+
+    made = []
+
+    def make(G):
+        cs = provekit_amd.Context.create_set([0] * G)
+        made.append(cs)
+        return cs
+
+    yield make
+    for cs in made:
+        for c in cs:
+            c.close()
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_local_transport_collectives(rank_sets, G):
+    from provekit_amd._lib import PK_OK, lib
+
+    ctxs = rank_sets(G)
+    assert [c.comm_info() for c in ctxs] == [(r, G, 1) for r in range(G)]  # kind 1 = PK_COMM_LOCAL
+    n = 1000
+
+    def fn(r, c):
+        send = np.full((n,), r + 1, np.uint64) * np.arange(1, n + 1, dtype=np.uint64)
+        d_send, d_recv = c.upload(send), c.alloc(8 * n * G)
+        c._check(lib.pk_comm_all_gather(c.handle, d_send.ptr, d_recv.ptr, 8 * n))
+        got = c.download(d_recv, (G, n))
+        red = np.zeros(n, np.uint64)
+        red[r::G] = 7 + r  # each element non-zero on exactly one rank
+        d_red = c.upload(red)
+        c._check(lib.pk_comm_all_reduce_sum_u64(c.handle, d_red.ptr, n))
+        return got, c.download(d_red, (n,))
+
+    for got, red in run_ranks(ctxs, fn):
+        for p in range(G):
+            assert np.array_equal(got[p], np.full((n,), p + 1, np.uint64) * np.arange(1, n + 1, dtype=np.uint64))
+        assert np.array_equal(red, np.array([7 + (i % G) for i in range(n)], np.uint64))
+
+
+def test_rccl_communicator_of_one_rank(ctx):
+    """the RCCL transport on the one GPU there is: librccl resolves, ncclCommInitRank succeeds, both collectives run"""
+    import provekit_amd
+    from provekit_amd._lib import lib
+
+    c = provekit_amd.Context(0)
+    c.comm_init_rank(provekit_amd.Context.comm_unique_id(), 1, 0)
+    assert c.comm_info() == (0, 1, 2)  # PK_COMM_RCCL
+    x = np.arange(4096, dtype=np.uint64)
+    d, e = c.upload(x), c.alloc(x.nbytes)
+    c._check(lib.pk_comm_all_gather(c.handle, d.ptr, e.ptr, x.nbytes))
+    c._check(lib.pk_comm_all_reduce_sum_u64(c.handle, e.ptr, x.size))
+    c.sync()
+    assert np.array_equal(c.download(e, x.shape), x)
+    c.comm_destroy()
+    c.close()
+
+
+@pytest.mark.parametrize("G,batch,n_vars", [(2, 2, 12), (4, 2, 16), (8, 1, 17), (4, 2, 21)])
+def test_sharded_commit_and_openings_match_unsharded(ctx, oracle, rank_sets, G, batch, n_vars):
+    from provekit_amd.field import random_field
+    from provekit_amd.whir import commit_batch
+
+    polys = [random_field(1 << n_vars, 70 + b + n_vars) for b in range(batch)]
+    ref = commit_batch(ctx, [ctx.upload(p) for p in polys], n_vars)
+    rows = ref.n_leaves
+    rng = np.random.default_rng(G + n_vars)
+    idx = np.unique(np.concatenate([rng.integers(0, rows, size=60), [0, rows - 1]])).astype(np.uint64)
+    want = [ref.open(idx, canonical_leaves=cl) for cl in (True, False)]
+    ctxs = rank_sets(G)
+
+    def fn(r, c):
+        com = commit_batch(c, [c.upload(p) for p in polys], n_vars)
+        res = (com.root, [com.open(idx, canonical_leaves=cl) for cl in (True, False)])
+        com.close()
+        return res
+
+    for root, opened in run_ranks(ctxs, fn):
+        assert root == ref.root
+        for got, exp in zip(opened, want):
+            for a, b in zip(got, exp):
+                assert np.array_equal(a, b)
+    ref.close()
+
+
+def _sharded_prove_case(ctx, oracle, rank_sets, G, m, m_0, nc, n_in, seed, test_pow, verify_r1cs):
+    import verifier as V
+    from test_gpu_prove import satisfiable_r1cs, to_sparse
+
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS
+
+    nw, z, coeffs, trips = satisfiable_r1cs(nc, n_in, seed)
+    zm = oracle.to_mont(oracle.ints_to_limbs(z))
+    interner = oracle.to_mont(oracle.ints_to_limbs(coeffs))
+    cfg_w, cfg_b = WhirConfig.for_size(m, test_pow), blinding_config_for(m_0, test_pow)
+
+    def prove_on(c):
+        r1cs = R1CS(c, *(to_sparse(nc, nw, t) for t in trips), interner)
+        s = WhirR1CSScheme(c, r1cs, m, m_0, cfg_w, cfg_b)
+        proofs = [s.prove(c.upload(zm), seed=sd) for sd in (seed, seed + 1)]
+        ds = s.domain_separator
+        s.close()
+        r1cs.close()
+        return proofs, ds
+
+    want, ds = prove_on(ctx)
+    for proofs, _ in run_ranks(rank_sets(G), lambda r, c: prove_on(c)):
+        assert proofs == want, "a rank of the sharded prover diverged from the lone prover's transcript"
+
+    def vcfg(c):
+        return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
+
+    mats = [(t[0], t[1], [coeffs[v] for v in t[2]]) for t in trips]
+    assert V.verify(want[0], ds, m, m_0, vcfg(cfg_w), vcfg(cfg_b), r1cs=(nc, nw, mats) if verify_r1cs else None)
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_sharded_prove_m17_transcript_identical(ctx, oracle, rank_sets, G):
+    _sharded_prove_case(ctx, oracle, rank_sets, G, m=17, m_0=16, nc=60000, n_in=5000, seed=17, test_pow=8.0, verify_r1cs=False)
+
+
+def test_sharded_prove_bench_size_transcript_identical(ctx, oracle, rank_sets):
+    """m = 21 under the reference's own schedule on a satisfiable instance, two ranks: every commit of the witness WHIR down to
+    2^7 leaves is sharded; all transcripts equal the lone prover's and the verifier accepts"""
+    import verifier as V
+    from test_gpu_prove import size_class_instance
+
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS, SparseMatrix
+
+    m, m_0 = 21, 20
+    nc, nw, mats, interner, z = size_class_instance(oracle, m)
+    cfg_w, cfg_b = WhirConfig.derive(m), blinding_config_for(m_0)
+
+    def prove_on(c):
+        r1cs = R1CS(c, *(SparseMatrix(nc, nw, *t) for t in mats), interner)
+        s = WhirR1CSScheme(c, r1cs, m, m_0, cfg_w, cfg_b)
+        proof = s.prove(c.upload(z), seed=5)
+        ds = s.domain_separator
+        s.close()
+        r1cs.close()
+        return proof, ds
+
+    want, ds = prove_on(ctx)
+    for proof, _ in run_ranks(rank_sets(2), lambda r, c: prove_on(c)):
+        assert proof == want
+
+    def vcfg(c):
+        return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
+
+    assert V.verify(want, ds, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
