@@ -207,17 +207,33 @@ def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3):
             "frac_of_hbm_peak": alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "root": root}
 
 
+def join_device_set(ctx, rank, world, dist):
+    """one RCCL communicator behind the C ABI for this run's ranks: rank 0 makes the unique id, torch.distributed (already
+    up for the barrier / timing reduction) broadcasts its 128 bytes, every rank joins (include/provekit_hip.h "device sets")"""
+    import provekit_amd
+
+    box = [provekit_amd.Context.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    ctx.comm_init_rank(box[0], world, rank)
+
+
 def commit_workload(args, rank, local_rank, world, dist, torch):
     """configs[4]: one batch-2 commit of 2^m coefficients (default m as given; 26 for the BASELINE config), sharded by
-    leaf index over the ranks (provekit_amd/distributed.py): strong scaling, one all-gather of leaf digests per commit."""
+    leaf index over the ranks behind the C ABI (pk_commit_into on a context that joined the device set: rank g encodes and
+    hashes the rows i = g mod G, ncclAllGather of the leaf digests over xGMI, inner tree on every rank): strong scaling,
+    one collective per commit."""
+    import ctypes as C
+
     import provekit_amd
     from provekit_amd._lib import lib
-    from provekit_amd.distributed import HipShardBackend, ShardedCommitter
 
     m = args.m
     ctx = provekit_amd.Context(local_rank)
-    be = HipShardBackend(ctx)
-    sc = ShardedCommitter(be, rank=rank, world=world)
+    one_gpu = os.environ.get("PK_BENCH_ONE_GPU") == "1"
+    if one_gpu and world > 1:
+        return commit_workload_gloo(args, rank, local_rank, world, dist, torch, ctx)
+    if world > 1:
+        join_device_set(ctx, rank, world, dist)
     n = 1 << m
     # seeded uniform coefficients generated on the device (identical on every rank: each rank needs the full vectors)
     polys = []
@@ -225,12 +241,84 @@ def commit_workload(args, rank, local_rank, world, dist, torch):
         t = torch.randint(0, 2**62, (n, 4), dtype=torch.int64, device=f"cuda:{local_rank}", generator=torch.Generator(device=f"cuda:{local_rank}").manual_seed(17 + bidx))
         t[:, 3] &= (1 << 60) - 1  # < 2^252 < p: a valid field element image
         polys.append(t)
-    ptrs = [int(t.data_ptr()) for t in polys]
+    torch.cuda.synchronize()
+    ptrs = (C.c_void_p * 2)(*[int(t.data_ptr()) for t in polys])
+    szs = [C.c_size_t() for _ in range(3)]
+    ctx._check(lib.pk_commit_sizes(ctx.handle, 2, m, 1, 4, *[C.byref(x) for x in szs]))
+    leaves, nodes, scratch = (ctx.alloc_fe(x.value) for x in szs)
+    root = (C.c_uint8 * 32)()
+
+    def commit():
+        ctx._check(lib.pk_commit_into(ctx.handle, ptrs, 2, m, 1, 4, leaves.ptr, nodes.ptr, scratch.ptr, root))
 
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        commit()
+    ctx.profile(True)
+    ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        commit()  # blocking: returns the root (stream synchronised)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = ctx.profile_read()
+    if rank == 0:
+        emit_commit_line(args, world, m, dt, prof, bytes(root).hex(), "RCCL all-gather of leaf digests behind the C ABI (pk_commit_into)")
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def emit_commit_line(args, world, m, dt, prof, root_hex, how):
+    n, rows = 1 << m, 1 << (m + 1 - 4)
+    alg_bytes = 32 * 2 * n + 32 * 2 * 2 * n + 64 * rows  # coeffs read + leaves written + digests
+    n_l, ms_l = prof.get("leaf_hash", (1, 0.0))
+    avg_ms = ms_l / max(n_l, 1)
+    lh_bytes = (rows // world) * 33 * 32
+    achieved = lh_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
+    emit({
+        "metric": "commits/sec (2^m-coefficient batch-2 WHIR commit: RS-encode NTT + Skyscraper Merkle)",
+        "value": args.steps / dt, "unit": "commits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u32x8 (BN254-Fr, 256-bit Montgomery integers)", "data": "synthetic",
+        "config": {"workload": f"synthetic WHIR commit: batch 2, n={m}, rate 1/2, fold 16, sharded by leaf index over {world} GPU(s), {how}",
+                   "root": root_hex},
+        "commit_GBps_algorithmic": alg_bytes / (dt / args.steps) / 1e9,
+        "roofline": {"kernel": "leaf_hash_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                     "algorithmic_bytes_per_launch": lh_bytes},
+        "stage_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
+    })
+
+
+def commit_workload_gloo(args, rank, local_rank, world, dist, torch, ctx):
+    """development aid only (PK_BENCH_ONE_GPU=1: every rank on GPU 0, gloo): RCCL refuses two ranks on one device, so this mode
+    drives the same shard kernels with torch's collective (provekit_amd/distributed.py) to exercise the launcher contract"""
+    from provekit_amd.distributed import HipShardBackend, ShardedCommitter
+
+    m = args.m
+    be = HipShardBackend(ctx)
+    sc = ShardedCommitter(be, rank=rank, world=world)
+    n = 1 << m
+    polys = []
+    for bidx in range(2):
+        t = torch.randint(0, 2**62, (n, 4), dtype=torch.int64, device=f"cuda:{local_rank}", generator=torch.Generator(device=f"cuda:{local_rank}").manual_seed(17 + bidx))
+        t[:, 3] &= (1 << 60) - 1
+        polys.append(t)
+    ptrs = [int(t.data_ptr()) for t in polys]
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(max(args.warmup, 1)):
@@ -242,35 +330,15 @@ def commit_workload(args, rank, local_rank, world, dist, torch):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         root, _, leaves = sc.commit(ptrs, m)
-        be.release(leaves)  # steady state: no hipMalloc inside the timed region
+        be.release(leaves)
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    prof = ctx.profile_read()
+    t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
     if rank == 0:
-        rows = 1 << (m + 1 - 4)
-        alg_bytes = 32 * 2 * n + 32 * 2 * 2 * n + 64 * rows  # coeffs read + leaves written + digests
-        n_l, ms_l = prof.get("leaf_hash", (1, 0.0))
-        avg_ms = ms_l / max(n_l, 1)
-        lh_bytes = (rows // world) * 33 * 32
-        achieved = lh_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
-        emit({
-            "metric": "commits/sec (2^m-coefficient batch-2 WHIR commit: RS-encode NTT + Skyscraper Merkle)",
-            "value": args.steps / dt, "unit": "commits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u32x8 (BN254-Fr, 256-bit Montgomery integers)", "data": "synthetic",
-            "config": {"workload": f"synthetic WHIR commit: batch 2, n={m}, rate 1/2, fold 16, sharded by leaf index over {world} GPU(s), "
-                                   "one all-gather of leaf digests", "root": root.tobytes().hex()},
-            "commit_GBps_algorithmic": alg_bytes / (dt / args.steps) / 1e9,
-            "roofline": {"kernel": "leaf_hash_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms},
-            "stage_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
-        })
-    if dist is not None:
-        dist.destroy_process_group()
+        emit_commit_line(args, world, m, dt, ctx.profile_read(), root.tobytes().hex(), "gloo all-gather (single-GPU development mode)")
+    dist.destroy_process_group()
 
 
 _STDOUT_FD = None
@@ -300,6 +368,9 @@ def main():
     ap.add_argument("--concurrency", type=int, default=16,
                     help="provers per GPU, each with its own context/stream/arena (host transcript work of one proof overlaps "
                          "the kernels of another); 1 = strictly one proof at a time")
+    ap.add_argument("--sharded", action="store_true",
+                    help="prove workload, latency mode (BASELINE configs[3]): ONE proof at a time sharded over all ranks -- every large "
+                         "commit split by leaf index with an RCCL all-gather of leaf digests behind the C ABI; strong scaling")
     ap.add_argument("--h2d", action="store_true",
                     help="upload the witness from (pageable) host memory before every proof: the PCIe-inclusive rate DESIGN.md quotes; "
                          "never the judged line (inputs are resident when the clock starts)")
@@ -353,15 +424,18 @@ def main():
     n_wit = (1 << (m - 1)) - 5
     cfg_w = WhirConfig.derive(m)  # the reference's own schedule (new_whir_config_for_size): queries, OOD samples, pow_bits
     cfg_b = blinding_config_for(m_0)
-    conc = max(1, args.concurrency)
+    conc = 1 if args.sharded else max(1, args.concurrency)
     # every prover owns an arena of 26 x 32 B x 2^m (+ workspace, R1CS copy): keep the provers within half of the HBM
     per_prover = 40 * 32 * (1 << m)
     conc = max(1, min(conc, int(0.5 * torch.cuda.get_device_properties(local_rank).total_memory / per_prover)))
     workers = []  # (ctx, prover, witness): one independent prover per worker, all on this rank's GPU
     for w in range(conc):
         c = provekit_amd.Context(local_rank)
-        r1cs_w, mats, interner, nc = synth_r1cs(c, m_0, n_wit, seed=1234 + rank)
-        z_host = random_field(n_wit, 99 + rank + 1000 * w)
+        if args.sharded and world > 1:  # this context is one rank of the device set: its commits are sharded from here on
+            join_device_set(c, rank, world, dist)
+        srank = 0 if args.sharded else rank  # the ranks of a sharded prover hold the SAME statement and witness
+        r1cs_w, mats, interner, nc = synth_r1cs(c, m_0, n_wit, seed=1234 + srank)
+        z_host = random_field(n_wit, 99 + srank + 1000 * w)
         workers.append((c, WhirR1CSScheme(c, r1cs_w, m, m_0, cfg_w, cfg_b), c.upload(z_host), r1cs_w, z_host))
     ctx = workers[0][0]
 
@@ -462,14 +536,14 @@ def main():
         stage_ms = {k: round(v[1] / iso_steps, 4) for k, v in sorted(prof_iso.items(), key=lambda kv: -kv[1][1])}
         line = {
             "metric": "proofs/sec (noir-r1cs prove hot path, WHIR commit + sumcheck + folding rounds)",
-            "value": world * args.steps * conc / dt,
+            "value": (1 if args.sharded else world) * args.steps * conc / dt,
             "unit": "proofs/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.sharded else "weak",
             "vs_baseline": None,
             "dtype": "u32x8 (BN254-Fr, 256-bit Montgomery integers)",
             "data": "synthetic",
@@ -477,8 +551,10 @@ def main():
                 "workload": f"poseidon-rounds size class: m={m}, m_0={m_0}, batch-2 WHIR commit + zk-sumcheck + {cfg_w.n_rounds}-round WHIR opening, "
                             f"queries {cfg_w.num_queries}/{cfg_w.final_queries}, pow_bits {cfg_w.pow_bits}/{cfg_w.final_pow_bits} (WhirConfig::new derivation, security 128, "
                             f"ConjectureList), blinding WHIR n={cfg_b.n_vars} queries {cfg_b.num_queries}/{cfg_b.final_queries}, Skyscraper-sponge transcript, ChaCha20 masks",
-                "proofs_per_step": conc * world,
-                "parallelism": f"one step = one wave of {conc} proofs per GPU; {world} GPU(s) x {conc} concurrent provers per GPU, work handed out "
+                "proofs_per_step": conc * (1 if args.sharded else world),
+                "parallelism": (f"one step = one proof, sharded over {world} GPU(s): every commit of >= 64 rows per rank split by leaf index, "
+                                "RCCL all-gather of leaf digests + all-reduce of opened rows behind the C ABI; the rest of the proof is "
+                                "replicated on every rank") if args.sharded else f"one step = one wave of {conc} proofs per GPU; {world} GPU(s) x {conc} concurrent provers per GPU, work handed out "
                                f"dynamically (independent proofs, no collective; "
                                f"GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')})"
                                + (", witness uploaded over PCIe before every proof (--h2d)" if args.h2d else ""),

@@ -288,6 +288,12 @@ int pk_gather_leaves(pk_ctx *ctx, const uint64_t *d_leaves, size_t n_leaves, siz
  * (types.go:17-22; utilities.go:71-82); out == NULL queries the length. */
 int pk_commit(pk_ctx *ctx, const uint64_t *const *d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
               unsigned fold, uint8_t root_out[32], pk_tree **out);
+/* pk_commit into caller-owned device buffers (no allocation; sizes in FEs from pk_commit_sizes, which account for the
+ * context's device set: a rank of G keeps 1/G of the codeword rows).  d_nodes is the full heap on every rank. */
+int pk_commit_sizes(const pk_ctx *ctx, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
+                    size_t *leaves_fes, size_t *nodes_fes, size_t *scratch_fes);
+int pk_commit_into(pk_ctx *ctx, const uint64_t *const *d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
+                   unsigned fold, uint64_t *d_leaves, uint64_t *d_nodes, uint64_t *d_scratch, uint8_t root_out[32]);
 int pk_tree_from_leaves(pk_ctx *ctx, const uint64_t *d_leaves, size_t n_leaves, size_t width, int layout,
                         uint8_t root_out[32], pk_tree **out);
 int pk_tree_info(const pk_tree *tree, size_t *n_leaves, size_t *width, const uint64_t **d_leaves,

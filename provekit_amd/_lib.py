@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libprovekit_hip.so")
+# PK_LIB_PATH: development aid for A/B timing against another build of the same ABI
+LIB_PATH = os.environ.get("PK_LIB_PATH") or os.path.join(_HERE, "lib", "libprovekit_hip.so")
 
 PK_OK = 0
 PK_LEAF_MAJOR = 0
@@ -108,6 +109,8 @@ SIGNATURES = {
     "pk_pow_solve": (C.c_int, [vp, vp, C.c_double, C.POINTER(C.c_uint64)]),
     "pk_pow_check": (C.c_int, [vp, vp, C.c_double, C.c_uint64, C.POINTER(C.c_int)]),
     "pk_commit": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, C.POINTER(vp)]),
+    "pk_commit_sizes": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
+    "pk_commit_into": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp, vp, vp]),
     "pk_tree_from_leaves": (C.c_int, [vp, vp, sz, sz, C.c_int, vp, C.POINTER(vp)]),
     "pk_tree_info": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(vp), C.POINTER(vp)]),
     "pk_tree_root": (C.c_int, [vp, vp, vp]),

@@ -12,7 +12,7 @@
 //                   children 2i,2i+1 are adjacent in the heap, so a wave reads 4 KiB
 //                   contiguous; the workgroup then walks up its own subtree.
 #include "ctx.hpp"
-#include "skyscraper29.hpp"
+#include "skyscraper29s.hpp"
 
 using namespace pk;
 
@@ -20,9 +20,9 @@ template <int VERSION>
 __global__ __launch_bounds__(256) void compress_many_kernel(const fe* __restrict__ msgs, fe* __restrict__ out, size_t n) {
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        fe29 l = unpack_reduce29(fe_load(msgs + 2 * i));
-        fe29 r = unpack_reduce29(fe_load(msgs + 2 * i + 1));
-        fe_store(out + i, pack29(compress29<VERSION>(l, r)));
+        fe29 l = to_scaled29(fe_load(msgs + 2 * i));  // any 256-bit value (generic.rs:81-82: inputs >= p are legal)
+        fe29 r = to_scaled29(fe_load(msgs + 2 * i + 1));
+        fe_store(out + i, from_scaled_canon(compress29s<VERSION>(l, r)));
     }
 }
 
@@ -34,14 +34,15 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const fe* __restrict__ l
     if (i >= n_leaves) return;
     size_t step = LAYOUT == PK_COL_MAJOR ? n_leaves : 1;
     const fe* p = leaves + (LAYOUT == PK_COL_MAJOR ? i : i * (size_t)width);
-    fe29 h = from_mont29(fe_load(p));  // into_bigint(), whir.rs:21
+    // into_bigint() (whir.rs:21) and the hash's internal scaling in one Montgomery reduction: x*2^256 -> 32x
+    fe29 h = mont_to_scaled29(fe_load(p));
     fe nxt = width > 1 ? fe_load(p + step) : fe_zero();
     for (unsigned j = 1; j < width; j++) {
-        fe29 x = from_mont29(nxt);
+        fe29 x = mont_to_scaled29(nxt);
         if (j + 1 < width) nxt = fe_load(p + (size_t)(j + 1) * step);  // prefetch next column
-        h = compress29<VERSION, false>(h, x);  // intermediate digests of the fold stay lazily reduced
+        h = compress29s<VERSION>(h, x);  // the fold never leaves the scaled domain
     }
-    fe_store(digests + i, pack29(cond_sub_p29(h)));  // h < 2p: exact canonical form once per leaf (also for width 1)
+    fe_store(digests + i, from_scaled_canon(h));  // exact canonical form once per leaf (also for width 1)
 }
 
 // `levels` consecutive levels of ark MerkleTree::new in one launch: nodes[i] = C(nodes[2i], nodes[2i+1]).  A workgroup
@@ -55,8 +56,8 @@ __global__ __launch_bounds__(256) void merkle_levels_kernel(fe* __restrict__ nod
     for (unsigned l = 0; l < levels; l++) {
         if (threadIdx.x < width && base + threadIdx.x < count) {
             size_t i = count + base + threadIdx.x;
-            fe29 a = unpack29<0>(fe_load(nodes + 2 * i)), b = unpack29<0>(fe_load(nodes + 2 * i + 1));  // digests are canonical
-            fe_store(nodes + i, pack29(compress29<VERSION>(a, b)));
+            fe29 a = to_scaled29(fe_load(nodes + 2 * i)), b = to_scaled29(fe_load(nodes + 2 * i + 1));  // digests are canonical
+            fe_store(nodes + i, from_scaled_canon(compress29s<VERSION>(a, b)));
         }
         __threadfence_block();
         __syncthreads();
@@ -73,8 +74,8 @@ __global__ __launch_bounds__(512) void merkle_top_kernel(fe* __restrict__ nodes,
     for (size_t lvl = top_leaves / 2; lvl >= 1; lvl >>= 1) {
         if (threadIdx.x < lvl) {
             size_t i = lvl + threadIdx.x;
-            fe29 l = unpack29<0>(fe_load(nodes + 2 * i)), r = unpack29<0>(fe_load(nodes + 2 * i + 1));
-            fe x = pack29(compress29<VERSION>(l, r));
+            fe29 l = to_scaled29(fe_load(nodes + 2 * i)), r = to_scaled29(fe_load(nodes + 2 * i + 1));
+            fe x = from_scaled_canon(compress29s<VERSION>(l, r));
             fe_store(nodes + i, x);
             if (i == 1 && host_root) fe_store(host_root, x);
         }

@@ -9,7 +9,7 @@
 #include <cmath>
 
 #include "ctx.hpp"
-#include "skyscraper29.hpp"
+#include "skyscraper29s.hpp"
 
 using namespace pk;
 
@@ -25,21 +25,30 @@ __device__ __forceinline__ fe from_arg(const fe_arg& a) {
     return r;
 }
 
-// best / ticket: two device words, best == ~0 and ticket == 0 between launches.  The workgroup that draws the last ticket
-// publishes the window's smallest valid nonce (or ~0) to pinned host memory and re-arms both words, so a window costs one
-// launch and one stream synchronisation -- no copy operations.
+// best / ticket: two device words, best == ~0 and ticket == 0 between launches.  Lanes walk the window in ascending
+// grid-stride order and stop as soon as a smaller valid nonce is known (a lane's later nonces are all larger), so the work
+// done is the expected 2^bits hashes plus about one stride, whatever the window; the result is still the SMALLEST valid
+// nonce (every nonce below the final `best` has been tried).  The left input of every hash is the challenge: its round-0
+// square is computed once per lane, 13 squarings per hash instead of 14.  The workgroup that draws the last ticket
+// publishes the result (or ~0) to pinned host memory and re-arms both words: a window costs one launch and one stream
+// synchronisation -- no copy operations.
 __global__ __launch_bounds__(256) void pow_search_kernel(fe_arg challenge_arg, fe_arg threshold_arg, unsigned long long base,
                                                          unsigned long long count, unsigned long long* best, unsigned* ticket,
                                                          unsigned long long* host_best) {
-    const fe29 challenge = unpack_reduce29(from_arg(challenge_arg));  // generic.rs:81 reduce_partial on arbitrary input
+    const fe29 challenge = to_scaled29(from_arg(challenge_arg));  // generic.rs:81 reduce_partial on arbitrary input
+    fe29 s0 = challenge, zero;
+#pragma unroll
+    for (int k = 0; k < 9; k++) zero.v[k] = 0;
+    sky_sq_round_s<0>(s0, zero);  // round 0 for r = 0, once per lane: s0 = 32 sq(challenge)
     const fe threshold = from_arg(threshold_arg);
     const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
     for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
-        unsigned long long nonce = base + t;
+        const unsigned long long nonce = base + t;
+        if (nonce > __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         fe r = fe_zero();
         r.v[0] = (u32)nonce;
         r.v[1] = (u32)(nonce >> 32);
-        fe h = pack29(compress29<2>(challenge, unpack29<0>(r)));
+        fe h = from_scaled_canon(compress29s_v2_fixed_left(challenge, s0, unpack29<5>(r)));  // 32*nonce < 2^69: three limbs
         if (fe_lt(h, threshold)) atomicMin(best, nonce);
     }
     __syncthreads();  // every lane of the workgroup has issued its atomicMin
@@ -130,16 +139,20 @@ int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
     memcpy(ch.v, challenge, 32);
     memcpy(th.v, thr, 32);
     unsigned long long best = ~0ull, base = 0;
-    // first window = 2x the expected work (miss probability e^-2; a miss costs one more round trip), then doubling:
-    // ~2.7x the expected hashes on average instead of a fixed large window; never more lanes than nonces
-    unsigned wbits = (unsigned)bits + 1;
+    // One launch almost always: the window is 2^(bits+5) nonces (miss probability e^-32) but lanes stop once a smaller valid
+    // nonce is known, so the hashes actually computed are ~2^bits plus one stride.  The stride (lanes in flight) is a quarter
+    // of the expected work: enough lanes to keep the search short, few enough that little is wasted after the first hit.
+    unsigned wbits = (unsigned)bits + 5;
     if (wbits < 12) wbits = 12;
-    if (wbits > 26) wbits = 26;
     unsigned long long window = 1ull << wbits;
+    unsigned lbits = (unsigned)bits > 2 ? (unsigned)bits - 2 : 0;
+    if (lbits < 12) lbits = 12;
+    if (lbits > 18) lbits = 18;
+    unsigned grid = 1u << (lbits - 8);
+    const unsigned grid_cap = (unsigned)ctx->num_cus * 4;
+    if (grid > grid_cap) grid = grid_cap;
     ProfScope prof(ctx, "pow_search");
     for (;;) {
-        unsigned long long want = (window + 255) / 256;
-        const unsigned grid = (unsigned)(want < (unsigned long long)ctx->num_cus * 16 ? want : (unsigned long long)ctx->num_cus * 16);
         pow_search_kernel<<<grid, 256, 0, ctx->stream>>>(ch, th, base, window, d_best, d_ticket, h_best);
         PK_LAUNCH_CHECK(ctx);
         rc = sync_stream(ctx);
@@ -147,7 +160,6 @@ int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
         best = *(volatile unsigned long long*)h_best;
         if (best != ~0ull) break;
         base += window;
-        if (window < (1ull << 28)) window <<= 1;
         if (base > (1ull << 62)) return set_err(ctx, PK_ERR_BAD_ARG, "proof of work search exhausted");
     }
     *nonce = best;

@@ -2,7 +2,7 @@
 // (fe29.hpp, skyscraper29.hpp), so the CPU test suite can check it against the oracle without a GPU.
 #include "ctx.hpp"
 #include "reduce.hpp"
-#include "skyscraper29.hpp"
+#include "skyscraper29s.hpp"
 #include "transcript.hpp"
 
 using namespace pk;
@@ -39,6 +39,19 @@ PK_HD fe selftest_op(int op, const fe& x, const fe& y) {
             wide w;
             for (int i = 0; i < 8; i++) w.l[i] = 700ull * x.v[i] + 324ull * y.v[i];
             r = wide_reduce(w);
+            break;
+        }
+        // the scaled-by-32 fast path (skyscraper29s.hpp) through its own conversions: must equal ops 1 / 2 / x mod p / op 3
+        case 15: r = from_scaled_canon(compress29s<2>(to_scaled29(x), to_scaled29(y))); break;
+        case 16: r = from_scaled_canon(compress29s<1>(to_scaled29(x), to_scaled29(y))); break;
+        case 17: r = from_scaled_canon(to_scaled29(x)); break;
+        case 18: r = from_scaled_canon(mont_to_scaled29(x)); break;
+        case 19: {  // a fold of three compressions without leaving the scaled domain: C(C(C(x, y), x), y)
+            fe29 a = to_scaled29(x), b = to_scaled29(y);
+            fe29 h = compress29s<2>(a, b);
+            h = compress29s<2>(h, a);
+            h = compress29s<2>(h, b);
+            r = from_scaled_canon(h);
             break;
         }
         default: break;
@@ -131,10 +144,10 @@ int pk_selftest_permute(uint64_t l[4], uint64_t r[4]) {
 // op: 0 fe_mul29(a,b)  1 compress v2  2 compress v1  3 from_mont  4 a*b*2^-256 via mont256_29  5 a^2*2^-256 via sqr256_29
 // a, b, out: n field elements (4 x u64 each).  Host only; no device needed.
 int pk_selftest_arith(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-    if (!a || !out || (!b && (op == 0 || op == 1 || op == 2 || op == 4))) return PK_ERR_BAD_ARG;
+    if (!a || !out || (!b && (op == 0 || op == 1 || op == 2 || op == 4 || op == 15 || op == 16 || op == 19))) return PK_ERR_BAD_ARG;
     for (size_t i = 0; i < n; i++) {
         fe x = load_host(a + 4 * i), y = b ? load_host(b + 4 * i) : x;
-        if (op < 0 || op > 14) return PK_ERR_BAD_ARG;
+        if (op < 0 || op > 19) return PK_ERR_BAD_ARG;
         fe r = selftest_op(op, x, y);
         store_host(out + 4 * i, r);
     }

@@ -33,13 +33,18 @@ __host__ __device__ __forceinline__ constexpr u32 rc_limb(int rc, int i) {
     return (u32)(RC[rc][i >> 1] >> ((i & 1) * 32));
 }
 
-// byte-wise S-box on 4 packed bytes (skyscraper/core/src/bar.rs:40-42,63-67)
+// byte-wise S-box on 4 packed bytes (skyscraper/core/src/bar.rs:40-42,63-67): per byte
+//   sbox(v) = rotl1(v ^ (rotl1(~v) & rotl2(v) & rotl3(v))).
+// Rotation commutes with the bitwise operations, so with W = ~v & rotl1(v) & rotl2(v) this is rotl1(v) ^ rotl2(W): three
+// byte-lane rotations instead of four, each two shifts and one bit-select.
+__host__ __device__ __forceinline__ u32 rotl_bytes(u32 v, int s) {
+    const u32 keep = (u32)((0xffu << s) & 0xffu) * 0x01010101u;  // bits that receive the left-shifted part
+    return ((v << s) & keep) | ((v >> (8 - s)) & ~keep);
+}
 __host__ __device__ __forceinline__ u32 sbox4(u32 v) {
-    u32 t1 = ((v & 0x80808080u) >> 7) | ((v & 0x7f7f7f7fu) << 1);
-    u32 t2 = ((v & 0xc0c0c0c0u) >> 6) | ((v & 0x3f3f3f3fu) << 2);
-    u32 t3 = ((v & 0xe0e0e0e0u) >> 5) | ((v & 0x1f1f1f1fu) << 3);
-    u32 x = (~t1 & t2 & t3) ^ v;
-    return ((x & 0x80808080u) >> 7) | ((x & 0x7f7f7f7fu) << 1);
+    const u32 r1 = rotl_bytes(v, 1), r2 = rotl_bytes(v, 2);
+    const u32 w = ~v & r1 & r2;
+    return r1 ^ rotl_bytes(w, 2);
 }
 
 }  // namespace pk

@@ -98,6 +98,35 @@ PK_HD fe29 compress29(const fe29& l_in, const fe29& r_in) {
     return cond_sub_p29(s);
 }
 
+// Skyscraper v2 with round 0 hoisted: f0 = sq(l_in) (normalized, < 1.2p) is supplied by a caller that hashes many messages
+// sharing the same left input (the proof-of-work grinder: l = challenge, r = nonce).  Returns the canonical digest.
+PK_HD fe29 compress29_v2_fixed_left(const fe29& l_in, const fe29& f0, const fe29& r_in) {
+    fe29 l = add29(r_in, f0);  // round 0 adds no constant (RC[0] = 0)
+    reduce_almost29(l);
+    fe29 r = l_in;
+    sky_round29<1, false>(l, r);
+    sky_round29<2, false>(l, r);
+    sky_round29<3, false>(l, r);
+    sky_round29<4, false>(l, r);
+    sky_round29<5, false>(l, r);
+    sky_round29<6, true>(l, r);
+    sky_round29<7, true>(l, r);
+    sky_round29<8, false>(l, r);
+    sky_round29<9, false>(l, r);
+    sky_round29<10, true>(l, r);
+    sky_round29<11, true>(l, r);
+    sky_round29<12, false>(l, r);
+    sky_round29<13, false>(l, r);
+    sky_round29<14, false>(l, r);
+    sky_round29<15, false>(l, r);
+    sky_round29<16, false>(l, r);
+    sky_round29<17, false>(l, r);
+    fe29 a = cond_sub_p29(l), b = cond_sub_p29(l_in);
+    fe29 s = add29(a, b);
+    normalize29(s);
+    return cond_sub_p29(s);
+}
+
 // any 256-bit value -> almost reduced fe29
 PK_HD fe29 unpack_reduce29(const fe& x) {
     fe29 r = unpack29<0>(x);

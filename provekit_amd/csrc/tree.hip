@@ -184,6 +184,28 @@ int pk_commit(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsi
     return PK_OK;
 }
 
+// the same commit into caller-owned buffers (nothing is allocated: the steady-state form; pk_prove's own path)
+int pk_commit_sizes(const pk_ctx* ctx, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold, size_t* leaves_fes,
+                    size_t* nodes_fes, size_t* scratch_fes) {
+    if (!ctx || fold > n_vars || n_vars + log_inv_rate - fold > 27) return PK_ERR_BAD_ARG;
+    const size_t rows = (size_t)1 << (n_vars + log_inv_rate - fold), width = (size_t)batch << fold;
+    if (leaves_fes) *leaves_fes = rows * width / shard_factor(ctx, rows);
+    if (nodes_fes) *nodes_fes = 2 * rows;
+    if (scratch_fes) *scratch_fes = commit_scratch_fes(ctx, rows, width);
+    return PK_OK;
+}
+int pk_commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
+                   uint64_t* d_leaves, uint64_t* d_nodes, uint64_t* d_scratch, uint8_t root_out[32]) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, d_coeffs && d_leaves && d_nodes && d_scratch, "null pointer");
+    PK_REQUIRE(ctx, batch >= 1 && batch <= 16, "batch out of range");
+    PK_REQUIRE(ctx, fold <= n_vars && fold <= 8, "fold out of range");
+    PK_REQUIRE(ctx, n_vars + log_inv_rate - fold <= 27, "domain too large (two-adicity 28)");
+    int rc = commit_into(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, d_leaves, d_nodes, d_scratch);
+    if (!rc && root_out) rc = read_root(ctx, d_nodes, (size_t)1 << (n_vars + log_inv_rate - fold), (uint64_t*)root_out);
+    return rc;
+}
+
 // MerkleTree::new over leaves the caller already holds on the device (borrowed, not copied)
 int pk_tree_from_leaves(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, uint8_t root_out[32],
                         pk_tree** out) {

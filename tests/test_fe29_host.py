@@ -149,3 +149,36 @@ def test_bar_every_sbox_input(oracle):
     got = oracle.limbs_to_ints(run(13, oracle.ints_to_limbs(xs)))
     for x, g in zip(xs, got):
         assert g % P == pr.bar(x) and g < 2 * P + (3 * P) // 10, hex(x)
+
+
+@pytest.mark.parametrize("version", [2, 1])
+def test_scaled_compress_equals_reference_compress(oracle, version):
+    """skyscraper29s.hpp (state scaled by 32, fused rounds) against the plain path, the golden vectors and the oracle"""
+    vec = VEC["compress_v2" if version == 2 else "compress_v1"]
+    a = oracle.ints_to_limbs(int(x, 16) for x, _, _ in vec)
+    b = oracle.ints_to_limbs(int(y, 16) for _, y, _ in vec)
+    assert oracle.limbs_to_ints(run(15 if version == 2 else 16, a, b)) == [int(e, 16) for _, _, e in vec]
+    edge = [0, 1, P - 1, P, P + 1, 2 * P, (1 << 256) - 1, (1 << 255), 5 * P, (1 << 253) - 1]
+    xs = [x for x in edge for _ in edge] + rand_fe(20000, 31 + version, 1 << 256)
+    ys = [y for _ in edge for y in edge] + rand_fe(20000, 41 + version, 1 << 256)
+    a, b = oracle.ints_to_limbs(xs), oracle.ints_to_limbs(ys)
+    assert np.array_equal(run(15 if version == 2 else 16, a, b), run(1 if version == 2 else 2, a, b))
+    msgs = np.concatenate([a, b], axis=1).astype("<u8").tobytes()
+    assert run(15 if version == 2 else 16, a, b).astype("<u8").tobytes() == oracle.compress_many(msgs, version)
+
+
+def test_scaled_conversions(oracle):
+    xs = rand_fe(5000, 51, 1 << 256) + [0, 1, P - 1, P, P + 1, (1 << 256) - 1, 31 * P // 32, P // 32 + 1]
+    a = oracle.ints_to_limbs(xs)
+    assert oracle.limbs_to_ints(run(17, a)) == [x % P for x in xs]  # x -> 32x mod p -> /32: the identity mod p
+    ms = rand_fe(5000, 52) + [0, 1, P - 1]
+    m = oracle.ints_to_limbs(ms)
+    assert np.array_equal(run(18, m), oracle.from_mont(m))  # Montgomery image -> scaled -> canonical == into_bigint()
+
+
+def test_scaled_fold_stays_in_domain(oracle):
+    """three chained compressions without leaving the scaled domain (what the leaf fold does)"""
+    xs, ys = rand_fe(3000, 61, 1 << 256), rand_fe(3000, 62, 1 << 256)
+    a, b = oracle.ints_to_limbs(xs), oracle.ints_to_limbs(ys)
+    c = lambda u, v: np.frombuffer(oracle.compress_many(np.concatenate([u, v], axis=1).astype("<u8").tobytes()), dtype="<u8").reshape(-1, 4)
+    assert np.array_equal(run(19, a, b), c(c(c(a, b), a), b))
