@@ -27,7 +27,9 @@ __global__ __launch_bounds__(256) void compress_many_kernel(const fe* __restrict
 }
 
 // SkyscraperCRH::evaluate (provekit/common/src/skyscraper/whir.rs:30-48): h = x0; h = C(h, x_j)
-template <int VERSION, int LAYOUT>
+// SCALED_IN: the leaves are in the hash-ready encoding the commit's own NTT emits (32 * value as a plain integer < p,
+// ntt.hip ntt_scaled_available): they enter the fold as they are.  Otherwise they are Montgomery images (the C ABI form).
+template <int VERSION, int LAYOUT, bool SCALED_IN>
 __global__ __launch_bounds__(256) void leaf_hash_kernel(const fe* __restrict__ leaves, size_t n_leaves, unsigned width,
                                                         fe* __restrict__ digests) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -35,10 +37,10 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const fe* __restrict__ l
     size_t step = LAYOUT == PK_COL_MAJOR ? n_leaves : 1;
     const fe* p = leaves + (LAYOUT == PK_COL_MAJOR ? i : i * (size_t)width);
     // into_bigint() (whir.rs:21) and the hash's internal scaling in one Montgomery reduction: x*2^256 -> 32x
-    fe29 h = mont_to_scaled29(fe_load(p));
+    fe29 h = SCALED_IN ? unpack29<0>(fe_load(p)) : mont_to_scaled29(fe_load(p));
     fe nxt = width > 1 ? fe_load(p + step) : fe_zero();
     for (unsigned j = 1; j < width; j++) {
-        fe29 x = mont_to_scaled29(nxt);
+        fe29 x = SCALED_IN ? unpack29<0>(nxt) : mont_to_scaled29(nxt);
         if (j + 1 < width) nxt = fe_load(p + (size_t)(j + 1) * step);  // prefetch next column
         h = compress29s<VERSION>(h, x);  // the fold never leaves the scaled domain
     }
@@ -85,29 +87,41 @@ __global__ __launch_bounds__(512) void merkle_top_kernel(fe* __restrict__ nodes,
     if (threadIdx.x == 0) fe_store(nodes, fe_zero());
 }
 
-static int leaf_hash_launch(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, uint64_t* d_digests) {
+static int leaf_hash_launch(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, uint64_t* d_digests,
+                            bool scaled_in) {
     ProfScope prof(ctx, "leaf_hash");
     unsigned block = 256;
     unsigned grid = (unsigned)((n_leaves + block - 1) / block);
     const fe* L = (const fe*)d_leaves;
     fe* D = (fe*)d_digests;
     unsigned w = (unsigned)width;
+#define PK_LH(V, LAY, SC) leaf_hash_kernel<V, LAY, SC><<<grid, block, 0, ctx->stream>>>(L, n_leaves, w, D)
     if (ctx->hash_version == 2) {
-        if (layout == PK_COL_MAJOR)
-            leaf_hash_kernel<2, PK_COL_MAJOR><<<grid, block, 0, ctx->stream>>>(L, n_leaves, w, D);
-        else
-            leaf_hash_kernel<2, PK_LEAF_MAJOR><<<grid, block, 0, ctx->stream>>>(L, n_leaves, w, D);
+        if (layout == PK_COL_MAJOR) {
+            if (scaled_in) PK_LH(2, PK_COL_MAJOR, true);
+            else PK_LH(2, PK_COL_MAJOR, false);
+        } else {
+            PK_LH(2, PK_LEAF_MAJOR, false);
+        }
     } else {
-        if (layout == PK_COL_MAJOR)
-            leaf_hash_kernel<1, PK_COL_MAJOR><<<grid, block, 0, ctx->stream>>>(L, n_leaves, w, D);
-        else
-            leaf_hash_kernel<1, PK_LEAF_MAJOR><<<grid, block, 0, ctx->stream>>>(L, n_leaves, w, D);
+        if (layout == PK_COL_MAJOR) {
+            if (scaled_in) PK_LH(1, PK_COL_MAJOR, true);
+            else PK_LH(1, PK_COL_MAJOR, false);
+        } else {
+            PK_LH(1, PK_LEAF_MAJOR, false);
+        }
     }
+#undef PK_LH
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
 }
 
 namespace pk {
+// leaf hash of a column-major codeword in the commit's internal (hash-ready) encoding, or in Montgomery form
+int leaf_hash_x(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, uint64_t* d_digests, bool scaled_in) {
+    if (!n_leaves) return PK_OK;
+    return leaf_hash_launch(ctx, d_leaves, n_leaves, width, PK_COL_MAJOR, d_digests, scaled_in);
+}
 // root of the tree pk_merkle_inner / pk_merkle_commit just built on this context's stream
 int read_root(pk_ctx* ctx, const uint64_t* d_nodes, size_t n_leaves, uint64_t root[4]) {
     if (n_leaves < 2) return pk_memcpy_d2h(ctx, root, d_nodes + 4, 32);
@@ -166,7 +180,7 @@ int pk_leaf_hash(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t 
     PK_REQUIRE(ctx, layout == PK_LEAF_MAJOR || layout == PK_COL_MAJOR, "unknown layout");
     PK_REQUIRE(ctx, n_leaves == 0 || (d_leaves && d_digests), "null pointer");
     if (!n_leaves) return PK_OK;
-    return leaf_hash_launch(ctx, d_leaves, n_leaves, width, layout, d_digests);
+    return leaf_hash_launch(ctx, d_leaves, n_leaves, width, layout, d_digests, false);
 }
 
 int pk_merkle_inner(pk_ctx* ctx, uint64_t* d_nodes, size_t n_leaves) {

@@ -67,6 +67,17 @@ __global__ void twiddle_seed_kernel(fe* W, size_t h) {
     if (threadIdx.x == 0 && blockIdx.x == 0) fe_store(W + h, fe_sqrx(fe_load(W + h / 2)));
 }
 
+// Ws[e] = 32 * w_N^e as a plain integer (W holds Montgomery images: mont(W[e], 32) = w * 32).  Multiplying a Montgomery
+// image x*2^256 by it in the Montgomery product drops the 2^256 and scales by 32: the form the hash kernels consume
+// (skyscraper29s.hpp), so the leaf hash needs no conversion of its inputs.
+__global__ __launch_bounds__(256) void twiddle_scale_kernel(const fe* __restrict__ W, fe* __restrict__ Ws, size_t n) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    fe c = fe_zero();
+    c.v[0] = 32u;
+    fe_store(Ws + j, fe_mulx(fe_load(W + j), c));
+}
+
 struct PassParams {
     const fe* in;
     fe* out;
@@ -77,6 +88,7 @@ struct PassParams {
     size_t nonzero;     // pass 1 only: natural input indices >= nonzero read as zero
     size_t in_nat_r, in_nat_v, in_nat_u;  // natural-index weights for the zero test
     const fe* W;        // w_N^e table, N entries
+    const fe* Wtw;      // table the inter-pass twiddle is read from: W, or its hash-ready variant 32*w_N^e (see ntt_columns)
     size_t n_mask;      // N - 1
     size_t tw_mul;      // twiddle exponent = tw_mul * k * v  (0 = no twiddle)
     size_t wr_step;     // w_R^j = W[j * wr_step]
@@ -312,7 +324,7 @@ __device__ __forceinline__ void ntt8_round(fe29 (&x)[8], const PassParams& p, co
             fe29 y;
             if (p.tw_mul) {
                 size_t ex = (p.tw_mul * (size_t)k * (c.v0 + b)) & p.n_mask;
-                y = mont261_29(x[reg], tw29(p.W, ex));
+                y = mont261_29(x[reg], tw29(p.Wtw, ex));
             } else {
                 y = red29(x[reg]);
             }
@@ -425,11 +437,30 @@ int get_twiddles(pk_ctx* ctx, unsigned log_n, const fe** out) {
     return PK_OK;
 }
 
+int get_twiddles_scaled(pk_ctx* ctx, unsigned log_n, const fe* W, const fe** out) {
+    auto it = ctx->twiddles_scaled.find(log_n);
+    if (it != ctx->twiddles_scaled.end()) {
+        *out = (const fe*)it->second;
+        return PK_OK;
+    }
+    const size_t n = (size_t)1 << log_n;
+    fe* Ws = nullptr;
+    PK_HIP(ctx, hipMalloc((void**)&Ws, 32 * (n < 2 ? 2 : n)));
+    twiddle_scale_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(W, Ws, n);
+    PK_LAUNCH_CHECK(ctx);
+    ctx->twiddles_scaled[log_n] = Ws;
+    *out = Ws;
+    return PK_OK;
+}
+
+// does a pass of radix 2^log_r over a v axis of 2^log_v take the register-radix kernel?
+inline bool pass_is_fast(unsigned log_r, unsigned log_v, size_t N) { return log_r >= 3 && log_v < 62 && log_v >= 11 - log_r && N >= 8; }
+
 template <int LOG_R>
 int launch_pass_r(pk_ctx* ctx, const PassParams& p, bool in_r_contig, size_t tiles, unsigned ncols) {
     constexpr int R = 1 << LOG_R;
     // register-radix fast path: needs at least BT8 = 2048/R elements along v per tile and a real twiddle table
-    if (LOG_R >= 3 && p.log_v < 62 && p.log_v >= (unsigned)(11 - LOG_R) && p.n_mask + 1 >= 8) {
+    if (pass_is_fast(LOG_R, p.log_v, p.n_mask + 1)) {
         ProfScope prof(ctx, in_r_contig ? "ntt_pass_last" : "ntt_pass");
         const size_t tiles8 = (tiles * BT) >> (11 - LOG_R);
         const size_t lds_bytes = 9 * 2048 * 4;
@@ -490,21 +521,41 @@ namespace pk {
 void ntt_release_ctx(pk_ctx* ctx) {
     for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
     ctx->twiddles.clear();
+    for (auto& kv : ctx->twiddles_scaled) (void)hipFree(kv.second);
+    ctx->twiddles_scaled.clear();
+}
+
+// Can a transform of this size deliver the hash-ready output (every output = 32 * value as a plain integer < p instead of
+// the Montgomery image)?  It rides on the LAST inter-pass twiddle multiplication, so the size needs two or more passes and
+// that pass must be the register-radix kernel.  A pure function of the size: commit and openings agree on the encoding.
+bool ntt_scaled_available(unsigned log_n) {
+    if (log_n <= 9 || log_n > 27) return false;
+    if (log_n <= 18) {
+        unsigned l1 = (log_n + 1) / 2, l2 = log_n - l1;
+        return pass_is_fast(l1, l2, (size_t)1 << log_n);
+    }
+    unsigned l1 = (log_n + 2) / 3, l2 = (log_n - l1 + 1) / 2, l3 = log_n - l1 - l2;
+    return pass_is_fast(l2, l3, (size_t)1 << log_n);
 }
 
 // Column-batched NTT, natural -> natural.  `ncols` vectors of length N = 2^log_n:
 // input column c at in + c*in_col_stride holds `nonzero` leading coefficients (rest is zero
 // and is never read); output column c at out + c*out_col_stride.  `scratch` must hold
 // ncols columns of N elements (column stride N) when log_n > 9, and may alias nothing.
+// scaled_out: deliver the hash-ready encoding (only legal when ntt_scaled_available(log_n)).
 int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero, fe* out, size_t out_col_stride, fe* scratch,
-                unsigned log_n, unsigned ncols) {
+                unsigned log_n, unsigned ncols, bool scaled_out) {
     PK_REQUIRE(ctx, log_n <= 27, "NTT size above 2^27");
+    PK_REQUIRE(ctx, !scaled_out || ntt_scaled_available(log_n), "hash-ready NTT output is not available at this size");
     const size_t N = (size_t)1 << log_n;
     const fe* W = nullptr;
     int rc = get_twiddles(ctx, log_n, &W);
     if (rc) return rc;
+    const fe* Ws = W;
+    if (scaled_out && (rc = get_twiddles_scaled(ctx, log_n, W, &Ws))) return rc;
     PassParams p{};
     p.W = W;
+    p.Wtw = W;
     p.n_mask = N - 1;
     if (log_n <= 9) {
         // single pass: R = N and the tile's batch axis v runs over BT adjacent *columns*
@@ -560,9 +611,11 @@ int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero,
         p.in_nat_r = R2; p.in_nat_v = 1; p.in_nat_u = 0;
         p.nonzero = nonzero;
         p.tw_mul = 1;
+        p.Wtw = Ws;  // the only inter-pass twiddle of a two-pass transform carries the output scaling
         p.wr_step = N >> l1;
         rc = launch_pass(ctx, l1, p, false, R2 / BT, ncols);
         if (rc) return rc;
+        p.Wtw = W;
         // pass 2: DFT over n2 (contiguous); v = k1 (in stride R2, out stride 1); out k2 stride R1
         p.in = scratch;
         p.out = out;
@@ -605,9 +658,11 @@ int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero,
     p.in_nat_r = 0; p.in_nat_v = 0; p.in_nat_u = 0;
     p.nonzero = 1;
     p.tw_mul = R1;
+    p.Wtw = Ws;  // the last inter-pass twiddle carries the output scaling
     p.wr_step = N >> l2;
     rc = launch_pass(ctx, l2, p, false, R1 * (R3 / BT), ncols);
     if (rc) return rc;
+    p.Wtw = W;
     // pass 3: DFT over n3 (contiguous); v = k1 (in stride R2*R3, out stride 1); u = k2 (in stride R3, out stride R1)
     p.in = scratch;
     p.out = out;
@@ -644,7 +699,7 @@ int pk_ntt(pk_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, unsigned log_n, u
     size_t N = (size_t)1 << log_n;
     fe* scratch = nullptr;
     if (log_n > 9) PK_HIP(ctx, hipMalloc((void**)&scratch, 32 * N * ncols));
-    int rc = pk::ntt_columns(ctx, (const fe*)d_in, N, N, (fe*)d_out, N, scratch, log_n, ncols);
+    int rc = pk::ntt_columns(ctx, (const fe*)d_in, N, N, (fe*)d_out, N, scratch, log_n, ncols, false);
     if (scratch) {
         hipError_t e = hipStreamSynchronize(ctx->stream);
         (void)hipFree(scratch);
@@ -653,9 +708,13 @@ int pk_ntt(pk_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, unsigned log_n, u
     return rc;
 }
 
-int pk_rs_encode(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
-                 unsigned fold, uint64_t* d_leaves, uint64_t* d_scratch) {
-    PK_ENTER(ctx);
+}  // extern "C"
+
+namespace pk {
+// the two encodes with a choice of output encoding (scaled = hash-ready, see ntt_scaled_available); the C entry points
+// below always return Montgomery images
+int rs_encode_x(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
+                uint64_t* d_leaves, uint64_t* d_scratch, bool scaled) {
     PK_REQUIRE(ctx, d_coeffs && d_leaves && d_scratch, "null pointer");
     PK_REQUIRE(ctx, batch >= 1 && batch <= 16, "batch out of range");
     PK_REQUIRE(ctx, fold <= n_vars && fold <= 8, "fold out of range");
@@ -670,14 +729,13 @@ int pk_rs_encode(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, u
         int rc = pk::deinterleave(ctx, (const fe*)d_coeffs[b], (size_t)1 << n_vars, fold, S + (size_t)b * fw * rows, rows);
         if (rc) return rc;
     }
-    return pk::ntt_columns(ctx, S, rows, L, (fe*)d_leaves, rows, S2, log_rows, (unsigned)(batch * fw));
+    return pk::ntt_columns(ctx, S, rows, L, (fe*)d_leaves, rows, S2, log_rows, (unsigned)(batch * fw), scaled);
 }
 
 // rows of shard g only: d_leaves_local = column-major [batch*2^fold][rows/G]; local row t is global leaf g + G t.
 // d_scratch: (batch*2^fold) * (rows + 2*rows/G) FEs.
-int pk_rs_encode_shard(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
-                       unsigned fold, unsigned shard, unsigned n_shards, uint64_t* d_leaves_local, uint64_t* d_scratch) {
-    PK_ENTER(ctx);
+int rs_encode_shard_x(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
+                      unsigned shard, unsigned n_shards, uint64_t* d_leaves_local, uint64_t* d_scratch, bool scaled) {
     PK_REQUIRE(ctx, d_coeffs && d_leaves_local && d_scratch, "null pointer");
     PK_REQUIRE(ctx, batch >= 1 && batch <= 16, "batch out of range");
     PK_REQUIRE(ctx, fold <= n_vars && fold <= 8, "fold out of range");
@@ -685,7 +743,7 @@ int pk_rs_encode_shard(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned ba
     PK_REQUIRE(ctx, is_pow2(n_shards) && shard < n_shards, "n_shards must be a power of two and shard < n_shards");
     const unsigned log_rows = n_vars + log_inv_rate - fold, log_g = ilog2(n_shards);
     PK_REQUIRE(ctx, log_g <= log_rows, "more shards than leaves");
-    if (n_shards == 1) return pk_rs_encode(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, d_leaves_local, d_scratch);
+    if (n_shards == 1) return rs_encode_x(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, d_leaves_local, d_scratch, scaled);
     const size_t rows = (size_t)1 << log_rows, fw = (size_t)1 << fold, Ng = rows >> log_g;
     const size_t L = ((size_t)1 << n_vars) / fw;
     const unsigned ncols = (unsigned)(batch * fw);
@@ -706,7 +764,22 @@ int pk_rs_encode_shard(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned ba
         ntt_shard_prestep_kernel<<<grid, 256, 0, ctx->stream>>>(S, rows, L, Y, Ng, Ng, shard, n_shards, W, rows - 1);
     }
     PK_LAUNCH_CHECK(ctx);
-    return pk::ntt_columns(ctx, Y, Ng, Ng, (fe*)d_leaves_local, Ng, S2, log_rows - log_g, ncols);
+    return pk::ntt_columns(ctx, Y, Ng, Ng, (fe*)d_leaves_local, Ng, S2, log_rows - log_g, ncols, scaled);
+}
+}  // namespace pk
+
+extern "C" {
+
+int pk_rs_encode(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
+                 unsigned fold, uint64_t* d_leaves, uint64_t* d_scratch) {
+    PK_ENTER(ctx);
+    return pk::rs_encode_x(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, d_leaves, d_scratch, false);
+}
+
+int pk_rs_encode_shard(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
+                       unsigned fold, unsigned shard, unsigned n_shards, uint64_t* d_leaves_local, uint64_t* d_scratch) {
+    PK_ENTER(ctx);
+    return pk::rs_encode_shard_x(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, shard, n_shards, d_leaves_local, d_scratch, false);
 }
 
 }  // extern "C"

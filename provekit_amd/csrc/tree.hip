@@ -13,7 +13,7 @@
 #include <vector>
 
 #include "ctx.hpp"
-#include "fe29.hpp"
+#include "skyscraper29s.hpp"
 
 using namespace pk;
 
@@ -25,9 +25,31 @@ struct pk_tree {
     int layout = PK_COL_MAJOR;
     // sharded commit: this rank holds the codeword rows i = shard (mod n_shards), local row t = i / n_shards
     unsigned shard = 0, n_shards = 1;
+    // the codeword is held in the hash-ready encoding the commit's NTT emits (32 * value, plain integer < p) instead of
+    // Montgomery images: the leaf hash consumes it without conversion, openings convert the ~100 opened rows
+    bool scaled = false;
 };
 
+namespace pk {
+int rs_encode_x(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
+                uint64_t* d_leaves, uint64_t* d_scratch, bool scaled);
+int rs_encode_shard_x(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
+                      unsigned shard, unsigned n_shards, uint64_t* d_leaves_local, uint64_t* d_scratch, bool scaled);
+int leaf_hash_x(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, uint64_t* d_digests, bool scaled_in);
+bool ntt_scaled_available(unsigned log_n);
+}
+
 namespace {
+
+// an element of the stored codeword -> what an opening returns: canonical (the ark-serialize form) or Montgomery
+__device__ __forceinline__ fe opened_element(const fe& x, bool scaled, int canonical) {
+    if (!scaled) return canonical ? fe_from_montx(x) : x;
+    if (canonical) return from_scaled_canon(unpack29<0>(x));  // 32v -> v
+    fe k;  // 2^507 mod p: mont(32v, 2^507) = 32v * 2^507 * 2^-256 = v * 2^256
+    k.v[0] = 0xc0f10b6eu; k.v[1] = 0x95e64f0du; k.v[2] = 0x2e33c2c0u; k.v[3] = 0xf2087f4eu;
+    k.v[4] = 0x7fcae90cu; k.v[5] = 0xc4610290u; k.v[6] = 0x4be93745u; k.v[7] = 0x25df13cfu;
+    return fe_mulx(x, k);
+}
 
 // One launch serves an opening: the first k*width lanes gather the opened leaves to leaf-major order (optionally
 // converted to canonical, the ark-serialize form), the next k*(plen+1) lanes the sibling digests -- out_sib[q] =
@@ -37,14 +59,15 @@ namespace {
 __global__ __launch_bounds__(256) void gather_opening_kernel(const fe* __restrict__ leaves, const fe* __restrict__ nodes, size_t n_leaves,
                                                              unsigned width, int layout, unsigned logn,
                                                              const unsigned long long* __restrict__ idx, size_t k, int canonical,
-                                                             fe* __restrict__ out_leaves, fe* __restrict__ out_sib, fe* __restrict__ out_path) {
+                                                             fe* __restrict__ out_leaves, fe* __restrict__ out_sib, fe* __restrict__ out_path,
+                                                             bool scaled) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n1 = k * width;
     if (t < n1) {
         size_t q = t / width, j = t % width;
         size_t i = idx[q];
         fe x = fe_load(leaves + (layout == PK_COL_MAJOR ? j * n_leaves + i : i * (size_t)width + j));
-        fe_store(out_leaves + t, canonical ? fe_from_montx(x) : x);
+        fe_store(out_leaves + t, opened_element(x, scaled, canonical));
         return;
     }
     t -= n1;
@@ -72,14 +95,14 @@ __global__ __launch_bounds__(256) void interleave_digests_kernel(const fe* __res
 // follows is then a gather); canonical = the ark-serialize form
 __global__ __launch_bounds__(256) void gather_owned_rows_kernel(const fe* __restrict__ leaves_local, size_t loc, unsigned width, unsigned shard,
                                                                 unsigned G, const unsigned long long* __restrict__ idx, size_t k, int canonical,
-                                                                fe* __restrict__ out) {
+                                                                fe* __restrict__ out, bool scaled) {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= k * width) return;
     const size_t q = t / width, j = t % width;
     const size_t i = idx[q];
     if (i % G != shard) return;
     fe x = fe_load(leaves_local + j * loc + i / G);
-    fe_store(out + t, canonical ? fe_from_montx(x) : x);
+    fe_store(out + t, opened_element(x, scaled, canonical));
 }
 
 }  // namespace
@@ -91,6 +114,9 @@ unsigned shard_factor(const pk_ctx* ctx, size_t rows) {
     const unsigned G = (unsigned)comm_world(ctx);
     return (G > 1 && rows >= (size_t)64 * G) ? G : 1;
 }
+// is the codeword commit_into writes for `rows` leaves held in the hash-ready encoding (see pk_tree::scaled)?  Also a pure
+// function of (communicator size, rows).
+bool codeword_scaled(const pk_ctx* ctx, size_t rows) { return ntt_scaled_available(ilog2(rows / shard_factor(ctx, rows))); }
 // device scratch (in FEs) commit_into needs for a codeword of `rows` x `width`
 size_t commit_scratch_fes(const pk_ctx* ctx, size_t rows, size_t width) {
     const unsigned G = shard_factor(ctx, rows);
@@ -105,9 +131,11 @@ int commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, un
     const size_t rows = (size_t)1 << (n_vars + log_inv_rate - fold);
     const size_t width = (size_t)batch << fold;
     const unsigned G = shard_factor(ctx, rows);
+    const bool scaled = codeword_scaled(ctx, rows);
     if (G == 1) {
-        int rc = pk_rs_encode(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, d_leaves, d_scratch);
-        if (!rc) rc = pk_merkle_commit(ctx, d_leaves, rows, width, PK_COL_MAJOR, d_nodes);
+        int rc = rs_encode_x(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, d_leaves, d_scratch, scaled);
+        if (!rc) rc = leaf_hash_x(ctx, d_leaves, rows, width, d_nodes + 4 * rows, scaled);
+        if (!rc) rc = pk_merkle_inner(ctx, d_nodes, rows);
         return rc;
     }
     // rank g encodes and hashes the rows i = g (mod G) with no communication; ONE all-gather of the 32-byte leaf
@@ -115,8 +143,8 @@ int commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, un
     const size_t loc = rows / G;
     fe* dig_local = (fe*)d_scratch + width * (rows + 2 * loc);
     fe* gathered = dig_local + loc;
-    int rc = pk_rs_encode_shard(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, (unsigned)comm_rank(ctx), G, d_leaves, d_scratch);
-    if (!rc) rc = pk_leaf_hash(ctx, d_leaves, loc, width, PK_COL_MAJOR, (uint64_t*)dig_local);
+    int rc = rs_encode_shard_x(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, (unsigned)comm_rank(ctx), G, d_leaves, d_scratch, scaled);
+    if (!rc) rc = leaf_hash_x(ctx, d_leaves, loc, width, (uint64_t*)dig_local, scaled);
     if (!rc) rc = comm_all_gather(ctx, dig_local, gathered, loc * 32);
     if (rc) return rc;
     interleave_digests_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, ctx->stream>>>(gathered, (fe*)d_nodes, rows, G);
@@ -133,8 +161,9 @@ int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, siz
     t.width = width;
     t.owns_leaves = false;
     t.layout = PK_COL_MAJOR;
-    t.n_shards = shard_factor(ctx, n_leaves);  // the decision commit_into took for this tree
+    t.n_shards = shard_factor(ctx, n_leaves);  // the decisions commit_into took for this tree
     t.shard = t.n_shards > 1 ? (unsigned)comm_rank(ctx) : 0;
+    t.scaled = codeword_scaled(ctx, n_leaves);
     return pk_tree_open(ctx, &t, indices, k, canonical_leaves, leaves_out, sibling_digests, auth_paths);
 }
 }  // namespace pk
@@ -168,6 +197,7 @@ int pk_commit(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsi
     t->width = width;
     t->n_shards = shard_factor(ctx, rows);  // > 1: this context is one rank of a device set and keeps only its rows
     t->shard = t->n_shards > 1 ? (unsigned)comm_rank(ctx) : 0;
+    t->scaled = codeword_scaled(ctx, rows);
     int rc = PK_OK;
     if (hipMalloc((void**)&t->d_leaves, rows / t->n_shards * width * 32) != hipSuccess || hipMalloc((void**)&t->d_nodes, 2 * rows * 32) != hipSuccess) {
         pk_tree_destroy(ctx, t);
@@ -279,16 +309,16 @@ int pk_tree_open(pk_ctx* ctx, const pk_tree* t, const uint64_t* indices, size_t 
         fe* d_rows = (fe*)((char*)ctx->d_scratch + ((size_t)1 << 19));  // clear of the reduction area (head) and the PoW words (tail)
         PK_HIP(ctx, hipMemsetAsync(d_rows, 0, 32 * n1, ctx->stream));
         gather_owned_rows_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, ctx->stream>>>(t->d_leaves, t->n_leaves / t->n_shards, (unsigned)t->width, t->shard,
-                                                                                     t->n_shards, m_idx, k, canonical_leaves, d_rows);
+                                                                                     t->n_shards, m_idx, k, canonical_leaves, d_rows, t->scaled);
         PK_LAUNCH_CHECK(ctx);
         rc = comm_all_reduce_sum_u64(ctx, (uint64_t*)d_rows, 4 * n1);
         if (rc) return rc;
         PK_HIP(ctx, hipMemcpyAsync(m_leaves, d_rows, 32 * n1, hipMemcpyDeviceToHost, ctx->stream));
         if (n2) gather_opening_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, ctx->stream>>>(nullptr, t->d_nodes, t->n_leaves, 0, t->layout, logn, m_idx, k, 0,
-                                                                                          m_leaves, m_sib, m_path);
+                                                                                          m_leaves, m_sib, m_path, false);
     } else {
         gather_opening_kernel<<<(unsigned)((n1 + n2 + 255) / 256), 256, 0, ctx->stream>>>(t->d_leaves, t->d_nodes, t->n_leaves, (unsigned)t->width, t->layout,
-                                                                                          logn, m_idx, k, canonical_leaves, m_leaves, m_sib, m_path);
+                                                                                          logn, m_idx, k, canonical_leaves, m_leaves, m_sib, m_path, t->scaled);
     }
     PK_LAUNCH_CHECK(ctx);
     PK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // not sync_stream: the mailbox is read below
@@ -316,7 +346,7 @@ int pk_gather_leaves(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, siz
     fe* m_leaves = (fe*)(mail + idx_bytes);
     memcpy(m_idx, indices, k * 8);
     gather_opening_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, ctx->stream>>>((const fe*)d_leaves, nullptr, n_leaves, (unsigned)width, layout, 0, m_idx, k,
-                                                                                canonical_leaves, m_leaves, nullptr, nullptr);
+                                                                                canonical_leaves, m_leaves, nullptr, nullptr, false);
     PK_LAUNCH_CHECK(ctx);
     PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(leaves_out, m_leaves, 32 * n1);

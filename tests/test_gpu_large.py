@@ -77,16 +77,18 @@ def test_commit_2p26_batch2_against_definition_and_sharded_root(ctx, oracle):
         d_loc, d_dig = ctx.alloc_fe(width * loc), ctx.alloc_fe(loc)
         d_scr = ctx.alloc_fe(width * (rows + 2 * loc))
         all_dig = np.zeros((rows, 4), np.uint64)
-        t_leaves = C.c_void_p()
-        ctx._check(lib.pk_tree_info(tree, None, None, C.byref(t_leaves), None))
         for g in range(G):
             ctx._check(lib.pk_rs_encode_shard(ctx.handle, ptrs, batch, n_vars, rate, fold, g, G, d_loc.ptr, d_scr.ptr))
             ctx._check(lib.pk_leaf_hash(ctx.handle, d_loc.ptr, loc, width, PK_COL_MAJOR, d_dig.ptr))
             all_dig[g::G] = ctx.download_fe(d_dig, loc)
-            # shard row t is codeword row g + G t: compare one column segment with the unsharded matrix
-            got = ctx.download_fe(d_loc.view_fe(7 * loc), 64)
-            full = ctx.download_fe(t_leaves.value + 32 * (7 * rows), 64 * G)
-            assert np.array_equal(got, full[g::G])
+            # shard row t is codeword row g + G t: compare whole rows with openings of the unsharded tree
+            ts = np.array([0, 77, loc - 1], dtype=np.uint64)
+            got = np.zeros((len(ts), width, 4), np.uint64)
+            ctx._check(lib.pk_gather_leaves(ctx.handle, d_loc.ptr, loc, width, PK_COL_MAJOR, ts.ctypes.data, len(ts), 0, got.ctypes.data))
+            gi = (ts * np.uint64(G) + np.uint64(g)).astype(np.uint64)
+            lv, sb, pt = np.zeros((len(ts), width, 4), np.uint64), np.zeros((len(ts), 4), np.uint64), np.zeros((len(ts), plen, 4), np.uint64)
+            ctx._check(lib.pk_tree_open(ctx.handle, tree, gi.ctypes.data, len(ts), 0, lv.ctypes.data, sb.ctypes.data, pt.ctypes.data))
+            assert np.array_equal(got, lv)
         d_nodes = ctx.alloc_fe(2 * rows)
         ctx.upload_into(d_nodes.view_fe(rows), all_dig)
         ctx._check(lib.pk_merkle_inner(ctx.handle, d_nodes.ptr, rows))
