@@ -27,9 +27,11 @@ namespace {
 __device__ __forceinline__ fe sparse_row_dot(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ idx,
                                              const uint32_t* __restrict__ val, const fe* __restrict__ interner,
                                              const fe* __restrict__ x, size_t i) {
-    fe acc = fe_zero();
-    for (uint32_t k = ptr[i], e = ptr[i + 1]; k < e; k++) acc = fe_add(acc, fe_mulx(fe_load(interner + val[k]), fe_load(x + idx[k])));
-    return acc;
+    // the row's products share Montgomery reductions (fe29.hpp dot29): one per DOT29_GROUP entries
+    dot29 d;
+    dot29_init(d);
+    for (uint32_t k = ptr[i], e = ptr[i + 1]; k < e; k++) dot29_add(d, unpack29<0>(fe_load(interner + val[k])), unpack29<5>(fe_load(x + idx[k])));
+    return dot29_result(d);
 }
 
 // calculate_witness_bounds (provekit/common/src/utils/sumcheck.rs:181-193): a = A z, b = B z, c = a o b, zero-padded

@@ -54,6 +54,17 @@ PK_HD fe selftest_op(int op, const fe& x, const fe& y) {
             r = from_scaled_canon(h);
             break;
         }
+        case 20: {  // dot29: five products (one more than a reduction group): 3 x*y + x*x + y*y, Montgomery products, x, y < p
+            dot29 d;
+            dot29_init(d);
+            dot29_add(d, unpack29<0>(x), unpack29<5>(y));
+            dot29_add(d, unpack29<0>(y), unpack29<5>(x));
+            dot29_add(d, unpack29<0>(x), unpack29<5>(x));
+            dot29_add(d, unpack29<0>(y), unpack29<5>(y));
+            dot29_add(d, unpack29<0>(x), unpack29<5>(y));
+            r = dot29_result(d);
+            break;
+        }
         default: break;
     }
     return r;
@@ -144,10 +155,10 @@ int pk_selftest_permute(uint64_t l[4], uint64_t r[4]) {
 // op: 0 fe_mul29(a,b)  1 compress v2  2 compress v1  3 from_mont  4 a*b*2^-256 via mont256_29  5 a^2*2^-256 via sqr256_29
 // a, b, out: n field elements (4 x u64 each).  Host only; no device needed.
 int pk_selftest_arith(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-    if (!a || !out || (!b && (op == 0 || op == 1 || op == 2 || op == 4 || op == 15 || op == 16 || op == 19))) return PK_ERR_BAD_ARG;
+    if (!a || !out || (!b && (op == 0 || op == 1 || op == 2 || op == 4 || op == 15 || op == 16 || op == 19 || op == 20))) return PK_ERR_BAD_ARG;
     for (size_t i = 0; i < n; i++) {
         fe x = load_host(a + 4 * i), y = b ? load_host(b + 4 * i) : x;
-        if (op < 0 || op > 19) return PK_ERR_BAD_ARG;
+        if (op < 0 || op > 20) return PK_ERR_BAD_ARG;
         fe r = selftest_op(op, x, y);
         store_host(out + 4 * i, r);
     }

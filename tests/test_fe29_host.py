@@ -182,3 +182,11 @@ def test_scaled_fold_stays_in_domain(oracle):
     a, b = oracle.ints_to_limbs(xs), oracle.ints_to_limbs(ys)
     c = lambda u, v: np.frombuffer(oracle.compress_many(np.concatenate([u, v], axis=1).astype("<u8").tobytes()), dtype="<u8").reshape(-1, 4)
     assert np.array_equal(run(19, a, b), c(c(c(a, b), a), b))
+
+
+def test_grouped_dot_product(oracle):
+    """fe29.hpp dot29 (one Montgomery reduction per group of products): 3xy + x^2 + y^2 as Montgomery products"""
+    xs, ys = rand_fe(4000, 71) + [0, P - 1, 1, P - 1], rand_fe(4000, 72) + [0, P - 1, P - 1, 1]
+    rinv = pow(1 << 256, -1, P)
+    a, b = oracle.ints_to_limbs(xs), oracle.ints_to_limbs(ys)
+    assert oracle.limbs_to_ints(run(20, a, b)) == [(3 * x * y + x * x + y * y) * rinv % P for x, y in zip(xs, ys)]
