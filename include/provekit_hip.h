@@ -244,6 +244,13 @@ typedef struct pk_sparse_matrix {
 } pk_sparse_matrix;
 int pk_r1cs_create(pk_ctx *ctx, size_t num_constraints, size_t num_witnesses, const pk_sparse_matrix mats[3],
                    const uint64_t *interner, size_t n_interned, pk_r1cs **out);
+/* The same upload from the postcard bytes of the reference's `R1CS` (provekit/common/src/r1cs.rs:8-14 with the serde impls of
+ * sparse_matrix.rs:12-27 and interner.rs:6-13; postcard is the encoding of the reference's own .nps files,
+ * file/bin.rs:22-71).  This is how a Rust caller passes an R1CS: SparseMatrix keeps its three arrays private, but
+ * `postcard::to_allocvec(&scheme.r1cs)` is available to any crate.  Interned values arrive canonical (ark-serialize) and
+ * are converted to Montgomery form here.  *consumed = bytes read (an R1CS embedded in a longer stream). */
+int pk_r1cs_from_postcard(pk_ctx *ctx, const uint8_t *bytes, size_t len, pk_r1cs **out, size_t *num_constraints,
+                          size_t *num_witnesses, size_t *num_public_inputs, size_t *consumed);
 int pk_r1cs_destroy(pk_ctx *ctx, pk_r1cs *r1cs);
 /* calculate_witness_bounds (sumcheck.rs:181-193): a = A z, b = B z, c = a o b, each zero-padded to 2^m0 */
 int pk_r1cs_witness_bounds(pk_ctx *ctx, const pk_r1cs *r1cs, const uint64_t *d_z, unsigned m0, uint64_t *d_a,

@@ -100,6 +100,7 @@ SIGNATURES = {
     "pk_fold_coeffs": (C.c_int, [vp, vp, C.c_uint, vp, C.c_uint, vp]),
     "pk_fe_axpy": (C.c_int, [vp, vp, vp, vp, sz]),
     "pk_r1cs_create": (C.c_int, [vp, sz, sz, vp, vp, sz, C.POINTER(vp)]),
+    "pk_r1cs_from_postcard": (C.c_int, [vp, vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
     "pk_r1cs_destroy": (C.c_int, [vp, vp]),
     "pk_r1cs_witness_bounds": (C.c_int, [vp, vp, vp, C.c_uint, vp, vp, vp]),
     "pk_r1cs_matvec": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp]),

@@ -166,6 +166,94 @@ int pk_r1cs_create(pk_ctx* ctx, size_t num_constraints, size_t num_witnesses, co
     return PK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// R1CS from its postcard bytes.  The reference's SparseMatrix keeps new_row_indices / col_indices / values private
+// (provekit/common/src/sparse_matrix.rs:12-27), so a Rust caller cannot hand their pointers to pk_r1cs_create; what it can
+// do is serialise `&R1CS` with the serde impls the reference derives -- postcard, the encoding of its own .nps files
+// (provekit/common/src/file/bin.rs:22-71) -- and pass the bytes.  Layout (postcard: usize / u32 = LEB128 varint, Vec<T> =
+// varint length + items, bytes = varint length + raw):
+//   R1CS { num_public_inputs: usize, interner: Interner, a, b, c: SparseMatrix }                    (r1cs.rs:8-14)
+//   Interner { values: serde_ark(Vec<FieldElement>) } = bytes( u64-LE count | count x 32-byte canonical LE )   (interner.rs:6-10,
+//                                                                               utils/serde_ark.rs:11-31, ark-serialize compressed)
+//   SparseMatrix { num_rows, num_cols: usize, new_row_indices: Vec<u32>, col_indices: Vec<u32>, values: Vec<usize> }
+namespace {
+struct PcReader {
+    const uint8_t* p;
+    size_t n, off = 0;
+    bool ok = true;
+    uint64_t varint() {
+        uint64_t v = 0;
+        for (unsigned shift = 0; shift < 70; shift += 7) {
+            if (off >= n) return ok = false, 0;
+            const uint8_t b = p[off++];
+            if (shift == 63 && b > 1) return ok = false, 0;
+            v |= (uint64_t)(b & 0x7f) << shift;
+            if (!(b & 0x80)) return v;
+        }
+        return ok = false, 0;
+    }
+    bool vec_u32(std::vector<uint32_t>& out) {
+        const uint64_t len = varint();
+        if (!ok || len > n - off) return ok = false;  // every item takes at least one byte
+        out.resize(len);
+        for (uint64_t i = 0; i < len; i++) {
+            const uint64_t v = varint();
+            if (!ok || v > 0xffffffffull) return ok = false;
+            out[i] = (uint32_t)v;
+        }
+        return true;
+    }
+};
+}  // namespace
+
+int pk_r1cs_from_postcard(pk_ctx* ctx, const uint8_t* bytes, size_t len, pk_r1cs** out, size_t* num_constraints, size_t* num_witnesses,
+                          size_t* num_public_inputs, size_t* consumed) {
+    if (!ctx || !out) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
+    *out = nullptr;
+    PK_REQUIRE(ctx, bytes, "null pointer");
+    PcReader rd{bytes, len};
+    const uint64_t n_pub = rd.varint();
+    // interner: bytes( u64 count | count * 32 )
+    const uint64_t blob = rd.varint();
+    PK_REQUIRE(ctx, rd.ok && blob >= 8 && blob <= len - rd.off, "postcard R1CS: truncated interner");
+    uint64_t count = 0;
+    memcpy(&count, bytes + rd.off, 8);
+    PK_REQUIRE(ctx, count <= (blob - 8) / 32 && blob == 8 + 32 * count, "postcard R1CS: interner length mismatch (\"trailing bytes\")");
+    std::vector<uint64_t> interner(4 * (size_t)count);
+    {  // canonical -> Montgomery on the host (Fp::deserialize_compressed rejects values >= p)
+        const uint8_t* q = bytes + rd.off + 8;
+        for (size_t i = 0; i < count; i++) {
+            fe c;
+            memcpy(c.v, q + 32 * i, 32);
+            fe red = fe_reduce_any(c);
+            PK_REQUIRE(ctx, memcmp(red.v, c.v, 32) == 0, "postcard R1CS: interned value is not a canonical field element");
+            fe m = fe_to_montx(c);
+            memcpy(&interner[4 * i], m.v, 32);
+        }
+    }
+    rd.off += blob;
+    std::vector<uint32_t> nri[3], ci[3], vv[3];
+    uint64_t rows[3], cols[3];
+    for (int m = 0; m < 3; m++) {
+        rows[m] = rd.varint();
+        cols[m] = rd.varint();
+        PK_REQUIRE(ctx, rd.ok && rd.vec_u32(nri[m]) && rd.vec_u32(ci[m]) && rd.vec_u32(vv[m]), "postcard R1CS: truncated or malformed matrix");
+        PK_REQUIRE(ctx, nri[m].size() == rows[m], "postcard R1CS: new_row_indices does not have one entry per row");
+        PK_REQUIRE(ctx, vv[m].size() == ci[m].size(), "postcard R1CS: values and col_indices differ in length");
+        PK_REQUIRE(ctx, rows[m] == rows[0] && cols[m] == cols[0], "postcard R1CS: A, B, C differ in shape");
+    }
+    pk_sparse_matrix mats[3];
+    for (int m = 0; m < 3; m++) mats[m] = pk_sparse_matrix{nri[m].data(), ci[m].data(), vv[m].data(), ci[m].size()};
+    int rc = pk_r1cs_create(ctx, (size_t)rows[0], (size_t)cols[0], mats, interner.data(), (size_t)count, out);
+    if (rc) return rc;
+    if (num_constraints) *num_constraints = (size_t)rows[0];
+    if (num_witnesses) *num_witnesses = (size_t)cols[0];
+    if (num_public_inputs) *num_public_inputs = (size_t)n_pub;
+    if (consumed) *consumed = rd.off;
+    return PK_OK;
+}
+
 int pk_r1cs_witness_bounds(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, unsigned m0, uint64_t* d_a, uint64_t* d_b,
                            uint64_t* d_c) {
     PK_ENTER(ctx);

@@ -65,6 +65,20 @@ class R1CS:
                                       it.shape[0], C.byref(h)))
         self.handle = h.value
 
+    @classmethod
+    def from_postcard(cls, ctx: Context, data: bytes) -> "R1CS":
+        """upload from postcard(R1CS), the bytes a Rust caller gets from `postcard::to_allocvec(&scheme.r1cs)`
+        (pk_r1cs_from_postcard; layout in provekit_amd/file.py)"""
+        self = cls.__new__(cls)
+        self.ctx, self._keep = ctx, []
+        h = C.c_void_p()
+        nc, nw, npub, used = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        ctx._check(lib.pk_r1cs_from_postcard(ctx.handle, buf, len(data), C.byref(h), C.byref(nc), C.byref(nw), C.byref(npub), C.byref(used)))
+        self.handle = h.value
+        self.num_constraints, self.num_witnesses, self.num_public_inputs, self.bytes_consumed = nc.value, nw.value, npub.value, used.value
+        return self
+
     def close(self):
         if self.handle is not None and self.ctx.handle is not None:
             lib.pk_r1cs_destroy(self.ctx.handle, self.handle)

@@ -56,3 +56,39 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pk_oracle" not in txt and "pyref" not in txt and "oracle_lib" not in txt, f
+
+
+def test_rust_sys_bindings_match_the_header():
+    """rust/provekit-prover-hip/src/sys.rs is generated from include/provekit_hip.h (tools/gen_rust_sys.py): the checked-in
+    file must be current, declare every symbol of the header, and lib.rs must call only functions it declares with the
+    number of arguments it declares (there is no Rust toolchain here to compile the crate)."""
+    import subprocess
+    import sys
+
+    gen = os.path.join(ROOT, "tools", "gen_rust_sys.py")
+    assert subprocess.run([sys.executable, gen, "--check"]).returncode == 0, "rust sys.rs is stale: run tools/gen_rust_sys.py"
+    sys_rs = open(os.path.join(ROOT, "rust", "provekit-prover-hip", "src", "sys.rs")).read()
+    decls = dict(re.findall(r"pub fn (pk_\w+)\((.*?)\) ->", sys_rs))
+    assert sorted(decls) == declared_symbols()
+    lib_rs = open(os.path.join(ROOT, "rust", "provekit-prover-hip", "src", "lib.rs")).read()
+    calls = re.findall(r"sys::(pk_\w+)\s*\(", lib_rs)
+    assert len(set(calls)) >= 10
+    for name in set(calls):
+        assert name in decls, f"lib.rs calls {name}, which the header does not declare"
+    # argument counts of the calls (balanced-parenthesis scan of the call's argument list)
+    for m in re.finditer(r"sys::(pk_\w+)\s*\(", lib_rs):
+        depth, i, n_args, seen = 1, m.end(), 0, False
+        while depth:
+            ch = lib_rs[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            elif ch == "," and depth == 1:
+                n_args += 1
+            if not ch.isspace() and depth:
+                seen = True
+            i += 1
+        n_args = n_args + 1 if seen else 0
+        want = len([a for a in decls[m.group(1)].split(",") if a.strip()])
+        assert n_args == want, f"{m.group(1)}: lib.rs passes {n_args} arguments, the header declares {want}"

@@ -163,3 +163,33 @@ def test_commit_full_size(ctx, oracle):
             k >>= 1
         assert h.tobytes() == c.root
     c.close()
+
+
+def test_r1cs_from_postcard_matches_direct_upload(ctx, oracle):
+    """pk_r1cs_from_postcard (the Rust caller's route: postcard::to_allocvec(&scheme.r1cs)) builds the same device R1CS as
+    pk_r1cs_create: identical products; malformed bytes are rejected, never read out of bounds"""
+    from provekit_amd import ProveKitHipError
+    from provekit_amd import file as F
+    from provekit_amd.field import random_field
+    from provekit_amd.sparse_matrix import R1CS
+
+    nc, nw = 700, 500
+    a, b, c = synth_r1cs(nc, nw, 77)
+    interner_canon = [int(x) for x in np.random.default_rng(1).integers(1, 2**62, size=17)]
+    interner = oracle.to_mont(oracle.ints_to_limbs(interner_canon))
+    direct = R1CS(ctx, a, b, c, interner)
+    blob = F.encode_r1cs_postcard(2, interner_canon, [(nc, nw, m.new_row_indices, m.col_indices, m.values) for m in (a, b, c)])
+    viapc = R1CS.from_postcard(ctx, blob)
+    assert (viapc.num_constraints, viapc.num_witnesses, viapc.num_public_inputs, viapc.bytes_consumed) == (nc, nw, 2, len(blob))
+    z = ctx.upload(random_field(nw, 3))
+    m0 = 10
+    for x, y in zip(direct.calculate_witness_bounds(z, m0), viapc.calculate_witness_bounds(z, m0)):
+        assert np.array_equal(ctx.download_fe(x, 1 << m0), ctx.download_fe(y, 1 << m0))
+    eq = ctx.upload(random_field(1 << m0, 4))
+    assert np.array_equal(ctx.download_fe(direct.calculate_external_row_of_r1cs_matrices(eq), 3 * nw),
+                          ctx.download_fe(viapc.calculate_external_row_of_r1cs_matrices(eq), 3 * nw))
+    for bad in (blob[: len(blob) // 2], blob[:1] + b"\xff\xff\xff\xff\xff\xff\xff\xff\xff\x7f" + blob[2:], b""):
+        with pytest.raises(ProveKitHipError):
+            R1CS.from_postcard(ctx, bad if bad else b"\x00")
+    direct.close()
+    viapc.close()
