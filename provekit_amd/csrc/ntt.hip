@@ -78,6 +78,14 @@ __global__ __launch_bounds__(256) void twiddle_scale_kernel(const fe* __restrict
     fe_store(Ws + j, fe_mulx(fe_load(W + j), c));
 }
 
+__global__ __launch_bounds__(256) void twiddle_unpack_kernel(const fe* __restrict__ W, u32* __restrict__ W29, size_t n) {
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    fe29 t = unpack29<5>(fe_load(W + j));
+#pragma unroll
+    for (int l = 0; l < 9; l++) W29[9 * j + l] = t.v[l];
+}
+
 struct PassParams {
     const fe* in;
     fe* out;
@@ -89,6 +97,10 @@ struct PassParams {
     size_t in_nat_r, in_nat_v, in_nat_u;  // natural-index weights for the zero test
     const fe* W;        // w_N^e table, N entries
     const fe* Wtw;      // table the inter-pass twiddle is read from: W, or its hash-ready variant 32*w_N^e (see ntt_columns)
+    const u32* W29;     // W again, every entry already in the multiplier's operand form (9 limbs of 32*w): register-radix kernel
+    const u32* Wtw29;   // Wtw likewise
+    int lazy_store;     // outputs may be stored almost reduced (< 1.6p) instead of canonical: intermediate passes, and the
+                        // hash-ready final pass (its consumers reduce anyway)
     size_t n_mask;      // N - 1
     size_t tw_mul;      // twiddle exponent = tw_mul * k * v  (0 = no twiddle)
     size_t wr_step;     // w_R^j = W[j * wr_step]
@@ -220,6 +232,14 @@ __device__ __forceinline__ fe29 sub2p29(const fe29& a, const fe29& b) {
     return r;
 }
 __device__ __forceinline__ fe29 tw29(const fe* W, size_t idx) { return unpack29<5>(fe_load(W + idx)); }
+// the same operand from the pre-unpacked table (36 bytes per entry): no shifting and masking per multiplication
+__device__ __forceinline__ fe29 tw29u(const u32* __restrict__ W29, size_t idx) {
+    const u32* q = W29 + 9 * idx;
+    fe29 t;
+#pragma unroll
+    for (int l = 0; l < 9; l++) t.v[l] = q[l];
+    return t;
+}
 
 template <int D>  // radix-2^D DIF over the top D bits of the register index; low 3-D bits are independent batches
 __device__ __forceinline__ void dft_regs(fe29 (&x)[8], const fe29& w8_1, const fe29& w8_2, const fe29& w8_3) {
@@ -304,7 +324,7 @@ __device__ __forceinline__ void ntt8_round(fe29 (&x)[8], const PassParams& p, co
             constexpr int dummy = 0;
             (void)dummy;
             const int a = bitrev_c(reg >> E, D);
-            fe29 y = a == 0 ? red29(x[reg]) : mont261_29(x[reg], tw29(p.W, (size_t)(a * m) * unit));
+            fe29 y = a == 0 ? red29(x[reg]) : mont261_29(x[reg], tw29u(p.W29, (size_t)(a * m) * unit));
             const int I = (PK_TILE_INDEX(reg) & ~(((1 << D) - 1) << POS)) | (a << POS);  // keep the true frequency digit
 #pragma unroll
             for (int l = 0; l < 9; l++) planes[l * 2048 + I] = y.v[l];
@@ -324,11 +344,11 @@ __device__ __forceinline__ void ntt8_round(fe29 (&x)[8], const PassParams& p, co
             fe29 y;
             if (p.tw_mul) {
                 size_t ex = (p.tw_mul * (size_t)k * (c.v0 + b)) & p.n_mask;
-                y = mont261_29(x[reg], tw29(p.Wtw, ex));
+                y = mont261_29(x[reg], tw29u(p.Wtw29, ex));
             } else {
                 y = red29(x[reg]);
             }
-            fe_store(c.out + (size_t)k * p.out_stride_r + (size_t)b * p.out_stride_v, pack29(cond_sub_p29(y)));
+            fe_store(c.out + (size_t)k * p.out_stride_r + (size_t)b * p.out_stride_v, pack29(p.lazy_store ? y : cond_sub_p29(y)));
         }
     }
 #undef PK_TILE_INDEX
@@ -349,7 +369,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     c.nat0 = u * p.in_nat_u + c.v0 * p.in_nat_v;
     c.tid = threadIdx.x;
     const size_t N8 = (p.n_mask + 1) >> 3;
-    const fe29 w8_1 = tw29(p.W, N8), w8_2 = tw29(p.W, 2 * N8), w8_3 = tw29(p.W, 3 * N8);
+    const fe29 w8_1 = tw29u(p.W29, N8), w8_2 = tw29u(p.W29, 2 * N8), w8_3 = tw29u(p.W29, 3 * N8);
     fe29 x[8];
     ntt8_round<LOG_R, 0>(x, p, c, planes, w8_1, w8_2, w8_3);
     if (NR > 1) ntt8_round<LOG_R, (NR > 1 ? 1 : 0)>(x, p, c, planes, w8_1, w8_2, w8_3);
@@ -453,6 +473,23 @@ int get_twiddles_scaled(pk_ctx* ctx, unsigned log_n, const fe* W, const fe** out
     return PK_OK;
 }
 
+int get_twiddles29(pk_ctx* ctx, unsigned log_n, int which, const fe* W, const u32** out) {
+    auto& cache = ctx->twiddles29[which];
+    auto it = cache.find(log_n);
+    if (it != cache.end()) {
+        *out = (const u32*)it->second;
+        return PK_OK;
+    }
+    const size_t n = (size_t)1 << log_n;
+    u32* T = nullptr;
+    PK_HIP(ctx, hipMalloc((void**)&T, 36 * (n < 2 ? 2 : n)));
+    twiddle_unpack_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(W, T, n);
+    PK_LAUNCH_CHECK(ctx);
+    cache[log_n] = T;
+    *out = T;
+    return PK_OK;
+}
+
 // does a pass of radix 2^log_r over a v axis of 2^log_v take the register-radix kernel?
 inline bool pass_is_fast(unsigned log_r, unsigned log_v, size_t N) { return log_r >= 3 && log_v < 62 && log_v >= 11 - log_r && N >= 8; }
 
@@ -523,6 +560,10 @@ void ntt_release_ctx(pk_ctx* ctx) {
     ctx->twiddles.clear();
     for (auto& kv : ctx->twiddles_scaled) (void)hipFree(kv.second);
     ctx->twiddles_scaled.clear();
+    for (auto& c : ctx->twiddles29) {
+        for (auto& kv : c) (void)hipFree(kv.second);
+        c.clear();
+    }
 }
 
 // Can a transform of this size deliver the hash-ready output (every output = 32 * value as a plain integer < p instead of
@@ -553,9 +594,18 @@ int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero,
     if (rc) return rc;
     const fe* Ws = W;
     if (scaled_out && (rc = get_twiddles_scaled(ctx, log_n, W, &Ws))) return rc;
+    const u32 *W29 = nullptr, *Ws29 = nullptr;
+    if (log_n >= 3) {  // the register-radix kernel's operand tables
+        if ((rc = get_twiddles29(ctx, log_n, 0, W, &W29))) return rc;
+        Ws29 = W29;
+        if (scaled_out && (rc = get_twiddles29(ctx, log_n, 1, Ws, &Ws29))) return rc;
+    }
     PassParams p{};
     p.W = W;
     p.Wtw = W;
+    p.W29 = W29;
+    p.Wtw29 = W29;
+    p.lazy_store = 0;
     p.n_mask = N - 1;
     if (log_n <= 9) {
         // single pass: R = N and the tile's batch axis v runs over BT adjacent *columns*
@@ -612,10 +662,14 @@ int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero,
         p.nonzero = nonzero;
         p.tw_mul = 1;
         p.Wtw = Ws;  // the only inter-pass twiddle of a two-pass transform carries the output scaling
+        p.Wtw29 = Ws29;
+        p.lazy_store = pass_is_fast(l2, l1, N);  // the register-radix kernel takes almost reduced inputs
         p.wr_step = N >> l1;
         rc = launch_pass(ctx, l1, p, false, R2 / BT, ncols);
         if (rc) return rc;
         p.Wtw = W;
+        p.Wtw29 = W29;
+        p.lazy_store = scaled_out ? 1 : 0;
         // pass 2: DFT over n2 (contiguous); v = k1 (in stride R2, out stride 1); out k2 stride R1
         p.in = scratch;
         p.out = out;
@@ -644,6 +698,7 @@ int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero,
     p.in_nat_r = R2 * R3; p.in_nat_v = 1; p.in_nat_u = 0;
     p.nonzero = nonzero;
     p.tw_mul = 1;
+    p.lazy_store = pass_is_fast(l2, l3, N);
     p.wr_step = N >> l1;
     rc = launch_pass(ctx, l1, p, false, (R2 * R3) / BT, ncols);
     if (rc) return rc;
@@ -659,10 +714,14 @@ int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero,
     p.nonzero = 1;
     p.tw_mul = R1;
     p.Wtw = Ws;  // the last inter-pass twiddle carries the output scaling
+    p.Wtw29 = Ws29;
+    p.lazy_store = pass_is_fast(l3, l1, N);
     p.wr_step = N >> l2;
     rc = launch_pass(ctx, l2, p, false, R1 * (R3 / BT), ncols);
     if (rc) return rc;
     p.Wtw = W;
+    p.Wtw29 = W29;
+    p.lazy_store = scaled_out ? 1 : 0;
     // pass 3: DFT over n3 (contiguous); v = k1 (in stride R2*R3, out stride 1); u = k2 (in stride R3, out stride R1)
     p.in = scratch;
     p.out = out;
