@@ -550,7 +550,7 @@ def main():
             "config": {
                 "workload": f"poseidon-rounds size class: m={m}, m_0={m_0}, batch-2 WHIR commit + zk-sumcheck + {cfg_w.n_rounds}-round WHIR opening, "
                             f"queries {cfg_w.num_queries}/{cfg_w.final_queries}, pow_bits {cfg_w.pow_bits}/{cfg_w.final_pow_bits} (WhirConfig::new derivation, security 128, "
-                            f"ConjectureList), blinding WHIR n={cfg_b.n_vars} queries {cfg_b.num_queries}/{cfg_b.final_queries}, Skyscraper-sponge transcript, ChaCha20 masks",
+                            f"ConjectureList), blinding WHIR n={cfg_b.n_vars} queries {cfg_b.num_queries}/{cfg_b.final_queries}, Skyscraper-sponge transcript, ChaCha12 masks",
                 "proofs_per_step": conc * (1 if args.sharded else world),
                 "parallelism": (f"one step = one proof, sharded over {world} GPU(s): every commit of >= 64 rows per rank split by leaf index, "
                                 "RCCL all-gather of leaf digests + all-reduce of opened rows behind the C ABI; the rest of the proof is "

@@ -324,7 +324,7 @@ int pk_multipath_serialize(const uint64_t *indices, size_t k, size_t path_len, c
  * Randomness: the reference takes the ZK mask, the random polynomial and the blinding univariates from thread_rng
  * (provekit/common/src/utils/zk_utils.rs:13-22, provekit/prover/src/whir_r1cs.rs:197,212-221).  With
  * rng_seed32 == NULL (production) pk_prove draws a fresh 256-bit key from the OS CSPRNG (getrandom) for every proof
- * and expands it on the device with ChaCha20 + rejection sampling; a non-NULL rng_seed32 (32 bytes) injects the key
+ * and expands it on the device with ChaCha12 (the cipher of rand's ThreadRng) + rejection sampling; a non-NULL rng_seed32 (32 bytes) injects the key
  * instead -- a TEST HOOK for reproducible transcripts, never to be used with a fixed value in deployment. */
 #define PK_MAX_WHIR_ROUNDS 16
 typedef struct pk_whir_config {
@@ -368,10 +368,11 @@ int pk_scheme_domain_separator(const pk_scheme *scheme, char *buf, size_t cap, s
 int pk_selftest_keccak_tag(const uint8_t *data, size_t len, uint8_t tag[32]);
 int pk_selftest_permute(uint64_t l[4], uint64_t r[4]);
 int pk_selftest_arith(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
-/* the proof RNG: one ChaCha20 block (host; RFC 8439 state layout, words 12-13 = counter, 14-15 = nonce) and the device
- * draw of n uniform field elements for (seed32, stream) -- element i = first candidate < p of blocks (counter i, nonce
- * {stream, attempt}), two 254-bit candidates per block */
-int pk_selftest_chacha20(const uint8_t key[32], uint64_t counter, uint32_t n0, uint32_t n1, uint8_t out[64]);
+/* the proof RNG: one ChaCha block (host; RFC 8439 state layout, words 12-13 = counter, 14-15 = nonce; `rounds` = 20 for the
+ * RFC's vectors, 12 is what the library runs -- rand's ThreadRng cipher) and the device draw of n uniform field elements
+ * for (seed32, stream): elements 2j, 2j+1 take the first / second 254-bit candidate of blocks (counter j, nonce {stream,
+ * attempt}), attempt = 0, 1, ... until the candidate is < p */
+int pk_selftest_chacha(const uint8_t key[32], uint64_t counter, uint32_t n0, uint32_t n1, int rounds, uint8_t out[64]);
 int pk_selftest_random_fe(pk_ctx *ctx, const uint8_t seed32[32], uint32_t stream, uint64_t *d_out, size_t n);
 /* the same ops run by a kernel on device buffers (device-vs-host codegen diff in the GPU suite) */
 int pk_selftest_arith_device(pk_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n);

@@ -127,7 +127,7 @@ SIGNATURES = {
     "pk_selftest_keccak_tag": (C.c_int, [vp, sz, vp]),
     "pk_selftest_permute": (C.c_int, [vp, vp]),
     "pk_selftest_arith": (C.c_int, [C.c_int, vp, vp, vp, sz]),
-    "pk_selftest_chacha20": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, vp]),
+    "pk_selftest_chacha": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, vp]),
     "pk_selftest_random_fe": (C.c_int, [vp, vp, C.c_uint32, vp, sz]),
     "pk_selftest_arith_device": (C.c_int, [vp, C.c_int, vp, vp, vp, sz]),
     "pk_selftest_modmul_rate": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),

@@ -49,28 +49,30 @@ struct pk_scheme {
 namespace {
 
 // ------------------------------------------------------------------ device CSPRNG
-// The reference draws the ZK mask, the random polynomial g and the Spartan blinding univariates from thread_rng, a
-// ChaCha-based CSPRNG seeded from the OS (provekit/common/src/utils/zk_utils.rs:13-22, provekit/prover/src/whir_r1cs.rs:197,
-// 212-221).  Here: one 256-bit key per proof (getrandom(2) inside pk_prove unless the caller injects a seed -- a test hook),
-// expanded on the device with the ChaCha20 block function (RFC 8439 quarter rounds, 20 rounds): element i of draw `stream`
-// takes block (counter = i, nonce = {stream, attempt}); a block yields two 254-bit candidates, accepted iff < p -- the same
-// rejection sampling ark-ff's Fp::rand does, so every element is uniform on [0, p).
+// The reference draws the ZK mask, the random polynomial g and the Spartan blinding univariates from thread_rng
+// (provekit/common/src/utils/zk_utils.rs:13-22, provekit/prover/src/whir_r1cs.rs:197,212-221): rand's ThreadRng, i.e. ChaCha12
+// seeded from the OS.  Here: one 256-bit key per proof (getrandom(2) inside pk_prove unless the caller injects a seed -- a test
+// hook), expanded on the device with the same cipher -- the ChaCha block function (RFC 8439 quarter rounds and state layout),
+// 12 rounds.  Elements 2j and 2j+1 of draw `stream` share the blocks (counter = j, nonce = {stream, attempt}): a block holds
+// two 254-bit candidates, the first for element 2j, the second for 2j+1, each accepted iff < p (what ark-ff's Fp::rand does,
+// so every element is uniform on [0, p)); an element whose candidate was rejected takes its candidate of the next attempt.
 struct RngKey {
     u32 k[8];
 };
+constexpr int PK_RNG_ROUNDS = 12;
 #define PK_QR(a, b, c, d)                    \
     a += b; d ^= a; d = (d << 16) | (d >> 16); \
     c += d; b ^= c; b = (b << 12) | (b >> 20); \
     a += b; d ^= a; d = (d << 8) | (d >> 24);  \
     c += d; b ^= c; b = (b << 7) | (b >> 25)
-__host__ __device__ __forceinline__ void chacha20_block(const RngKey& key, u64 counter, u32 n0, u32 n1, u32 (&out)[16]) {
+__host__ __device__ __forceinline__ void chacha_block(const RngKey& key, u64 counter, u32 n0, u32 n1, int rounds, u32 (&out)[16]) {
     u32 s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3],
                  key.k[4],    key.k[5],    key.k[6],    key.k[7],    (u32)counter, (u32)(counter >> 32), n0, n1};
     u32 x[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] = s[i];
 #pragma unroll 1
-    for (int r = 0; r < 10; r++) {
+    for (int r = 0; r < rounds / 2; r++) {
         PK_QR(x[0], x[4], x[8], x[12]);
         PK_QR(x[1], x[5], x[9], x[13]);
         PK_QR(x[2], x[6], x[10], x[14]);
@@ -84,17 +86,17 @@ __host__ __device__ __forceinline__ void chacha20_block(const RngKey& key, u64 c
     for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
 }
 #undef PK_QR
-// uniform field elements by rejection (accept probability p / 2^254 = 0.76 per candidate); any value < p is a valid Montgomery image
 __global__ __launch_bounds__(256) void random_fe_kernel(fe* __restrict__ out, size_t n, RngKey key, u32 stream) {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        fe x;
-        bool done = false;
-        for (u32 attempt = 0; !done; attempt++) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, pairs = (n + 1) / 2;
+    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < pairs; j += stride) {
+        bool done[2] = {false, 2 * j + 1 >= n};
+        for (u32 attempt = 0; !(done[0] && done[1]); attempt++) {
             u32 blk[16];
-            chacha20_block(key, (u64)i, stream, attempt, blk);
+            chacha_block(key, (u64)j, stream, attempt, PK_RNG_ROUNDS, blk);
 #pragma unroll
-            for (int half = 0; half < 2 && !done; half++) {
+            for (int half = 0; half < 2; half++) {
+                if (done[half]) continue;
+                fe x;
 #pragma unroll
                 for (int w = 0; w < 8; w++) x.v[w] = blk[8 * half + w];
                 x.v[7] &= 0x3fffffffu;  // < 2^254
@@ -104,10 +106,12 @@ __global__ __launch_bounds__(256) void random_fe_kernel(fe* __restrict__ out, si
                     u64 t = (u64)x.v[k] - kPlimb(k) - borrow;
                     borrow = (u32)(t >> 32) & 1u;
                 }
-                done = borrow != 0;  // x < p
+                if (borrow) {  // x < p: accepted
+                    fe_store(out + 2 * j + half, x);
+                    done[half] = true;
+                }
             }
         }
-        fe_store(out + i, x);
     }
 }
 // draws of one proof (the `stream` word of the nonce)
@@ -830,13 +834,14 @@ int pk_whir_config_derive(unsigned n_vars, unsigned batch_size, unsigned folding
     return PK_OK;
 }
 
-// host-only: one ChaCha20 block of the proof RNG (RFC 8439 layout: words 12,13 = counter, 14,15 = nonce)
-int pk_selftest_chacha20(const uint8_t key[32], uint64_t counter, uint32_t n0, uint32_t n1, uint8_t out[64]) {
-    if (!key || !out) return PK_ERR_BAD_ARG;
+// host-only: one block of the proof RNG's cipher (RFC 8439 layout: words 12,13 = counter, 14,15 = nonce); rounds = 20 for
+// the RFC's vectors, 12 (PK_RNG_ROUNDS) for what random_fe_kernel runs
+int pk_selftest_chacha(const uint8_t key[32], uint64_t counter, uint32_t n0, uint32_t n1, int rounds, uint8_t out[64]) {
+    if (!key || !out || rounds < 2 || (rounds & 1)) return PK_ERR_BAD_ARG;
     RngKey k;
     memcpy(k.k, key, 32);
     u32 blk[16];
-    chacha20_block(k, counter, n0, n1, blk);
+    chacha_block(k, counter, n0, n1, rounds, blk);
     memcpy(out, blk, 64);
     return PK_OK;
 }

@@ -1,4 +1,4 @@
-"""GPU: the proof RNG (ChaCha20-keyed rejection sampling, provekit_amd/csrc/prover.hip) against its Python restatement, and
+"""GPU: the proof RNG (ChaCha12-keyed rejection sampling, provekit_amd/csrc/prover.hip) against its Python restatement, and
 the production path of pk_prove (fresh OS randomness per proof)."""
 import ctypes as C
 

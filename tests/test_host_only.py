@@ -68,7 +68,7 @@ def test_whir_config_derivation_matches_the_fixture_shape():
         assert all(q * r + p >= 128 - 1e-9 for q, r, p in zip(c.num_queries, range(1, 40, 3), c.pow_bits))
 
 
-def _chacha20_block_py(key: bytes, counter: int, n0: int, n1: int) -> bytes:
+def _chacha_block_py(key: bytes, counter: int, n0: int, n1: int, rounds: int) -> bytes:
     """RFC 8439 section 2.3, restated independently (state words 12, 13 = 64-bit counter, 14, 15 = nonce)"""
     import struct
 
@@ -83,44 +83,50 @@ def _chacha20_block_py(key: bytes, counter: int, n0: int, n1: int) -> bytes:
         x[a] = (x[a] + x[b]) & M; x[d] = rotl(x[d] ^ x[a], 8)
         x[c] = (x[c] + x[d]) & M; x[b] = rotl(x[b] ^ x[c], 7)
 
-    for _ in range(10):
+    for _ in range(rounds // 2):
         qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
         qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
     return struct.pack("<16I", *[(a + b) & M for a, b in zip(x, s)])
 
 
 def random_fe_py(seed32: bytes, stream: int, i: int) -> int:
-    """element i of the proof RNG's draw `stream`: first candidate < p (two 254-bit candidates per block)"""
+    """element i of the proof RNG's draw `stream`: candidate (i mod 2) of the blocks (counter i // 2, nonce {stream, attempt}),
+    attempt = 0, 1, ... until it is < p; 12 rounds"""
     P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
-    attempt = 0
+    attempt, half = 0, i & 1
     while True:
-        blk = _chacha20_block_py(seed32, i, stream, attempt)
-        for half in range(2):
-            v = int.from_bytes(blk[32 * half : 32 * half + 32], "little") & ((1 << 254) - 1)
-            if v < P:
-                return v
+        blk = _chacha_block_py(seed32, i >> 1, stream, attempt, 12)
+        v = int.from_bytes(blk[32 * half : 32 * half + 32], "little") & ((1 << 254) - 1)
+        if v < P:
+            return v
         attempt += 1
 
 
-def test_chacha20_block_rfc8439_vector():
-    """the proof RNG's block function against RFC 8439 section 2.3.2 (key 00..1f, nonce 00:00:00:09:00:00:00:4a:00:00:00:00,
-    block counter 1) and against the independent Python restatement on random inputs"""
+def test_chacha_block_vectors():
+    """the proof RNG's block function: RFC 8439 section 2.3.2 (20 rounds; key 00..1f, nonce 00:00:00:09:00:00:00:4a:00:00:00:00,
+    block counter 1), the all-zero ChaCha12 and ChaCha20 keystream blocks (draft-strombergson-chacha-test-vectors TC1), and
+    the independent Python restatement on random inputs at 12 rounds (what the device runs)"""
     import ctypes as C
 
     from provekit_amd._lib import lib
 
     key = bytes(range(32))
     out = (C.c_uint8 * 64)()
-    assert lib.pk_selftest_chacha20(key, 1 | (0x09000000 << 32), 0x4A000000, 0, out) == 0
+    assert lib.pk_selftest_chacha(key, 1 | (0x09000000 << 32), 0x4A000000, 0, 20, out) == 0
     want = bytes.fromhex("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
                          "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
     assert bytes(out) == want
+    assert lib.pk_selftest_chacha(bytes(32), 0, 0, 0, 12, out) == 0
+    assert bytes(out).hex() == ("9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f"
+                                "0564f879d27ae3c02ce82834acfa8c793a629f2ca0de6919610be82f411326be")
+    assert lib.pk_selftest_chacha(bytes(32), 0, 0, 0, 20, out) == 0
+    assert bytes(out).hex().startswith("76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7")
     rng = np.random.default_rng(3)
     for _ in range(20):
         k = rng.bytes(32)
         ctr, n0, n1 = int(rng.integers(0, 2**63)), int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32))
-        assert lib.pk_selftest_chacha20(k, ctr, n0, n1, out) == 0
-        assert bytes(out) == _chacha20_block_py(k, ctr, n0, n1)
+        assert lib.pk_selftest_chacha(k, ctr, n0, n1, 12, out) == 0
+        assert bytes(out) == _chacha_block_py(k, ctr, n0, n1, 12)
 
 
 def test_sparse_matrix_rejects_malformed_arrays():
