@@ -180,7 +180,7 @@ def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3):
     timed with hipEvents on the context's stream.  Algorithmic bytes as BASELINE.md 4."""
     import ctypes as C
 
-    from provekit_amd._lib import PK_COL_MAJOR, lib
+    from provekit_amd._lib import lib
 
     n, rows, width = 1 << n_vars, 1 << (n_vars + 1 - 4), 32
     polys = []
@@ -190,16 +190,18 @@ def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3):
         polys.append(t)
     torch.cuda.synchronize()
     ptrs = (C.c_void_p * 2)(*[int(t.data_ptr()) for t in polys])
-    leaves, nodes, scratch = ctx.alloc_fe(rows * width), ctx.alloc_fe(2 * rows), ctx.alloc_fe(2 * rows * width)
+    szs = [C.c_size_t() for _ in range(3)]
+    ctx._check(lib.pk_commit_sizes(ctx.handle, 2, n_vars, 1, 4, *[C.byref(x) for x in szs]))
+    leaves, nodes, scratch = (ctx.alloc_fe(x.value) for x in szs)
+    root_buf = (C.c_uint8 * 32)()
     ms = []
     for i in range(reps + 1):
         ctx.timer_start()
-        ctx._check(lib.pk_rs_encode(ctx.handle, ptrs, 2, n_vars, 1, 4, leaves.ptr, scratch.ptr))
-        ctx._check(lib.pk_merkle_commit(ctx.handle, leaves.ptr, rows, width, PK_COL_MAJOR, nodes.ptr))
+        ctx._check(lib.pk_commit_into(ctx.handle, ptrs, 2, n_vars, 1, 4, leaves.ptr, nodes.ptr, scratch.ptr, root_buf))
         t = ctx.timer_stop()
         if i:
             ms.append(t)
-    root = ctx.download_fe(nodes.view_fe(1), 1)[0].tobytes().hex()
+    root = bytes(root_buf).hex()
     alg = 32 * 2 * n + 32 * 2 * 2 * n + 64 * rows
     best = min(ms)
     return {"workload": f"batch-2 WHIR commit of 2^{n_vars} coefficients (rate 1/2, fold 16): {rows * 31 + rows - 1} compressions, 32 NTTs of 2^{n_vars - 3}",
