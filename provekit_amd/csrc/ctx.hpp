@@ -55,6 +55,14 @@ struct pk_ctx {
 #define PK_PIN_ROOT 2048 /* 32 B: the root of the last Merkle tree built on this context (hash.hip) */
 #define PK_PIN_POW 2112  /* 8 B: the nonce found by the last proof-of-work launch (pow.hip) */
 
+// A launch too small to fill the chip is latency-bound, and it sits on some prover's Fiat-Shamir critical path while the
+// chip-filling kernels of the other provers share its SIMDs: let its wavefronts issue ahead of theirs (s_setprio 3).  The
+// chip-filling launches keep the default priority 0, so among themselves nothing changes.
+#define PK_LATENCY_PRIO()                                                        \
+    do {                                                                         \
+        if (gridDim.x * gridDim.y <= 128u) __builtin_amdgcn_s_setprio(3);        \
+    } while (0)
+
 namespace pk {
 
 inline int set_err(pk_ctx* ctx, int code, const char* fmt, ...) {

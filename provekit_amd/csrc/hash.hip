@@ -18,6 +18,7 @@ using namespace pk;
 
 template <int VERSION>
 __global__ __launch_bounds__(256) void compress_many_kernel(const fe* __restrict__ msgs, fe* __restrict__ out, size_t n) {
+    PK_LATENCY_PRIO();
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         fe29 l = to_scaled29(fe_load(msgs + 2 * i));  // any 256-bit value (generic.rs:81-82: inputs >= p are legal)
@@ -32,6 +33,7 @@ __global__ __launch_bounds__(256) void compress_many_kernel(const fe* __restrict
 template <int VERSION, int LAYOUT, bool SCALED_IN>
 __global__ __launch_bounds__(256) void leaf_hash_kernel(const fe* __restrict__ leaves, size_t n_leaves, unsigned width,
                                                         fe* __restrict__ digests) {
+    PK_LATENCY_PRIO();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_leaves) return;
     size_t step = LAYOUT == PK_COL_MAJOR ? n_leaves : 1;
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const fe* __restrict__ l
 // instead of a launch.
 template <int VERSION>
 __global__ __launch_bounds__(256) void merkle_levels_kernel(fe* __restrict__ nodes, size_t count, unsigned levels) {
+    PK_LATENCY_PRIO();
     size_t base = (size_t)blockIdx.x * 256;  // first owned node of the widest level, relative to that level
     unsigned width = 256;
     for (unsigned l = 0; l < levels; l++) {
@@ -73,6 +76,7 @@ __global__ __launch_bounds__(256) void merkle_levels_kernel(fe* __restrict__ nod
 // into pinned host memory (the host reads it after the stream synchronisation, no copy operation)
 template <int VERSION>
 __global__ __launch_bounds__(512) void merkle_top_kernel(fe* __restrict__ nodes, size_t top_leaves, fe* __restrict__ host_root) {
+    PK_LATENCY_PRIO();
     for (size_t lvl = top_leaves / 2; lvl >= 1; lvl >>= 1) {
         if (threadIdx.x < lvl) {
             size_t i = lvl + threadIdx.x;

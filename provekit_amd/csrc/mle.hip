@@ -46,6 +46,7 @@ __device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, int i, const fe& x
 // low kernel: bits [0, LOGT) on a contiguous tile of 2^LOGT elements held in LDS.
 template <bool SUB>
 __global__ __launch_bounds__(256) void wavelet_low_kernel(const fe* src, fe* data, unsigned logt) {
+    PK_LATENCY_PRIO();
     extern __shared__ uint4 lds[];
     const int T = 1 << logt;
     uint4* lo = lds;
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256) void wavelet_low_kernel(const fe* src, fe* dat
 // high kernel: bits [s, s+logr): element index = u*2^(s+logr) + r*2^s + v; tile = [2^logr][4 adjacent v]
 template <bool SUB, int BT>
 __global__ __launch_bounds__(256) void wavelet_high_kernel(fe* __restrict__ data, unsigned s, unsigned logr) {
+    PK_LATENCY_PRIO();
     extern __shared__ uint4 lds[];
     const int R = 1 << logr;
     const int TILE = R * BT;
@@ -156,6 +158,7 @@ int wavelet(pk_ctx* ctx, const uint64_t* d_src, uint64_t* d_data, unsigned n_var
 // tables layout: [pt][ 2^nhi hi entries | 2^nlo lo entries ]
 __global__ __launch_bounds__(256) void eq_half_tables_kernel(const fe* __restrict__ points, const fe* __restrict__ scales,
                                                              unsigned n_vars, unsigned nhi, unsigned nlo, fe* __restrict__ tables) {
+    PK_LATENCY_PRIO();
     // points / scales sit in pinned host memory (the mailbox): fetch this half's <= 15 coordinates in one go
     __shared__ uint4 xs[2 * 16];
     const unsigned pt = blockIdx.x, half = blockIdx.y;
@@ -186,6 +189,7 @@ __global__ __launch_bounds__(256) void eq_half_tables_kernel(const fe* __restric
 // Montgomery reduction per DOT29_GROUP terms (fe29.hpp dot29): ~100 multiply-adds per (point, element) instead of 162+.
 __global__ __launch_bounds__(256) void eq_accumulate_kernel(fe* __restrict__ w, size_t n, unsigned nhi, unsigned nlo, unsigned q,
                                                             const fe* __restrict__ tables, int overwrite) {
+    PK_LATENCY_PRIO();
     const size_t per_pt = ((size_t)1 << nhi) + ((size_t)1 << nlo);
     const size_t mask = ((size_t)1 << nlo) - 1;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -227,6 +231,7 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_kernel(fe* __restr
                                                                      fe* __restrict__ eq, size_t len, fe_arg fold_arg,
                                                                      fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                                      fe* __restrict__ result, unsigned seq) {
+    PK_LATENCY_PRIO();
     __shared__ uint4 smem[3 * 16];
     const fe alpha = from_arg(fold_arg);
     const size_t npairs = FOLD ? len / 4 : len / 2;
@@ -271,6 +276,7 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_kernel(const f
                                                                          size_t out_len, fe_arg fold_arg, fe* __restrict__ f_out,
                                                                          fe* __restrict__ w_out, fe* __restrict__ partials,
                                                                          unsigned* __restrict__ ticket, fe* __restrict__ result, unsigned seq) {
+    PK_LATENCY_PRIO();
     __shared__ uint4 smem[3 * 16];
     const fe r = from_arg(fold_arg);
     fe acc[3] = {fe_zero(), fe_zero(), fe_zero()};
@@ -313,6 +319,7 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_small_kernel(fe* _
                                                                            fe* __restrict__ eq, size_t len, fe_arg fold_arg,
                                                                            fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                                            fe* __restrict__ result, unsigned seq) {
+    PK_LATENCY_PRIO();
     __shared__ uint4 smem[3 * 16];
     __shared__ uint4 xs[2 * RED_THREADS];  // folded value of lane t at [t] (lo) and [RED_THREADS + t] (hi)
     const fe alpha = from_arg(fold_arg);
@@ -366,6 +373,7 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_small_kernel(c
                                                                                fe_arg fold_arg, fe* __restrict__ f_out, fe* __restrict__ w_out,
                                                                                fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                                                fe* __restrict__ result, unsigned seq) {
+    PK_LATENCY_PRIO();
     __shared__ uint4 smem[3 * 16];
     __shared__ uint4 xs[2 * RED_THREADS];
     const fe r = from_arg(fold_arg);
@@ -412,6 +420,7 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_small_kernel(c
 // one of up to two arrays folded by the same challenge (the sumcheck's polynomial and its weights) in one launch.
 __global__ void fold_pairs_kernel(const fe* __restrict__ v0, fe* __restrict__ out0, const fe* __restrict__ v1, fe* __restrict__ out1,
                                   size_t out_len, fe_arg r_arg) {
+    PK_LATENCY_PRIO();
     const fe r = from_arg(r_arg);
     const fe* v = blockIdx.y ? v1 : v0;
     fe* out = blockIdx.y ? out1 : out0;
@@ -428,6 +437,7 @@ template <int NV>
 __global__ __launch_bounds__(RED_THREADS) void dot_kernel(const fe* __restrict__ w, const fe* __restrict__ f, const fe* __restrict__ g,
                                                           size_t n, fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                           fe* __restrict__ result, unsigned seq) {
+    PK_LATENCY_PRIO();
     __shared__ uint4 smem[NV * 16];
     fe acc[NV];
 #pragma unroll
@@ -450,6 +460,7 @@ struct pow2_args {
 __global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restrict__ c, size_t n, pow2_args zp, fe_arg zT_arg,
                                                              fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                              fe* __restrict__ result, unsigned seq) {
+    PK_LATENCY_PRIO();
     __shared__ uint4 smem[16];
     const fe zT = from_arg(zT_arg);
     const size_t T = (size_t)gridDim.x * blockDim.x;
@@ -482,6 +493,7 @@ struct fold_args {
 };
 __global__ __launch_bounds__(256) void fold_coeffs_kernel(const fe* __restrict__ c, size_t n_out, unsigned k, fold_args ra,
                                                           fe* __restrict__ out) {
+    PK_LATENCY_PRIO();
     __shared__ uint4 wts[256 * 2];
     // weight j = prod_b r_b^{bit_b(j)}: thread j builds its own with at most k multiplications (no serial doubling pass)
     if (threadIdx.x < (1u << k)) {
@@ -508,6 +520,7 @@ struct fold16_args {
 };
 template <int LANES>
 __global__ __launch_bounds__(256) void fold16_kernel(const fe* __restrict__ c, size_t n_out, fold16_args wa, fe* __restrict__ out) {
+    PK_LATENCY_PRIO();
     __shared__ uint4 wts[16 * 2];
     if (threadIdx.x < 16) lds_put(wts, wts + 16, threadIdx.x, from_arg(wa.w[threadIdx.x]));
     __syncthreads();
@@ -535,6 +548,7 @@ __global__ __launch_bounds__(256) void fold16_kernel(const fe* __restrict__ c, s
 // out = a + beta * b (out may alias neither): the batching combination of two committed polynomials in one pass
 __global__ __launch_bounds__(256) void lincomb_kernel(fe* __restrict__ out, const fe* __restrict__ a, const fe* __restrict__ b, size_t n,
                                                       fe_arg beta_arg) {
+    PK_LATENCY_PRIO();
     const fe beta = from_arg(beta_arg);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -542,6 +556,7 @@ __global__ __launch_bounds__(256) void lincomb_kernel(fe* __restrict__ out, cons
 }
 // y += beta * x ; y = a o b
 __global__ __launch_bounds__(256) void axpy_kernel(fe* __restrict__ y, const fe* __restrict__ x, size_t n, fe_arg beta_arg) {
+    PK_LATENCY_PRIO();
     const fe beta = from_arg(beta_arg);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)

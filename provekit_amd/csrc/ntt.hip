@@ -108,6 +108,7 @@ struct PassParams {
 
 template <int LOG_R, bool IN_R_CONTIG>
 __global__ __launch_bounds__(NTHREADS) void ntt_pass_kernel(PassParams p) {
+    PK_LATENCY_PRIO();
     constexpr int R = 1 << LOG_R;
     constexpr int TILE = R * BT;
     extern __shared__ uint4 lds[];
@@ -356,6 +357,7 @@ __device__ __forceinline__ void ntt8_round(fe29 (&x)[8], const PassParams& p, co
 
 template <int LOG_R, bool IN_R_CONTIG>
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ntt8_pass_kernel(PassParams p) {
+    PK_LATENCY_PRIO();
     constexpr int LOGB = 11 - LOG_R;
     constexpr int NR = (LOG_R + 2) / 3;
     extern __shared__ u32 planes[];  // [9][2048]
@@ -380,6 +382,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
 template <int FW_MAX>
 __global__ __launch_bounds__(256) void deinterleave_kernel(const fe* __restrict__ c, fe* __restrict__ S, size_t L, unsigned fw,
                                                            size_t col_stride) {
+    PK_LATENCY_PRIO();
     // tile: TT consecutive t x fw columns
     extern __shared__ uint4 tl[];
     const unsigned TT = 1024 / fw;  // 1024 elements per tile = 32 KiB
@@ -415,6 +418,7 @@ __global__ __launch_bounds__(256) void deinterleave_kernel(const fe* __restrict_
 __global__ __launch_bounds__(256) void ntt_shard_prestep_kernel(const fe* __restrict__ S, size_t s_col_stride, size_t L, fe* __restrict__ Y,
                                                                 size_t y_col_stride, size_t Ng /* N/G */, unsigned g, unsigned G,
                                                                 const fe* __restrict__ W /* w_N^e */, size_t n_mask) {
+    PK_LATENCY_PRIO();
     const size_t col = blockIdx.y;
     const fe* x = S + col * s_col_stride;
     fe* y = Y + col * y_col_stride;

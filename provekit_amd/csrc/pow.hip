@@ -35,6 +35,7 @@ __device__ __forceinline__ fe from_arg(const fe_arg& a) {
 __global__ __launch_bounds__(256) void pow_search_kernel(fe_arg challenge_arg, fe_arg threshold_arg, unsigned long long base,
                                                          unsigned long long count, unsigned long long* best, unsigned* ticket,
                                                          unsigned long long* host_best) {
+    PK_LATENCY_PRIO();
     const fe29 challenge = to_scaled29(from_arg(challenge_arg));  // generic.rs:81 reduce_partial on arbitrary input
     fe29 s0 = challenge, zero;
 #pragma unroll

@@ -87,6 +87,7 @@ __host__ __device__ __forceinline__ void chacha_block(const RngKey& key, u64 cou
 }
 #undef PK_QR
 __global__ __launch_bounds__(256) void random_fe_kernel(fe* __restrict__ out, size_t n, RngKey key, u32 stream) {
+    PK_LATENCY_PRIO();
     const size_t stride = (size_t)gridDim.x * blockDim.x, pairs = (n + 1) / 2;
     for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < pairs; j += stride) {
         bool done[2] = {false, 2 * j + 1 >= n};

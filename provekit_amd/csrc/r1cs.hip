@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void witness_bounds_kernel(const uint32_t* pa,
                                                              const uint32_t* ib, const uint32_t* vb, const fe* __restrict__ interner,
                                                              const fe* __restrict__ z, size_t num_rows, size_t padded, fe* __restrict__ a,
                                                              fe* __restrict__ b, fe* __restrict__ c) {
+    PK_LATENCY_PRIO();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= padded) return;
     fe ra = fe_zero(), rb = fe_zero();
@@ -54,6 +55,7 @@ __global__ __launch_bounds__(256) void witness_bounds_kernel(const uint32_t* pa,
 __global__ __launch_bounds__(256) void sparse_gather_kernel(const uint32_t* ptr, const uint32_t* idx, const uint32_t* val,
                                                             const fe* __restrict__ interner, const fe* __restrict__ x, size_t n_out,
                                                             fe* __restrict__ y) {
+    PK_LATENCY_PRIO();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
     fe_store(y + i, sparse_row_dot(ptr, idx, val, interner, x, i));
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(256) void satisfaction_kernel(const uint32_t* pa, c
                                                            const uint32_t* ib, const uint32_t* vb, const uint32_t* pc, const uint32_t* ic,
                                                            const uint32_t* vc, const fe* __restrict__ interner, const fe* __restrict__ z,
                                                            size_t num_rows, unsigned long long* __restrict__ first_bad) {
+    PK_LATENCY_PRIO();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_rows) return;
     fe ra = sparse_row_dot(pa, ia, va, interner, z, i);
@@ -80,6 +83,7 @@ struct csc3 {
 };
 __global__ __launch_bounds__(256) void sparse_gather3_kernel(csc3 m, const fe* __restrict__ interner, const fe* __restrict__ x, size_t n_out,
                                                              fe* __restrict__ y) {
+    PK_LATENCY_PRIO();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
 #pragma unroll 1

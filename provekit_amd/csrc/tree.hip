@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void gather_opening_kernel(const fe* __restric
                                                              const unsigned long long* __restrict__ idx, size_t k, int canonical,
                                                              fe* __restrict__ out_leaves, fe* __restrict__ out_sib, fe* __restrict__ out_path,
                                                              bool scaled) {
+    PK_LATENCY_PRIO();
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n1 = k * width;
     if (t < n1) {
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256) void gather_opening_kernel(const fe* __restric
 
 // the all-gather delivers rank g's digests as one block: leaf i = g + G t is gathered[g*loc + t]; the heap wants it at rows + i
 __global__ __launch_bounds__(256) void interleave_digests_kernel(const fe* __restrict__ gathered, fe* __restrict__ nodes, size_t rows, unsigned G) {
+    PK_LATENCY_PRIO();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     const size_t loc = rows / G;
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(256) void interleave_digests_kernel(const fe* __res
 __global__ __launch_bounds__(256) void gather_owned_rows_kernel(const fe* __restrict__ leaves_local, size_t loc, unsigned width, unsigned shard,
                                                                 unsigned G, const unsigned long long* __restrict__ idx, size_t k, int canonical,
                                                                 fe* __restrict__ out, bool scaled) {
+    PK_LATENCY_PRIO();
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= k * width) return;
     const size_t q = t / width, j = t % width;
