@@ -20,7 +20,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != c:
                 continue
-            k = row["Kernel_Name"].split("(")[0]
+            k = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
             agg[k][0] += 1
             agg[k][1] += float(row["Counter_Value"])
     out[c] = {k: {"dispatches": v[0], "sum": v[1], "per_dispatch": v[1] / max(v[0], 1)} for k, v in agg.items()}
