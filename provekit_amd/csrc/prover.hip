@@ -637,6 +637,17 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
             }
             got += (size_t)r;
         }
+        // one proof sharded over a device set: every rank must mask with the SAME polynomials -- rank 0's key goes to everybody
+        if (comm_world(ctx) > 1) {
+            int rc = ensure_scratch(ctx, ((size_t)1 << 19) + 32 * (size_t)(PK_MAX_RANKS + 1));
+            if (rc) return rc;
+            char* d_key = (char*)ctx->d_scratch + ((size_t)1 << 19);  // clear of the reduction area (head) and the PoW words (tail)
+            PK_HIP(ctx, hipMemcpyAsync(d_key, key.k, 32, hipMemcpyHostToDevice, ctx->stream));
+            rc = comm_all_gather(ctx, d_key, d_key + 32, 32);
+            if (rc) return rc;
+            PK_HIP(ctx, hipMemcpyAsync(key.k, d_key + 32, 32, hipMemcpyDeviceToHost, ctx->stream));
+            PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
     }
     Arena A{s->arena, s->arena_bytes};
     Transcript T(s->domain_separator);

@@ -151,8 +151,21 @@ def _sharded_prove_case(ctx, oracle, rank_sets, G, m, m_0, nc, n_in, seed, test_
         return proofs, ds
 
     want, ds = prove_on(ctx)
-    for proofs, _ in run_ranks(rank_sets(G), lambda r, c: prove_on(c)):
+    ranks = rank_sets(G)
+    for proofs, _ in run_ranks(ranks, lambda r, c: prove_on(c)):
         assert proofs == want, "a rank of the sharded prover diverged from the lone prover's transcript"
+
+    # production randomness (no injected seed): rank 0's OS key is shared, so the ranks still agree with each other
+    def prove_fresh(c):
+        r1cs = R1CS(c, *(to_sparse(nc, nw, t) for t in trips), interner)
+        s = WhirR1CSScheme(c, r1cs, m, m_0, cfg_w, cfg_b)
+        proof = s.prove(c.upload(zm))
+        s.close()
+        r1cs.close()
+        return proof
+
+    fresh = run_ranks(ranks, lambda r, c: prove_fresh(c))
+    assert all(p == fresh[0] for p in fresh) and fresh[0] not in want
 
     def vcfg(c):
         return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
@@ -160,6 +173,7 @@ def _sharded_prove_case(ctx, oracle, rank_sets, G, m, m_0, nc, n_in, seed, test_
 
     mats = [(t[0], t[1], [coeffs[v] for v in t[2]]) for t in trips]
     assert V.verify(want[0], ds, m, m_0, vcfg(cfg_w), vcfg(cfg_b), r1cs=(nc, nw, mats) if verify_r1cs else None)
+    assert V.verify(fresh[0], ds, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
 
 
 @pytest.mark.parametrize("G", [2, 4])
