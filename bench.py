@@ -2,7 +2,7 @@
 """bench.py -- proofs/sec of the WHIR prover hot path on MI355X (BASELINE.json metric), one JSON line.
 
 A "step" is the device work of one `prove` on the poseidon-rounds size class (BASELINE configs[1]; m = 21,
-m_0 = 20, synthetic R1CS + witness since the .nps is absent from the reference tree): batch-2 WHIR commit of the
+m_0 = 20, synthetic satisfiable R1CS + satisfying witness since the .nps is absent from the reference tree): batch-2 WHIR commit of the
 masked witness (to_coeffs, RS-encode NTT, Skyscraper Merkle), the 20-round zk-sumcheck with its blinding
 commitment and small WHIR proof, the external row and weighted sums, and the 4-round WHIR batch opening
 (fold, re-commit, OOD, PoW grind, STIR openings, equality weights, quadratic sumcheck) -- every call through
@@ -28,22 +28,43 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 
 def synth_r1cs(ctx, m_0, n_wit, seed):
-    """R1CS-shaped synthetic instance: ~3 entries per row, distinct sorted columns, small
-    interned coefficients; built vectorised."""
-    from provekit_amd.field import ints_to_limbs, random_field
+    """R1CS-shaped synthetic instance, SATISFIABLE by construction: 3/4 * 2^m_0 constraints
+    (sum a z)(sum b z) = z[out_i] with ~3 entries per row in A and B over the inputs, C selecting a fresh output per row, small
+    interned coefficients; built vectorised.  -> (R1CS, mats, interner, num_constraints, n_in)"""
+    from provekit_amd.field import ints_to_limbs
     from provekit_amd.sparse_matrix import R1CS, SparseMatrix
 
     rng = np.random.default_rng(seed)
-    nc = (1 << m_0) - 3  # not a power of two on purpose: exercises the zero padding
+    nc = (3 << m_0) // 4 - 3  # not a power of two on purpose: exercises the zero padding
+    n_in = n_wit - 1 - nc
+    assert n_in >= 8, "witness capacity too small for one output per constraint"
     mats = []
-    for _ in range(3):
-        base = np.sort(rng.integers(0, n_wit - 2, size=(nc, 3), dtype=np.int64), axis=1) + np.arange(3)
+    for _ in range(2):
+        base = np.sort(rng.integers(0, 1 + n_in - 2, size=(nc, 3), dtype=np.int64), axis=1) + np.arange(3)
         nri = (np.arange(nc, dtype=np.uint32) * 3).astype(np.uint32)
         mats.append(SparseMatrix(nc, n_wit, nri, base.reshape(-1).astype(np.uint32), rng.integers(0, 16, size=3 * nc).astype(np.uint32)))
+    mats.append(SparseMatrix(nc, n_wit, np.arange(nc, dtype=np.uint32), (1 + n_in + np.arange(nc)).astype(np.uint32), np.zeros(nc, dtype=np.uint32)))
     R = (1 << 256) % 21888242871839275222246405745257275088548364400416034343698204186575808495617
     P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
     interner = ints_to_limbs([(v * R) % P for v in [1, 2, 3, 5, 7, P - 1, P - 2, 11, 13, 17, 19, 23, 29, 31, 37, 41]])
-    return R1CS(ctx, *mats, interner), mats, interner, nc
+    return R1CS(ctx, *mats, interner), mats, interner, nc, n_in
+
+
+def satisfying_witness(ctx, r1cs, n_wit, nc, n_in, seed):
+    """z = [1 | random inputs | outputs (A z) o (B z)], the outputs computed by the library itself (pk_r1cs_matvec, pk_fe_mul);
+    checked with pk_r1cs_test_witness_satisfaction.  -> (device buffer, host copy)"""
+    from provekit_amd._lib import lib
+    from provekit_amd.field import ints_to_limbs, random_field
+
+    R = (1 << 256) % 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    z = np.zeros((n_wit, 4), dtype=np.uint64)
+    z[0] = ints_to_limbs([R])[0]
+    z[1 : 1 + n_in] = random_field(n_in, seed)
+    d_z = ctx.upload(z)
+    az, bz = r1cs.matvec(0, d_z), r1cs.matvec(1, d_z)
+    ctx._check(lib.pk_fe_mul(ctx.handle, az.ptr, bz.ptr, d_z.view_fe(1 + n_in), nc))
+    r1cs.test_witness_satisfaction(d_z)
+    return d_z, ctx.download_fe(d_z, n_wit)
 
 
 def leaf_hash_bytes(cfg_list):
@@ -436,9 +457,9 @@ def main():
         if args.sharded and world > 1:  # this context is one rank of the device set: its commits are sharded from here on
             join_device_set(c, rank, world, dist)
         srank = 0 if args.sharded else rank  # the ranks of a sharded prover hold the SAME statement and witness
-        r1cs_w, mats, interner, nc = synth_r1cs(c, m_0, n_wit, seed=1234 + srank)
-        z_host = random_field(n_wit, 99 + srank + 1000 * w)
-        workers.append((c, WhirR1CSScheme(c, r1cs_w, m, m_0, cfg_w, cfg_b), c.upload(z_host), r1cs_w, z_host))
+        r1cs_w, mats, interner, nc, n_in = synth_r1cs(c, m_0, n_wit, seed=1234 + srank)
+        d_z, z_host = satisfying_witness(c, r1cs_w, n_wit, nc, n_in, 99 + srank + 1000 * w)
+        workers.append((c, WhirR1CSScheme(c, r1cs_w, m, m_0, cfg_w, cfg_b), d_z, r1cs_w, z_host))
     ctx = workers[0][0]
 
     def run_proofs(first_seed, count):
@@ -550,7 +571,7 @@ def main():
             "dtype": "u32x8 (BN254-Fr, 256-bit Montgomery integers)",
             "data": "synthetic",
             "config": {
-                "workload": f"poseidon-rounds size class: m={m}, m_0={m_0}, batch-2 WHIR commit + zk-sumcheck + {cfg_w.n_rounds}-round WHIR opening, "
+                "workload": f"poseidon-rounds size class: m={m}, m_0={m_0}, satisfiable synthetic R1CS ({nc} constraints, {n_wit} witnesses), batch-2 WHIR commit + zk-sumcheck + {cfg_w.n_rounds}-round WHIR opening, "
                             f"queries {cfg_w.num_queries}/{cfg_w.final_queries}, pow_bits {cfg_w.pow_bits}/{cfg_w.final_pow_bits} (WhirConfig::new derivation, security 128, "
                             f"ConjectureList), blinding WHIR n={cfg_b.n_vars} queries {cfg_b.num_queries}/{cfg_b.final_queries}, Skyscraper-sponge transcript, ChaCha12 masks",
                 "proofs_per_step": conc * (1 if args.sharded else world),
