@@ -58,9 +58,13 @@ struct pk_ctx {
 // A launch too small to fill the chip is latency-bound, and it sits on some prover's Fiat-Shamir critical path while the
 // chip-filling kernels of the other provers share its SIMDs: let its wavefronts issue ahead of theirs (s_setprio 3).  The
 // chip-filling launches keep the default priority 0, so among themselves nothing changes.
+#ifndef PK_BASE_PRIO
+#define PK_BASE_PRIO 0
+#endif
 #define PK_LATENCY_PRIO()                                                        \
     do {                                                                         \
         if (gridDim.x * gridDim.y <= 128u) __builtin_amdgcn_s_setprio(3);        \
+        else if (PK_BASE_PRIO) __builtin_amdgcn_s_setprio(PK_BASE_PRIO);         \
     } while (0)
 
 namespace pk {

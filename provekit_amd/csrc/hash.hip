@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void leaf_hash_kernel(const fe* __restrict__ l
 // instead of a launch.
 template <int VERSION>
 __global__ __launch_bounds__(256) void merkle_levels_kernel(fe* __restrict__ nodes, size_t count, unsigned levels) {
-    PK_LATENCY_PRIO();
+    if (gridDim.x <= 128u) __builtin_amdgcn_s_setprio(3);  // a chain of dependent levels: latency-bound at any width
+    else __builtin_amdgcn_s_setprio(2);
     size_t base = (size_t)blockIdx.x * 256;  // first owned node of the widest level, relative to that level
     unsigned width = 256;
     for (unsigned l = 0; l < levels; l++) {

@@ -5,6 +5,8 @@
 // element, so each is laid out for coalesced 32 B/lane access, keeps its arrays resident
 // in HBM across rounds, and returns only the 3-4 field elements the Fiat-Shamir
 // transcript needs per round (grid reduction in reduce.hpp).
+// memory- / latency-bound kernels: their wavefronts issue ahead of the ALU-bound hash / NTT / grinder kernels they share SIMDs with
+#define PK_BASE_PRIO 2
 #include "ctx.hpp"
 #include "fe29.hpp"
 #include "reduce.hpp"

@@ -26,6 +26,8 @@
 
 #include <atomic>
 
+// partly memory-bound (VALUBusy ~75 %): between the pure-ALU hash kernels (0) and the memory-bound kernels (2)
+#define PK_BASE_PRIO 1
 #include "ctx.hpp"
 #include "fe29.hpp"
 

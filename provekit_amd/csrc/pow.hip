@@ -8,6 +8,8 @@
 // searched in ascending windows, one compression per lane, device-wide atomicMin.
 #include <cmath>
 
+// pure ALU like the hash, but a prover is waiting for the nonce: one step above the hash kernels
+#define PK_BASE_PRIO 1
 #include "ctx.hpp"
 #include "skyscraper29s.hpp"
 

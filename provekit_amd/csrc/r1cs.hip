@@ -8,6 +8,8 @@
 // gathers: one lane per output row (A*z) or per output column (eq^T * A).
 #include <vector>
 
+// memory- / latency-bound kernels: their wavefronts issue ahead of the ALU-bound hash / NTT / grinder kernels they share SIMDs with
+#define PK_BASE_PRIO 2
 #include "ctx.hpp"
 #include "fe29.hpp"
 

@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <vector>
 
+// memory- / latency-bound kernels: their wavefronts issue ahead of the ALU-bound hash / NTT / grinder kernels they share SIMDs with
+#define PK_BASE_PRIO 2
 #include "ctx.hpp"
 #include "skyscraper29s.hpp"
 
