@@ -1,7 +1,9 @@
 // skyscraper29.hpp -- Skyscraper compression on the 9x29-bit representation.
 //
 // Semantics as skyscraper.hpp (skyscraper/core/src/reference.rs:41-98, generic.rs:77-102, v1.rs:19-32);
-// this is the fast path every hashing kernel uses.  State values are canonical-domain integers kept
+// this is the plain path: the reference's structure on the 29-bit limbs, state in the true domain, one lazy reduction per
+// round.  The kernels run skyscraper29s.hpp (state scaled by 32, fused rounds); this file stays as the host/device cross-check
+// of that faster path (pk_selftest_arith ops 1, 2, 13) and supplies its shared pieces (rc limbs, quotient estimate, bar).  State values are canonical-domain integers kept
 // "almost reduced" (< p(1 + 2^-10), limbs normalized) between rounds, the lazy-reduction idea of
 // skyscraper/core/src/reduce.rs:35-55 (table of multiples indexed by the top limb) restated for 29-bit
 // limbs: subtract floor(top/(p_top+1)) * p, one signed carry sweep.
@@ -92,35 +94,6 @@ PK_HD fe29 compress29(const fe29& l_in, const fe29& r_in) {
         return s;
     }
     // out = l + l_in mod p, exactly
-    fe29 a = cond_sub_p29(l), b = cond_sub_p29(l_in);
-    fe29 s = add29(a, b);
-    normalize29(s);
-    return cond_sub_p29(s);
-}
-
-// Skyscraper v2 with round 0 hoisted: f0 = sq(l_in) (normalized, < 1.2p) is supplied by a caller that hashes many messages
-// sharing the same left input (the proof-of-work grinder: l = challenge, r = nonce).  Returns the canonical digest.
-PK_HD fe29 compress29_v2_fixed_left(const fe29& l_in, const fe29& f0, const fe29& r_in) {
-    fe29 l = add29(r_in, f0);  // round 0 adds no constant (RC[0] = 0)
-    reduce_almost29(l);
-    fe29 r = l_in;
-    sky_round29<1, false>(l, r);
-    sky_round29<2, false>(l, r);
-    sky_round29<3, false>(l, r);
-    sky_round29<4, false>(l, r);
-    sky_round29<5, false>(l, r);
-    sky_round29<6, true>(l, r);
-    sky_round29<7, true>(l, r);
-    sky_round29<8, false>(l, r);
-    sky_round29<9, false>(l, r);
-    sky_round29<10, true>(l, r);
-    sky_round29<11, true>(l, r);
-    sky_round29<12, false>(l, r);
-    sky_round29<13, false>(l, r);
-    sky_round29<14, false>(l, r);
-    sky_round29<15, false>(l, r);
-    sky_round29<16, false>(l, r);
-    sky_round29<17, false>(l, r);
     fe29 a = cond_sub_p29(l), b = cond_sub_p29(l_in);
     fe29 s = add29(a, b);
     normalize29(s);
