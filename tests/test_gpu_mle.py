@@ -271,3 +271,24 @@ def test_to_coeffs_out_of_place(ctx, oracle, n_vars):
     back = ctx.alloc_fe(1 << n_vars)
     ctx._check(lib.pk_to_evals_into(ctx.handle, dst.ptr, back.ptr, n_vars))
     assert np.array_equal(ctx.download_fe(back, 1 << n_vars), ev)
+
+
+@pytest.mark.parametrize("n_vars,q", [(1, 1), (1, 5), (2, 3), (5, 1), (6, 4), (7, 5), (9, 9), (10, 13)])
+def test_eq_accumulate_group_boundaries(ctx, oracle, n_vars, q):
+    """eq_accumulate sums its q products per element with one Montgomery reduction per group of four (fe29.hpp dot29): every
+    residue of q mod 4, odd and even splits of the variables, accumulate and overwrite, against the oracle point by point"""
+    import ctypes as C
+
+    from provekit_amd._lib import lib
+    from provekit_amd.field import random_field
+
+    pts = random_field(q * n_vars, 40 + n_vars + q).reshape(q, n_vars, 4)
+    scales = random_field(q, 50 + q)
+    w0 = random_field(1 << n_vars, 60 + n_vars)
+    for overwrite in (1, 0):
+        d_w = ctx.upload(w0)
+        ctx._check(lib.pk_eq_accumulate(ctx.handle, d_w.ptr, n_vars, pts.ctypes.data, scales.ctypes.data, q, overwrite))
+        want = np.zeros_like(w0) if overwrite else w0.copy()
+        for t in range(q):
+            want = oracle.eq_accumulate_point(want, n_vars, pts[t], scales[t])
+        assert np.array_equal(ctx.download_fe(d_w, 1 << n_vars), want), (n_vars, q, overwrite)

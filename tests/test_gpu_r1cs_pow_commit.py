@@ -193,3 +193,39 @@ def test_r1cs_from_postcard_matches_direct_upload(ctx, oracle):
             R1CS.from_postcard(ctx, bad if bad else b"\x00")
     direct.close()
     viapc.close()
+
+
+@pytest.mark.parametrize("batch,n_vars", [(2, 13), (2, 14), (1, 14), (1, 15), (2, 17)])
+def test_commit_across_the_hash_ready_boundary(ctx, oracle, batch, n_vars):
+    """pk_commit holds its codeword hash-ready (32 * value) from 2^11 rows up and as Montgomery images below (tree.hip
+    codeword_scaled): roots and BOTH opening forms must equal the oracle's on either side of the switch, and pk_commit_into
+    (caller-owned buffers) must give the same root as pk_commit."""
+    import ctypes as C
+
+    from provekit_amd._lib import lib
+    from provekit_amd.field import random_field
+    from provekit_amd.whir import commit_batch
+
+    polys = [random_field(1 << n_vars, 900 + b + n_vars) for b in range(batch)]
+    bufs = [ctx.upload(p) for p in polys]
+    c = commit_batch(ctx, bufs, n_vars, 1, 4)
+    leaves = oracle.rs_encode(np.concatenate(polys), batch, n_vars, 1, 4)
+    nodes = oracle.merkle_commit(leaves)
+    n = leaves.shape[0]
+    assert int.from_bytes(c.root, "little") == oracle.limbs_to_ints(nodes[1])[0]
+    idx = np.unique(np.random.default_rng(n_vars).integers(0, n, size=25)).astype(np.uint64)
+    lv_c, sib, paths = c.open(idx, canonical_leaves=True)
+    lv_m, _, _ = c.open(idx, canonical_leaves=False)
+    assert np.array_equal(lv_m, leaves[idx])
+    assert np.array_equal(lv_c, np.stack([oracle.from_mont(leaves[i]) for i in idx]))
+    assert np.array_equal(sib, nodes[(n + idx.astype(np.int64)) ^ 1])
+    szs = [C.c_size_t() for _ in range(3)]
+    ctx._check(lib.pk_commit_sizes(ctx.handle, batch, n_vars, 1, 4, *[C.byref(x) for x in szs]))
+    assert szs[0].value == n * 16 * batch and szs[1].value == 2 * n
+    d_l, d_n, d_s = (ctx.alloc_fe(x.value) for x in szs)
+    ptrs = (C.c_void_p * batch)(*[b.ptr for b in bufs])
+    root = (C.c_uint8 * 32)()
+    ctx._check(lib.pk_commit_into(ctx.handle, ptrs, batch, n_vars, 1, 4, d_l.ptr, d_n.ptr, d_s.ptr, root))
+    assert bytes(root) == c.root
+    assert np.array_equal(ctx.download_fe(d_n.view_fe(1), 2 * n - 1), nodes[1:])  # every node of the heap
+    c.close()
