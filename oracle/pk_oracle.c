@@ -757,10 +757,19 @@ u64 pko_pow_solve(const u64 challenge[4], double difficulty) { /* pow.rs:33-41; 
     if (difficulty == 0.0) return 0;
     u64 thr[4];
     pko_pow_threshold(difficulty + 0.01, thr);
-    for (u64 nonce = 0;; nonce++) {
-        u64 h[4], n[4] = {nonce, 0, 0, 0};
-        pko_compress(challenge, n, h);
-        if (lt(h, thr)) return nonce;
+    /* the reference grinds on all cores (generic.rs:42-71: rayon::broadcast + fetch_min); here: windows of nonces searched in
+     * parallel, the smallest hit of the first window that has one -- i.e. still the globally smallest valid nonce */
+    const u64 window = 1u << 14;
+    for (u64 base = 0;; base += window) {
+        u64 best = ~(u64)0;
+#pragma omp parallel for schedule(static) reduction(min : best)
+        for (long long t = 0; t < (long long)window; t++) {
+            u64 nonce = base + (u64)t;
+            u64 h[4], n[4] = {nonce, 0, 0, 0};
+            pko_compress(challenge, n, h);
+            if (lt(h, thr) && nonce < best) best = nonce;
+        }
+        if (best != ~(u64)0) return best;
     }
 }
 
