@@ -295,3 +295,25 @@ def test_concurrent_provers_are_deterministic(oracle):
         s.close()
         r.close()
         c.close()
+
+
+@pytest.mark.parametrize("m,m_0,nc,nw", [(10, 12, 4000, 500), (14, 6, 60, 8000), (12, 12, 4096, 2048), (9, 9, 300, 256)])
+def test_scheme_shapes_fit_their_arena(ctx, oracle, m, m_0, nc, nw):
+    """pk_scheme_create sizes the proof arena from (m, m_0, rate, batch, fold, num_witnesses): shapes far from m_0 = m - 1
+    (more constraints than witnesses and the reverse) must prove without exhausting it, deterministically.  The instances are
+    random (not satisfiable): this exercises allocation and control flow, the verifier-checked cases are above."""
+    from test_gpu_r1cs_pow_commit import synth_r1cs
+
+    from provekit_amd.field import random_field
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS
+
+    a, b, c = synth_r1cs(nc, nw, m * 31 + m_0)
+    interner = random_field(17, 3)
+    r1cs = R1CS(ctx, a, b, c, interner)
+    scheme = WhirR1CSScheme(ctx, r1cs, m, m_0, WhirConfig.for_size(m, 5.0), blinding_config_for(m_0, 5.0))
+    d_z = ctx.upload(random_field(nw, 9))
+    p1, p2 = scheme.prove(d_z, seed=4), scheme.prove(d_z, seed=4)
+    assert p1 == p2 and len(p1) > 1000
+    scheme.close()
+    r1cs.close()
