@@ -317,3 +317,31 @@ def test_scheme_shapes_fit_their_arena(ctx, oracle, m, m_0, nc, nw):
     assert p1 == p2 and len(p1) > 1000
     scheme.close()
     r1cs.close()
+
+
+def test_the_bench_statement_verifies(ctx, oracle):
+    """bench.py's own workload -- its satisfiable synthetic R1CS, the satisfying witness the library computes for it, the
+    reference's schedule for m = 21 -- gives a proof the independent verifier accepts: the number bench.py reports is the
+    rate of proofs like this one."""
+    import verifier as V
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+
+    m, m_0 = 21, 20
+    n_wit = (1 << (m - 1)) - 5
+    r1cs, mats, interner, nc, n_in = bench.synth_r1cs(ctx, m_0, n_wit, seed=1234)
+    d_z, _ = bench.satisfying_witness(ctx, r1cs, n_wit, nc, n_in, 99)
+    cfg_w, cfg_b = WhirConfig.derive(m), blinding_config_for(m_0)
+    scheme = WhirR1CSScheme(ctx, r1cs, m, m_0, cfg_w, cfg_b)
+    proof = scheme.prove(d_z)  # production randomness
+
+    def vcfg(c):
+        return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
+
+    assert V.verify(proof, scheme.domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
+    scheme.close()
+    r1cs.close()
