@@ -205,3 +205,25 @@ def test_merkle_full_size_property(ctx, oracle):
     d_c2 = ctx.upload(cols2)
     ctx._check(lib.pk_merkle_commit(ctx.handle, d_c2.ptr, n, w, PK_COL_MAJOR, nodes.ptr))
     assert not np.array_equal(ctx.download_fe(nodes.view_fe(1), 1)[0], all1[1])
+
+
+def test_compress_structured_inputs(ctx, oracle):
+    """The scaled-by-32 hash kernels have their own boundary conditions (the exact division by 32, the conditional subtraction
+    of 32p, quotient estimates up to 169): structured inputs aimed at them -- multiples of p/32 and of p, powers of two, all byte
+    patterns the S-box treats specially, values just below 2^256 -- each with small offsets, in every (l, r) combination of a
+    sample, on the device against the oracle; plus 2^20 random messages."""
+    from provekit_amd.skyscraper import compress_many
+
+    P = oracle.P
+    base = [0, 1, P - 1, P, P + 1, 2 * P, 5 * P, (1 << 256) - 1, (1 << 255), (1 << 254), (1 << 253), (1 << 232), (1 << 29) - 1]
+    base += [k * P // 32 for k in (1, 2, 3, 15, 16, 17, 31, 32, 33, 100, 169)] + [k * P for k in (3, 4)]
+    base += [int.from_bytes(bytes([b]) * 32, "little") for b in (0x00, 0xFF, 0x80, 0x7F, 0x01, 0xFE, 0x55, 0xAA, 0x0F, 0xF0)]
+    base += [(1 << 261) // 32 // 5, ((1 << 256) - 1) // 3]
+    vals = sorted({(v + d) % (1 << 256) for v in base for d in (-2, -1, 0, 1, 2)})
+    rng = np.random.default_rng(8)
+    pick = [vals[i] for i in rng.permutation(len(vals))[:60]]
+    pairs = [(a, b) for a in pick for b in pick] + [(v, v) for v in vals] + [(v, 0) for v in vals] + [(0, v) for v in vals]
+    msgs = b"".join(a.to_bytes(32, "little") + b.to_bytes(32, "little") for a, b in pairs)
+    assert compress_many(msgs, ctx=ctx) == oracle.compress_many(msgs)
+    big = rng.integers(0, 256, size=64 << 20, dtype=np.uint8).tobytes()
+    assert compress_many(big, ctx=ctx) == oracle.compress_many(big)
