@@ -379,6 +379,14 @@ int pk_selftest_arith_device(pk_ctx *ctx, int op, const uint64_t *d_a, const uin
 /* measurement aid (SURVEY 8d "measured_peak_modmul_per_s"): rate of register-resident 9x29-bit Montgomery squarings,
  * ilp (1|2|4) independent chains per lane, waves_per_simd (1..8) resident waves, iters squarings per chain */
 int pk_selftest_modmul_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double *modmul_per_s);
+/* PROTOTYPE, not on the product path (csrc/fe52.hpp): the reference's f64-FMA Montgomery square on 5 x 52-bit limbs
+ * (skyscraper/block-multiplier/src/portable_simd.rs:17-196, utils.rs:66-147, constants.rs:100-133; round-toward-zero as
+ * fp-rounding/src/lib.rs:57-78).  a: n values < 2^256 (4 x u64 each) -> out5: n x 5 limbs of x^2 * 2^-260 mod p, lazily
+ * reduced (< 2^257).  Host: under fesetround(FE_TOWARDZERO); device: MODE.FP_ROUND set by the kernel; _rate_fp52: the same
+ * probe as pk_selftest_modmul_rate for this multiplier, so the two can be compared on one box. */
+int pk_selftest_fp52_sqr(const uint64_t *a, uint64_t *out5, size_t n);
+int pk_selftest_fp52_sqr_device(pk_ctx *ctx, const uint64_t *d_a, uint64_t *d_out5, size_t n);
+int pk_selftest_modmul_rate_fp52(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double *modmul_per_s);
 
 #ifdef __cplusplus
 }

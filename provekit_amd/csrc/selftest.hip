@@ -2,6 +2,7 @@
 // (fe29.hpp, skyscraper29.hpp), so the CPU test suite can check it against the oracle without a GPU.
 #include "ctx.hpp"
 #include "reduce.hpp"
+#include "fe52.hpp"
 #include "skyscraper29s.hpp"
 #include "transcript.hpp"
 
@@ -99,7 +100,91 @@ __global__ __launch_bounds__(256) void modmul_rate_kernel(const fe* __restrict__
     if (acc.v[8] == 0xffffffffu) fe_store(out + i, pack29(acc));  // never true (limbs stay < 2^30); keeps the chain live
 }
 
+// ---- the f64-FMA multiplier prototype (fe52.hpp) ----------------------------------------------------------------------------
+__global__ void fp52_sqr_kernel(const fe* a, u64* out, size_t n) {
+    f52_enter_rtz();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe52 x = unpack52(fe_load(a + i));
+#pragma unroll
+    for (int k = 0; k < 5; k++) asm volatile("" : "+v"(x.v[k]));  // the limbs exist only after the mode switch
+    const fe52 r = sqr260_52(x);
+#pragma unroll
+    for (int k = 0; k < 5; k++) out[5 * i + k] = r.v[k];
+}
+template <int ILP>
+__global__ __launch_bounds__(256) void modmul_rate_fp52_kernel(const fe* __restrict__ in, u64* __restrict__ out, unsigned iters) {
+    f52_enter_rtz();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    fe52 x[ILP];
+#pragma unroll
+    for (int k = 0; k < ILP; k++) {
+        x[k] = unpack52(fe_load(in + (i % 64)));
+        x[k].v[0] ^= (u64)k;
+#pragma unroll
+        for (int j = 0; j < 5; j++) asm volatile("" : "+v"(x[k].v[j]));
+    }
+    for (unsigned it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < ILP; k++) x[k] = sqr260_52(x[k]);
+    }
+    u64 acc = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; k++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) acc += x[k].v[j];
+    if (acc == 0xffffffffffffffffull) out[i] = acc;  // never true (limbs < 2^52); keeps the chains live
+}
+
 extern "C" {
+
+// x (n field elements, 4 x u64, any value < 2^256) -> the five 52-bit limbs of sqr260_52(x) = x^2 * 2^-260 mod p, lazily reduced
+// (value < 2^257).  Host execution of the shared code under fesetround(FE_TOWARDZERO).
+int pk_selftest_fp52_sqr(const uint64_t* a, uint64_t* out5, size_t n) {
+    if (!a || !out5) return PK_ERR_BAD_ARG;
+    const int old = fegetround();
+    if (fesetround(FE_TOWARDZERO)) return PK_ERR_BAD_ARG;
+    for (size_t i = 0; i < n; i++) {
+        const fe52 r = sqr260_52(unpack52(load_host(a + 4 * i)));
+        for (int k = 0; k < 5; k++) out5[5 * i + k] = r.v[k];
+    }
+    fesetround(old);
+    return PK_OK;
+}
+int pk_selftest_fp52_sqr_device(pk_ctx* ctx, const uint64_t* d_a, uint64_t* d_out5, size_t n) {
+    if (!ctx || !d_a || !d_out5) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
+    if (!n) return PK_OK;
+    fp52_sqr_kernel<<<(unsigned)((n + 63) / 64), 64, 0, ctx->stream>>>((const fe*)d_a, (u64*)d_out5, n);
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+// the counterpart of pk_selftest_modmul_rate for the f64-FMA square: register-resident chains, nothing else
+int pk_selftest_modmul_rate_fp52(pk_ctx* ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double* modmul_per_s) {
+    if (!ctx || !modmul_per_s) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, waves_per_simd >= 1 && waves_per_simd <= 8 && (ilp == 1 || ilp == 2 || ilp == 4) && iters >= 1, "waves 1..8, ilp 1|2|4");
+    int rc = ensure_scratch(ctx, (size_t)ctx->num_cus * 8 * 256 * 8);
+    if (rc) return rc;
+    PK_HIP(ctx, hipMemsetAsync(ctx->d_scratch, 0x11, 64 * 32, ctx->stream));
+    const unsigned blocks = (unsigned)ctx->num_cus * waves_per_simd;
+    auto launch = [&](unsigned n) {
+        const fe* in = (const fe*)ctx->d_scratch;
+        u64* out = (u64*)ctx->d_scratch;
+        if (ilp == 1) modmul_rate_fp52_kernel<1><<<blocks, 256, 0, ctx->stream>>>(in, out, n);
+        else if (ilp == 2) modmul_rate_fp52_kernel<2><<<blocks, 256, 0, ctx->stream>>>(in, out, n);
+        else modmul_rate_fp52_kernel<4><<<blocks, 256, 0, ctx->stream>>>(in, out, n);
+    };
+    launch(16);
+    PK_LAUNCH_CHECK(ctx);
+    float ms = 0;
+    if ((rc = pk_timer_start(ctx))) return rc;
+    launch(iters);
+    PK_LAUNCH_CHECK(ctx);
+    if ((rc = pk_timer_stop(ctx, &ms))) return rc;
+    *modmul_per_s = (double)blocks * 256.0 * ilp * iters / (ms * 1e-3);
+    return PK_OK;
+}
 
 int pk_selftest_modmul_rate(pk_ctx* ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double* modmul_per_s) {
     if (!ctx || !modmul_per_s) return PK_ERR_BAD_ARG;

@@ -25,3 +25,24 @@ def test_device_equals_host(ctx, oracle, op):
     da, db, do = ctx.upload(a), ctx.upload(b), ctx.alloc_fe(n)
     ctx._check(lib.pk_selftest_arith_device(ctx.handle, op, da.ptr, db.ptr, do.ptr, n))
     assert np.array_equal(ctx.download_fe(do, n), host)
+
+
+def test_fp52_prototype_device_equals_host_and_definition(ctx):
+    """csrc/fe52.hpp on the device (MODE.FP_ROUND = RTZ set by the kernel) against the host execution under
+    fesetround(FE_TOWARDZERO) and against x^2 * 2^-260 mod p."""
+    import ctypes as C
+
+    from provekit_amd._lib import lib
+    from test_fp52_host import check_fp52, fp52_inputs, limbs4
+
+    vals = fp52_inputs(100_000, 53)
+    a = limbs4(vals)
+    n = len(vals)
+    host = np.zeros((n, 5), dtype=np.uint64)
+    assert lib.pk_selftest_fp52_sqr(a.ctypes.data, host.ctypes.data, n) == 0
+    da, do = ctx.upload(a), ctx.alloc_fe(2 * n)
+    ctx._check(lib.pk_selftest_fp52_sqr_device(ctx.handle, da.ptr, do.ptr, n))
+    dev = np.zeros((n, 5), dtype=np.uint64)
+    ctx._check(lib.pk_memcpy_d2h(ctx.handle, dev.ctypes.data, do.ptr, dev.nbytes))
+    assert np.array_equal(dev, host)
+    check_fp52(vals[:5000], dev)
