@@ -218,7 +218,7 @@ def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3):
     ms = []
     for i in range(reps + 1):
         ctx.timer_start()
-        ctx._check(lib.pk_commit_into(ctx.handle, ptrs, 2, n_vars, 1, 4, leaves.ptr, nodes.ptr, scratch.ptr, root_buf))
+        ctx._check(lib.pk_commit_into(ctx.handle, ptrs, 2, n_vars, 1, 4, leaves.ptr, nodes.ptr, scratch.ptr, root_buf, None))
         t = ctx.timer_stop()
         if i:
             ms.append(t)
@@ -272,7 +272,7 @@ def commit_workload(args, rank, local_rank, world, dist, torch):
     root = (C.c_uint8 * 32)()
 
     def commit():
-        ctx._check(lib.pk_commit_into(ctx.handle, ptrs, 2, m, 1, 4, leaves.ptr, nodes.ptr, scratch.ptr, root))
+        ctx._check(lib.pk_commit_into(ctx.handle, ptrs, 2, m, 1, 4, leaves.ptr, nodes.ptr, scratch.ptr, root, None))
 
     def barrier():
         torch.cuda.synchronize()

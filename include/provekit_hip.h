@@ -279,6 +279,9 @@ int pk_pow_check(pk_ctx *ctx, const uint8_t challenge[32], double bits, uint64_t
 
 /* The leaf half of an opening by itself: k rows of a codeword matrix the caller holds on the device (one rank's shard of
  * a multi-GPU commit -- SURVEY 8e: leaf i is served by GPU i mod G) gathered to leaf-major host memory, k*width FEs. */
+int pk_gather_leaves_enc(pk_ctx *ctx, const uint64_t *d_leaves, size_t n_leaves, size_t width, int layout, int encoding,
+                         const uint64_t *indices, size_t k, int canonical_leaves, uint64_t *leaves_out);
+/* the same for Montgomery leaves (encoding = PK_LEAVES_MONTGOMERY) */
 int pk_gather_leaves(pk_ctx *ctx, const uint64_t *d_leaves, size_t n_leaves, size_t width, int layout,
                      const uint64_t *indices, size_t k, int canonical_leaves, uint64_t *leaves_out);
 /* ------------------------------------------------------------------ commitment handle + openings (N1+N2+M1+M2, Q1)
@@ -296,11 +299,33 @@ int pk_gather_leaves(pk_ctx *ctx, const uint64_t *d_leaves, size_t n_leaves, siz
 int pk_commit(pk_ctx *ctx, const uint64_t *const *d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
               unsigned fold, uint8_t root_out[32], pk_tree **out);
 /* pk_commit into caller-owned device buffers (no allocation; sizes in FEs from pk_commit_sizes, which account for the
- * context's device set: a rank of G keeps 1/G of the codeword rows).  d_nodes is the full heap on every rank. */
+ * context's device set: a rank of G keeps 1/G of the codeword rows).  d_nodes is the full heap on every rank.
+ * ENCODING OF d_leaves.  The codeword a commit leaves behind is the library's own working form, described by the
+ * pk_commit_layout it reports (layout_out, or pk_tree_layout for a pk_tree):
+ *   n_shards / shard   rows i = shard (mod n_shards) are present, local row t = i / n_shards (1 / 0 outside a device set)
+ *   encoding           PK_LEAVES_MONTGOMERY: elements are Montgomery images (what pk_rs_encode / pk_leaf_hash take and give);
+ *                      PK_LEAVES_SCALED32: elements are the plain integers 32*v mod p, lazily reduced (< 1.6 p) -- the form the
+ *                      Skyscraper kernels compute in (csrc/skyscraper29s.hpp), emitted by the commit's NTT from 2^11 local rows
+ *                      up, so the leaf hash converts nothing.
+ * Which encoding a commit uses is a function of (device set, rows) only.  Raw buffers in PK_LEAVES_SCALED32 must NOT be handed
+ * to pk_tree_from_leaves / pk_leaf_hash / pk_gather_leaves (they assume Montgomery): open them with pk_commit_open, or gather
+ * rows with pk_gather_leaves_enc; both convert the opened rows back to canonical / Montgomery. */
+#define PK_LEAVES_MONTGOMERY 0
+#define PK_LEAVES_SCALED32 1
+typedef struct pk_commit_layout {
+    unsigned n_shards, shard;
+    int encoding;
+} pk_commit_layout;
 int pk_commit_sizes(const pk_ctx *ctx, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
                     size_t *leaves_fes, size_t *nodes_fes, size_t *scratch_fes);
 int pk_commit_into(pk_ctx *ctx, const uint64_t *const *d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
-                   unsigned fold, uint64_t *d_leaves, uint64_t *d_nodes, uint64_t *d_scratch, uint8_t root_out[32]);
+                   unsigned fold, uint64_t *d_leaves, uint64_t *d_nodes, uint64_t *d_scratch, uint8_t root_out[32],
+                   pk_commit_layout *layout_out);
+/* pk_tree_open for buffers written by pk_commit_into, under the layout it reported */
+int pk_commit_open(pk_ctx *ctx, const uint64_t *d_leaves, const uint64_t *d_nodes, size_t n_leaves, size_t width,
+                   const pk_commit_layout *layout, const uint64_t *indices, size_t k, int canonical_leaves,
+                   uint64_t *leaves_out, uint64_t *sibling_digests, uint64_t *auth_paths);
+int pk_tree_layout(const pk_tree *tree, pk_commit_layout *layout);
 int pk_tree_from_leaves(pk_ctx *ctx, const uint64_t *d_leaves, size_t n_leaves, size_t width, int layout,
                         uint8_t root_out[32], pk_tree **out);
 int pk_tree_info(const pk_tree *tree, size_t *n_leaves, size_t *width, const uint64_t **d_leaves,
@@ -349,7 +374,9 @@ typedef struct pk_whir_config {
  * variables), queries = ceil((security - pow)/log_inv_rate) against the OLD rate, 1 OOD sample while
  * 2*list_size + n < field_bits, pow_bits[r] = max(0, security - min(queries*log_inv_rate, combination error)) -- and it is
  * pinned by the reference's proof fixture: for n = 21 it yields queries 109/28/16/11, final 9, one OOD sample per round,
- * and a nonce in every round, exactly the shape SURVEY Appendix A decodes (tests/test_host_only.py).  Host only. */
+ * and a nonce in every round, exactly the shape SURVEY Appendix A decodes (tests/test_host_only.py).  Host only.
+ * Smallest size: n_vars >= folding_factor (PK_ERR_BAD_ARG below it): pk_prove always folds folding_factor variables before the
+ * first re-commit, so the blinding scheme of m_0 = 1 (3 variables at fold 4) does not exist here; m_0 >= 2. */
 int pk_whir_config_derive(unsigned n_vars, unsigned batch_size, unsigned folding_factor, unsigned starting_log_inv_rate,
                           unsigned security_level, int pow_bits, pk_whir_config *out);
 int pk_scheme_create(pk_ctx *ctx, const pk_r1cs *r1cs, size_t num_constraints, size_t num_witnesses, unsigned m, unsigned m_0,

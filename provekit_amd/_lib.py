@@ -43,6 +43,15 @@ vp = C.c_void_p
 sz = C.c_size_t
 
 # name -> (restype, argtypes); kept in the same order as include/provekit_hip.h
+
+class CommitLayout(C.Structure):
+    """pk_commit_layout: how a commit laid its codeword out (include/provekit_hip.h)"""
+
+    _fields_ = [("n_shards", C.c_uint), ("shard", C.c_uint), ("encoding", C.c_int)]
+
+
+LEAVES_MONTGOMERY, LEAVES_SCALED32 = 0, 1
+
 SIGNATURES = {
     "pk_abi_version": (C.c_int, []),
     "pk_device_count": (C.c_int, [C.POINTER(C.c_int)]),
@@ -111,7 +120,10 @@ SIGNATURES = {
     "pk_pow_check": (C.c_int, [vp, vp, C.c_double, C.c_uint64, C.POINTER(C.c_int)]),
     "pk_commit": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, C.POINTER(vp)]),
     "pk_commit_sizes": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
-    "pk_commit_into": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp, vp, vp]),
+    "pk_commit_into": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp, vp, vp, vp]),
+    "pk_commit_open": (C.c_int, [vp, vp, vp, sz, sz, vp, vp, sz, C.c_int, vp, vp, vp]),
+    "pk_tree_layout": (C.c_int, [vp, vp]),
+    "pk_gather_leaves_enc": (C.c_int, [vp, vp, sz, sz, C.c_int, C.c_int, vp, sz, C.c_int, vp]),
     "pk_tree_from_leaves": (C.c_int, [vp, vp, sz, sz, C.c_int, vp, C.POINTER(vp)]),
     "pk_tree_info": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(vp), C.POINTER(vp)]),
     "pk_tree_root": (C.c_int, [vp, vp, vp]),

@@ -53,7 +53,8 @@ RcclApi* rccl() {
                 if (api.handle) break;
             }
         if (!api.handle) {
-            api.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+            const char* e = dlerror();  // one call: dlerror() clears the message it returns
+            api.error = std::string("librccl not found: ") + (e ? e : "dlopen failed");
             return;
         }
 #define PK_SYM(field, name)                                                  \
@@ -91,16 +92,25 @@ struct LocalGroup {
     const void* send[PK_MAX_RANKS] = {};
     hipEvent_t ready[PK_MAX_RANKS] = {};
     int refs = 0;
-    void barrier() {
+    bool aborted = false;  // sticky: a rank failed before or inside a collective; every later collective fails on every rank
+    // false = the group was aborted (by this or another rank): nobody waits for a rank that will not come
+    bool barrier() {
         std::unique_lock<std::mutex> lk(mu);
+        if (aborted) return false;
         const unsigned long long gen = generation;
         if (++arrived == world) {
             arrived = 0;
             generation++;
             cv.notify_all();
         } else {
-            cv.wait(lk, [&] { return generation != gen; });
+            cv.wait(lk, [&] { return generation != gen || aborted; });
         }
+        return !aborted;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lk(mu);
+        aborted = true;
+        cv.notify_all();
     }
 };
 
@@ -141,17 +151,32 @@ int comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes)
         PK_RCCL(ctx, rccl()->AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, ctx->stream));
         return PK_OK;
     }
+    // a rank that fails must not leave the others waiting at the barrier: it aborts the group, which wakes them with an error
     LocalGroup* g = c->grp;
-    PK_HIP(ctx, hipEventRecord(g->ready[c->rank], ctx->stream));  // the send buffer is complete at this point of the stream
+    auto fail = [&](hipError_t e, const char* what) {
+        g->abort();
+        return set_err(ctx, PK_ERR_HIP, "%s failed in the in-process all-gather: %s", what, hipGetErrorString(e));
+    };
+    const char* peer_failed = "a rank of the device set failed; the communicator is unusable";
+    hipError_t e = hipEventRecord(g->ready[c->rank], ctx->stream);  // the send buffer is complete at this point of the stream
+    if (e != hipSuccess) return fail(e, "hipEventRecord");
     g->send[c->rank] = d_send;
-    g->barrier();
+    if (!g->barrier()) return set_err(ctx, PK_ERR_RCCL, "%s", peer_failed);
     for (int p = 0; p < c->world; p++) {
-        PK_HIP(ctx, hipStreamWaitEvent(ctx->stream, g->ready[p], 0));
-        PK_HIP(ctx, hipMemcpyAsync((char*)d_recv + (size_t)p * bytes, g->send[p], bytes, hipMemcpyDefault, ctx->stream));
+        if ((e = hipStreamWaitEvent(ctx->stream, g->ready[p], 0)) != hipSuccess) return fail(e, "hipStreamWaitEvent");
+        if ((e = hipMemcpyAsync((char*)d_recv + (size_t)p * bytes, g->send[p], bytes, hipMemcpyDefault, ctx->stream)) != hipSuccess)
+            return fail(e, "hipMemcpyAsync");
     }
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    g->barrier();  // every rank has read every send buffer: they may be reused
+    if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
+    if (!g->barrier()) return set_err(ctx, PK_ERR_RCCL, "%s", peer_failed);  // every rank has read every send buffer: they may be reused
     return PK_OK;
+}
+
+// A rank that fails BEFORE reaching a collective (e.g. its encode ran out of memory) calls this so that the ranks already
+// waiting in the collective return an error instead of blocking forever.  RCCL: nothing to do here (its own abort / timeout).
+void comm_abort(pk_ctx* ctx) {
+    pk_comm* c = ctx->comm;
+    if (c && c->kind == PK_COMM_LOCAL && c->grp) c->grp->abort();
 }
 
 int comm_all_reduce_sum_u64(pk_ctx* ctx, uint64_t* d_buf, size_t count) {
@@ -249,10 +274,13 @@ int pk_comm_init_local(pk_ctx* const* ctxs, int n) {
     g->refs = n;
     pk_comm* cs[PK_MAX_RANKS] = {};
     bool ok = true;
+    int caller_device = 0;
+    const bool have_caller_device = hipGetDevice(&caller_device) == hipSuccess;
     for (int i = 0; i < n && ok; i++) {
         cs[i] = new (std::nothrow) pk_comm();
         ok = cs[i] && hipSetDevice(ctxs[i]->device) == hipSuccess && hipEventCreateWithFlags(&g->ready[i], hipEventDisableTiming) == hipSuccess;
     }
+    if (have_caller_device) (void)hipSetDevice(caller_device);  // the caller's current device is not ours to change
     if (!ok) {
         for (int i = 0; i < n; i++) {
             delete cs[i];
@@ -292,6 +320,8 @@ int pk_ctx_create_set(const int* devices, int n, pk_ctx** out) {
                 ncclResult_t r = a->CommInitAll(comms, n, devices);
                 if (r != ncclSuccess) rc = rccl_fail(out[0], "ncclCommInitAll", r);
             }
+            const bool have_comms = !rc;
+            int adopted = 0;  // communicators now owned by a context (released with it)
             for (int i = 0; i < n && !rc; i++) {
                 pk_comm* c = new (std::nothrow) pk_comm();
                 if (!c) {
@@ -303,7 +333,10 @@ int pk_ctx_create_set(const int* devices, int n, pk_ctx** out) {
                 c->world = n;
                 c->nccl = comms[i];
                 out[i]->comm = c;
+                adopted = i + 1;
             }
+            if (rc && have_comms)
+                for (int i = adopted; i < n; i++) (void)a->CommDestroy(comms[i]);  // not adopted: would leak
         }
     }
     if (rc) {

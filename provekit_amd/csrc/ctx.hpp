@@ -157,6 +157,7 @@ int comm_rank(const pk_ctx* ctx);
 int comm_world(const pk_ctx* ctx);
 int comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 int comm_all_reduce_sum_u64(pk_ctx* ctx, uint64_t* d_buf, size_t count);
+void comm_abort(pk_ctx* ctx);  // wake the ranks waiting in a collective this rank will never reach (in-process transport)
 void comm_release(pk_ctx* ctx);
 void ntt_release_ctx(pk_ctx* ctx);  // ntt.hip: frees the per-context twiddle tables
 

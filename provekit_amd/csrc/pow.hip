@@ -147,6 +147,7 @@ int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
     // of the expected work: enough lanes to keep the search short, few enough that little is wasted after the first hit.
     unsigned wbits = (unsigned)bits + 5;
     if (wbits < 12) wbits = 12;
+    if (wbits > 62) wbits = 62;  // bits in [58, 60) would shift by >= 63; the loop below moves the window on a miss
     unsigned long long window = 1ull << wbits;
     unsigned lbits = (unsigned)bits > 2 ? (unsigned)bits - 2 : 0;
     if (lbits < 12) lbits = 12;

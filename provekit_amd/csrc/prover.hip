@@ -27,9 +27,9 @@ using namespace pk;
 
 namespace pk {
 int commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
-                uint64_t* d_leaves, uint64_t* d_nodes, uint64_t* d_scratch);
-int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, size_t n_leaves, size_t width, const uint64_t* indices,
-             size_t k, int canonical_leaves, uint64_t* leaves_out, uint64_t* sibling_digests, uint64_t* auth_paths);
+                uint64_t* d_leaves, uint64_t* d_nodes, uint64_t* d_scratch, pk_commit_layout* layout_out);
+int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, size_t n_leaves, size_t width, const pk_commit_layout& lay,
+             const uint64_t* indices, size_t k, int canonical_leaves, uint64_t* leaves_out, uint64_t* sibling_digests, uint64_t* auth_paths);
 unsigned shard_factor(const pk_ctx* ctx, size_t rows);
 size_t commit_scratch_fes(const pk_ctx* ctx, size_t rows, size_t width);
 int lincomb2(pk_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* beta, const uint64_t* d_b, size_t n);
@@ -217,12 +217,12 @@ void pow_round(pk_ctx* ctx, Transcript& T, double bits, int* rc) {
 
 // hints: stir_answers = Vec<Vec<F>> and merkle_proof = ark MultiPath, ark-serialize uncompressed (common.go:36-61)
 int emit_opening_hints(pk_ctx* ctx, Transcript& T, const fe* d_leaves, const fe* d_nodes, size_t n_leaves, size_t width,
-                       const std::vector<uint64_t>& idx) {
+                       const pk_commit_layout& lay, const std::vector<uint64_t>& idx) {
     const size_t k = idx.size();
     const unsigned logn = ilog2(n_leaves);
     const size_t plen = logn ? logn - 1 : 0;
     std::vector<uint64_t> leaves(4 * k * width), sib(4 * (k ? k : 1)), paths(4 * (k * plen ? k * plen : 1));
-    CK(open_raw(ctx, U(d_leaves), U(d_nodes), n_leaves, width, idx.data(), k, /*canonical=*/1, leaves.data(), sib.data(), paths.data()));
+    CK(open_raw(ctx, U(d_leaves), U(d_nodes), n_leaves, width, lay, idx.data(), k, /*canonical=*/1, leaves.data(), sib.data(), paths.data()));
     std::vector<uint8_t> buf;
     auto put_u64 = [&](uint64_t v) {
         for (int i = 0; i < 8; i++) buf.push_back((uint8_t)(v >> (8 * i)));
@@ -250,6 +250,7 @@ struct Commitment {  // whir::committer::Witness
     fe* leaves = nullptr;
     fe* nodes = nullptr;
     size_t rows = 0, width = 0;
+    pk_commit_layout layout{};    // how commit_into laid the codeword out (shards, leaf encoding): recorded, not recomputed
     std::vector<fe> ood_points;   // Montgomery
     std::vector<fe> ood_answers;  // [poly][point], Montgomery
     fe beta;                      // batching randomness
@@ -270,7 +271,7 @@ int whir_commit(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, fe* const* pol
     CK(ensure_ws(ctx, commit_scratch_fes(ctx, C.rows, C.width) * 32));
     const uint64_t* ptrs[4];
     for (unsigned b = 0; b < batch; b++) ptrs[b] = U(polys[b]);
-    CK(commit_into(ctx, ptrs, batch, cfg.n_vars, cfg.starting_log_inv_rate, k, U(leaves), U(nodes), (uint64_t*)ctx->d_ws));
+    CK(commit_into(ctx, ptrs, batch, cfg.n_vars, cfg.starting_log_inv_rate, k, U(leaves), U(nodes), (uint64_t*)ctx->d_ws, &C.layout));
     fe root;
     CK(read_root(ctx, U(nodes), C.rows, (uint64_t*)root.v));
     T.add_canon(root);
@@ -385,6 +386,7 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
     const fe* prev_leaves = C.leaves;
     const fe* prev_nodes = C.nodes;
     size_t prev_rows = C.rows, prev_width = C.width;
+    pk_commit_layout prev_layout = C.layout;
     unsigned nv = n, log_inv_rate = cfg.starting_log_inv_rate;
     size_t domain_size = (size_t)1 << (n + log_inv_rate);
     // generator of the starting domain and its 2^k-th power (whir.go:99)
@@ -412,7 +414,8 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
         ALLOC(nodes, 2 * rows);
         CK(ensure_ws(ctx, commit_scratch_fes(ctx, rows, width) * 32));
         const uint64_t* ptr = U(d_c);
-        CK(commit_into(ctx, &ptr, 1, nv, log_inv_rate, k, U(leaves), U(nodes), (uint64_t*)ctx->d_ws));
+        pk_commit_layout layout;
+        CK(commit_into(ctx, &ptr, 1, nv, log_inv_rate, k, U(leaves), U(nodes), (uint64_t*)ctx->d_ws, &layout));
         fe root;
         CK(read_root(ctx, U(nodes), rows, (uint64_t*)root.v));
         T.add_canon(root);
@@ -433,7 +436,7 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
         CK(prc);
         // Q1: STIR queries into the previous tree
         std::vector<uint64_t> idx = stir_queries(T, domain_size, k, cfg.num_queries[r]);
-        CK(emit_opening_hints(ctx, T, prev_leaves, prev_nodes, prev_rows, prev_width, idx));
+        CK(emit_opening_hints(ctx, T, prev_leaves, prev_nodes, prev_rows, prev_width, prev_layout, idx));
         // W2: equality weights of the OOD and STIR points, scaled by powers of the combination randomness
         gamma = T.challenge_scalar();
         g = fe_one();
@@ -457,6 +460,7 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
         prev_nodes = nodes;
         prev_rows = rows;
         prev_width = width;
+        prev_layout = layout;
         domain_size /= 2;
         exp_gen = h_mul(exp_gen, exp_gen);
     }
@@ -473,7 +477,7 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
         pow_round(ctx, T, cfg.final_pow_bits, &prc);
         CK(prc);
         std::vector<uint64_t> idx = stir_queries(T, domain_size, k, cfg.final_queries);
-        CK(emit_opening_hints(ctx, T, prev_leaves, prev_nodes, prev_rows, prev_width, idx));
+        CK(emit_opening_hints(ctx, T, prev_leaves, prev_nodes, prev_rows, prev_width, prev_layout, idx));
         CK(sumcheck_rounds(nv, rs));
         prc = PK_OK;
         pow_round(ctx, T, cfg.final_folding_pow_bits, &prc);  // whir.go:196-201
@@ -800,6 +804,9 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
 // WhirConfig::new for provekit's parameters (provekit/r1cs-compiler/src/whir_r1cs.rs:38-53); see include/provekit_hip.h
 int pk_whir_config_derive(unsigned n_vars, unsigned batch_size, unsigned folding_factor, unsigned starting_log_inv_rate,
                           unsigned security_level, int pow_bits, pk_whir_config* out) {
+    // n_vars < folding_factor: whir would run no folding round at all; this prover always folds folding_factor variables before
+    // the first re-commit (pk_scheme_create requires n_vars >= folding_factor * (n_rounds + 1)), so the smallest scheme is
+    // n_vars = folding_factor -- m_0 >= 2 for the blinding scheme at fold 4 (include/provekit_hip.h)
     if (!out || folding_factor < 1 || folding_factor > 8 || n_vars < folding_factor || starting_log_inv_rate < 1 || batch_size < 1) return PK_ERR_BAD_ARG;
     const unsigned k = folding_factor;
     const double field_bits = 254.0, sec = (double)security_level;

@@ -135,6 +135,7 @@ int pk_r1cs_create(pk_ctx* ctx, size_t num_constraints, size_t num_witnesses, co
     if (hipMalloc((void**)&r->d_interner, (n_interned ? n_interned : 1) * 32) != hipSuccess) return fail(set_err(ctx, PK_ERR_OOM, "hipMalloc interner"));
     if (n_interned && hipMemcpy(r->d_interner, interner, n_interned * 32, hipMemcpyHostToDevice) != hipSuccess)
         return fail(set_err(ctx, PK_ERR_HIP, "interner upload"));
+    try {  // the host-side index arrays are sized by caller-supplied dimensions: no exception may cross the C ABI
     for (int m = 0; m < 3; m++) {
         const pk_sparse_matrix& M = mats[m];
         const size_t nnz = M.nnz;
@@ -167,6 +168,9 @@ int pk_r1cs_create(pk_ctx* ctx, size_t num_constraints, size_t num_witnesses, co
         if ((rc = upload_u32(ctx, rp, &r->csr_ptr[m])) || (rc = upload_u32(ctx, ci, &r->csr_idx[m])) || (rc = upload_u32(ctx, vv, &r->csr_val[m])) ||
             (rc = upload_u32(ctx, cp, &r->csc_ptr[m])) || (rc = upload_u32(ctx, ri, &r->csc_idx[m])) || (rc = upload_u32(ctx, cv, &r->csc_val[m])))
             return fail(rc);
+    }
+    } catch (const std::bad_alloc&) {
+        return fail(set_err(ctx, PK_ERR_OOM, "host memory exhausted while indexing the R1CS (%zu x %zu)", num_constraints, num_witnesses));
     }
     *out = r;
     return PK_OK;
@@ -212,8 +216,19 @@ struct PcReader {
 };
 }  // namespace
 
+static int r1cs_from_postcard_impl(pk_ctx* ctx, const uint8_t* bytes, size_t len, pk_r1cs** out, size_t* num_constraints,
+                                   size_t* num_witnesses, size_t* num_public_inputs, size_t* consumed);
 int pk_r1cs_from_postcard(pk_ctx* ctx, const uint8_t* bytes, size_t len, pk_r1cs** out, size_t* num_constraints, size_t* num_witnesses,
                           size_t* num_public_inputs, size_t* consumed) {
+    try {  // untrusted bytes size host vectors: an allocation failure is PK_ERR_OOM, never an exception through extern "C"
+        return r1cs_from_postcard_impl(ctx, bytes, len, out, num_constraints, num_witnesses, num_public_inputs, consumed);
+    } catch (const std::bad_alloc&) {
+        if (out) *out = nullptr;
+        return set_err(ctx, PK_ERR_OOM, "host memory exhausted while decoding the postcard R1CS");
+    }
+}
+static int r1cs_from_postcard_impl(pk_ctx* ctx, const uint8_t* bytes, size_t len, pk_r1cs** out, size_t* num_constraints,
+                                   size_t* num_witnesses, size_t* num_public_inputs, size_t* consumed) {
     if (!ctx || !out) return PK_ERR_BAD_ARG;
     PK_ENTER(ctx);
     *out = nullptr;
@@ -248,6 +263,9 @@ int pk_r1cs_from_postcard(pk_ctx* ctx, const uint8_t* bytes, size_t len, pk_r1cs
         PK_REQUIRE(ctx, nri[m].size() == rows[m], "postcard R1CS: new_row_indices does not have one entry per row");
         PK_REQUIRE(ctx, vv[m].size() == ci[m].size(), "postcard R1CS: values and col_indices differ in length");
         PK_REQUIRE(ctx, rows[m] == rows[0] && cols[m] == cols[0], "postcard R1CS: A, B, C differ in shape");
+        // num_cols comes from untrusted bytes and nothing else in the input bounds it: cap it at the scheme capacity
+        // (pk_scheme_create: m <= 27, witnesses <= 2^(m-1)) before pk_r1cs_create sizes its column arrays from it
+        PK_REQUIRE(ctx, cols[m] <= ((uint64_t)1 << 27), "postcard R1CS: more than 2^27 columns");
     }
     pk_sparse_matrix mats[3];
     for (int m = 0; m < 3; m++) mats[m] = pk_sparse_matrix{nri[m].data(), ci[m].data(), vv[m].data(), ci[m].size()};

@@ -131,12 +131,21 @@ size_t commit_scratch_fes(const pk_ctx* ctx, size_t rows, size_t width) {
 }
 // RS-encode + Merkle commit into caller-owned device buffers (no allocation): leaves = width*rows/shard_factor FEs
 // (column-major; the local shard when sharded), nodes = 2*rows FEs, scratch = commit_scratch_fes FEs.
+pk_commit_layout commit_layout(const pk_ctx* ctx, size_t rows) {
+    pk_commit_layout l;
+    l.n_shards = shard_factor(ctx, rows);
+    l.shard = l.n_shards > 1 ? (unsigned)comm_rank(ctx) : 0;
+    l.encoding = codeword_scaled(ctx, rows) ? PK_LEAVES_SCALED32 : PK_LEAVES_MONTGOMERY;
+    return l;
+}
 int commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
-                uint64_t* d_leaves, uint64_t* d_nodes, uint64_t* d_scratch) {
+                uint64_t* d_leaves, uint64_t* d_nodes, uint64_t* d_scratch, pk_commit_layout* layout_out) {
     const size_t rows = (size_t)1 << (n_vars + log_inv_rate - fold);
     const size_t width = (size_t)batch << fold;
-    const unsigned G = shard_factor(ctx, rows);
-    const bool scaled = codeword_scaled(ctx, rows);
+    const pk_commit_layout lay = commit_layout(ctx, rows);
+    if (layout_out) *layout_out = lay;  // what an opening of these buffers must know: kept WITH the commitment by the caller
+    const unsigned G = lay.n_shards;
+    const bool scaled = lay.encoding == PK_LEAVES_SCALED32;
     if (G == 1) {
         int rc = rs_encode_x(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, d_leaves, d_scratch, scaled);
         if (!rc) rc = leaf_hash_x(ctx, d_leaves, rows, width, d_nodes + 4 * rows, scaled);
@@ -150,15 +159,19 @@ int commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, un
     fe* gathered = dig_local + loc;
     int rc = rs_encode_shard_x(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, (unsigned)comm_rank(ctx), G, d_leaves, d_scratch, scaled);
     if (!rc) rc = leaf_hash_x(ctx, d_leaves, loc, width, (uint64_t*)dig_local, scaled);
-    if (!rc) rc = comm_all_gather(ctx, dig_local, gathered, loc * 32);
+    if (rc) {
+        comm_abort(ctx);  // the other ranks are (or will be) waiting in the all-gather this rank never reaches
+        return rc;
+    }
+    rc = comm_all_gather(ctx, dig_local, gathered, loc * 32);
     if (rc) return rc;
     interleave_digests_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, ctx->stream>>>(gathered, (fe*)d_nodes, rows, G);
     PK_LAUNCH_CHECK(ctx);
     return pk_merkle_inner(ctx, d_nodes, rows);
 }
 // open k leaves of a tree described by raw buffers (same outputs as pk_tree_open)
-int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, size_t n_leaves, size_t width, const uint64_t* indices,
-             size_t k, int canonical_leaves, uint64_t* leaves_out, uint64_t* sibling_digests, uint64_t* auth_paths) {
+int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, size_t n_leaves, size_t width, const pk_commit_layout& lay,
+             const uint64_t* indices, size_t k, int canonical_leaves, uint64_t* leaves_out, uint64_t* sibling_digests, uint64_t* auth_paths) {
     pk_tree t;
     t.d_leaves = (fe*)d_leaves;
     t.d_nodes = (fe*)d_nodes;
@@ -166,9 +179,9 @@ int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, siz
     t.width = width;
     t.owns_leaves = false;
     t.layout = PK_COL_MAJOR;
-    t.n_shards = shard_factor(ctx, n_leaves);  // the decisions commit_into took for this tree
-    t.shard = t.n_shards > 1 ? (unsigned)comm_rank(ctx) : 0;
-    t.scaled = codeword_scaled(ctx, n_leaves);
+    t.n_shards = lay.n_shards;  // the decisions commit_into took for this tree, as recorded at commit time
+    t.shard = lay.shard;
+    t.scaled = lay.encoding == PK_LEAVES_SCALED32;
     return pk_tree_open(ctx, &t, indices, k, canonical_leaves, leaves_out, sibling_digests, auth_paths);
 }
 }  // namespace pk
@@ -200,16 +213,17 @@ int pk_commit(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsi
     if (!t) return PK_ERR_OOM;
     t->n_leaves = rows;
     t->width = width;
-    t->n_shards = shard_factor(ctx, rows);  // > 1: this context is one rank of a device set and keeps only its rows
-    t->shard = t->n_shards > 1 ? (unsigned)comm_rank(ctx) : 0;
-    t->scaled = codeword_scaled(ctx, rows);
+    const pk_commit_layout lay = commit_layout(ctx, rows);
+    t->n_shards = lay.n_shards;  // > 1: this context is one rank of a device set and keeps only its rows
+    t->shard = lay.shard;
+    t->scaled = lay.encoding == PK_LEAVES_SCALED32;
     int rc = PK_OK;
     if (hipMalloc((void**)&t->d_leaves, rows / t->n_shards * width * 32) != hipSuccess || hipMalloc((void**)&t->d_nodes, 2 * rows * 32) != hipSuccess) {
         pk_tree_destroy(ctx, t);
         return set_err(ctx, PK_ERR_OOM, "hipMalloc of the codeword matrix failed");
     }
     rc = ensure_ws(ctx, commit_scratch_fes(ctx, rows, width) * 32);
-    if (!rc) rc = commit_into(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, (uint64_t*)t->d_leaves, (uint64_t*)t->d_nodes, (uint64_t*)ctx->d_ws);
+    if (!rc) rc = commit_into(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, (uint64_t*)t->d_leaves, (uint64_t*)t->d_nodes, (uint64_t*)ctx->d_ws, nullptr);
     if (!rc && root_out) rc = read_root(ctx, (const uint64_t*)t->d_nodes, rows, (uint64_t*)root_out);
     if (rc) {
         pk_tree_destroy(ctx, t);
@@ -230,15 +244,29 @@ int pk_commit_sizes(const pk_ctx* ctx, unsigned batch, unsigned n_vars, unsigned
     return PK_OK;
 }
 int pk_commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
-                   uint64_t* d_leaves, uint64_t* d_nodes, uint64_t* d_scratch, uint8_t root_out[32]) {
+                   uint64_t* d_leaves, uint64_t* d_nodes, uint64_t* d_scratch, uint8_t root_out[32], pk_commit_layout* layout_out) {
     PK_ENTER(ctx);
     PK_REQUIRE(ctx, d_coeffs && d_leaves && d_nodes && d_scratch, "null pointer");
     PK_REQUIRE(ctx, batch >= 1 && batch <= 16, "batch out of range");
     PK_REQUIRE(ctx, fold <= n_vars && fold <= 8, "fold out of range");
     PK_REQUIRE(ctx, n_vars + log_inv_rate - fold <= 27, "domain too large (two-adicity 28)");
-    int rc = commit_into(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, d_leaves, d_nodes, d_scratch);
+    int rc = commit_into(ctx, d_coeffs, batch, n_vars, log_inv_rate, fold, d_leaves, d_nodes, d_scratch, layout_out);
     if (!rc && root_out) rc = read_root(ctx, d_nodes, (size_t)1 << (n_vars + log_inv_rate - fold), (uint64_t*)root_out);
     return rc;
+}
+// the opening that goes with pk_commit_into: the same outputs as pk_tree_open, from the raw buffers and the layout recorded
+// at commit time (so it stays right if the context's communicator changes or goes away between commit and opening -- except
+// that a sharded layout still needs the communicator it was committed under for the exchange of the opened rows)
+int pk_commit_open(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, size_t n_leaves, size_t width, const pk_commit_layout* layout,
+                   const uint64_t* indices, size_t k, int canonical_leaves, uint64_t* leaves_out, uint64_t* sibling_digests, uint64_t* auth_paths) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, d_leaves && d_nodes && layout, "null pointer");
+    PK_REQUIRE(ctx, is_pow2(n_leaves) && width >= 1, "n_leaves must be a power of two");
+    PK_REQUIRE(ctx, layout->n_shards >= 1 && is_pow2(layout->n_shards) && layout->shard < layout->n_shards &&
+                        (layout->encoding == PK_LEAVES_MONTGOMERY || layout->encoding == PK_LEAVES_SCALED32), "bad commit layout");
+    PK_REQUIRE(ctx, layout->n_shards == 1 || (layout->n_shards == (unsigned)comm_world(ctx) && layout->shard == (unsigned)comm_rank(ctx)),
+               "a sharded commitment must be opened on the device set (and rank) it was committed on");
+    return open_raw(ctx, d_leaves, d_nodes, n_leaves, width, *layout, indices, k, canonical_leaves, leaves_out, sibling_digests, auth_paths);
 }
 
 // MerkleTree::new over leaves the caller already holds on the device (borrowed, not copied)
@@ -276,6 +304,14 @@ int pk_tree_info(const pk_tree* t, size_t* n_leaves, size_t* width, const uint64
     if (width) *width = t->width;
     if (d_leaves) *d_leaves = (const uint64_t*)t->d_leaves;
     if (d_nodes) *d_nodes = (const uint64_t*)t->d_nodes;
+    return PK_OK;
+}
+
+int pk_tree_layout(const pk_tree* t, pk_commit_layout* layout) {
+    if (!t || !layout) return PK_ERR_BAD_ARG;
+    layout->n_shards = t->n_shards;
+    layout->shard = t->shard;
+    layout->encoding = t->scaled ? PK_LEAVES_SCALED32 : PK_LEAVES_MONTGOMERY;
     return PK_OK;
 }
 
@@ -338,7 +374,12 @@ int pk_tree_open(pk_ctx* ctx, const pk_tree* t, const uint64_t* indices, size_t 
 // a multi-GPU commit, SURVEY 8e "Openings": leaf i is served by GPU i mod G) to leaf-major host memory.
 int pk_gather_leaves(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, const uint64_t* indices, size_t k,
                      int canonical_leaves, uint64_t* leaves_out) {
+    return pk_gather_leaves_enc(ctx, d_leaves, n_leaves, width, layout, PK_LEAVES_MONTGOMERY, indices, k, canonical_leaves, leaves_out);
+}
+int pk_gather_leaves_enc(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, int encoding, const uint64_t* indices,
+                         size_t k, int canonical_leaves, uint64_t* leaves_out) {
     PK_ENTER(ctx);
+    PK_REQUIRE(ctx, encoding == PK_LEAVES_MONTGOMERY || encoding == PK_LEAVES_SCALED32, "unknown leaf encoding");
     PK_REQUIRE(ctx, k == 0 || (d_leaves && indices && leaves_out), "null pointer");
     PK_REQUIRE(ctx, layout == PK_COL_MAJOR || layout == PK_LEAF_MAJOR, "unknown layout");
     if (!k || !width) return PK_OK;
@@ -351,7 +392,7 @@ int pk_gather_leaves(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, siz
     fe* m_leaves = (fe*)(mail + idx_bytes);
     memcpy(m_idx, indices, k * 8);
     gather_opening_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, ctx->stream>>>((const fe*)d_leaves, nullptr, n_leaves, (unsigned)width, layout, 0, m_idx, k,
-                                                                                canonical_leaves, m_leaves, nullptr, nullptr, false);
+                                                                                canonical_leaves, m_leaves, nullptr, nullptr, encoding == PK_LEAVES_SCALED32);
     PK_LAUNCH_CHECK(ctx);
     PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(leaves_out, m_leaves, 32 * n1);

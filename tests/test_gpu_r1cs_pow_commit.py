@@ -225,7 +225,26 @@ def test_commit_across_the_hash_ready_boundary(ctx, oracle, batch, n_vars):
     d_l, d_n, d_s = (ctx.alloc_fe(x.value) for x in szs)
     ptrs = (C.c_void_p * batch)(*[b.ptr for b in bufs])
     root = (C.c_uint8 * 32)()
-    ctx._check(lib.pk_commit_into(ctx.handle, ptrs, batch, n_vars, 1, 4, d_l.ptr, d_n.ptr, d_s.ptr, root))
+    from provekit_amd._lib import LEAVES_MONTGOMERY, LEAVES_SCALED32, CommitLayout
+
+    lay = CommitLayout()
+    ctx._check(lib.pk_commit_into(ctx.handle, ptrs, batch, n_vars, 1, 4, d_l.ptr, d_n.ptr, d_s.ptr, root, C.byref(lay)))
     assert bytes(root) == c.root
     assert np.array_equal(ctx.download_fe(d_n.view_fe(1), 2 * n - 1), nodes[1:])  # every node of the heap
+    # the layout the commit reports: hash-ready from 2^11 rows, Montgomery below; one shard outside a device set
+    assert (lay.n_shards, lay.shard) == (1, 0)
+    assert lay.encoding == (LEAVES_SCALED32 if n >= 2048 else LEAVES_MONTGOMERY)
+    tl = CommitLayout()
+    assert lib.pk_tree_layout(c.handle, C.byref(tl)) == 0 and (tl.n_shards, tl.shard, tl.encoding) == (1, 0, lay.encoding)
+    # openings of the raw buffers under that layout == the handle's openings == the oracle's
+    k, w, plen = len(idx), 16 * batch, int(np.log2(n)) - 1
+    for canon, want in ((1, lv_c), (0, lv_m)):
+        lo = np.zeros((k, w, 4), dtype=np.uint64)
+        so = np.zeros((k, 4), dtype=np.uint64)
+        po = np.zeros((k, plen, 4), dtype=np.uint64)
+        ctx._check(lib.pk_commit_open(ctx.handle, d_l.ptr, d_n.ptr, n, w, C.byref(lay), idx.ctypes.data, k, canon, lo.ctypes.data, so.ctypes.data, po.ctypes.data))
+        assert np.array_equal(lo, want) and np.array_equal(so, sib) and np.array_equal(po, paths)
+        ro = np.zeros((k, w, 4), dtype=np.uint64)
+        ctx._check(lib.pk_gather_leaves_enc(ctx.handle, d_l.ptr, n, w, 1, lay.encoding, idx.ctypes.data, k, canon, ro.ctypes.data))
+        assert np.array_equal(ro, want)
     c.close()
