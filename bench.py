@@ -273,16 +273,6 @@ def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3):
             "frac_of_hbm_peak": alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "root": root}
 
 
-def join_device_set(ctx, rank, world, dist):
-    """one RCCL communicator behind the C ABI for this run's ranks: rank 0 makes the unique id, torch.distributed (already
-    up for the barrier / timing reduction) broadcasts its 128 bytes, every rank joins (include/provekit_hip.h "device sets")"""
-    import provekit_amd
-
-    box = [provekit_amd.Context.comm_unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    ctx.comm_init_rank(box[0], world, rank)
-
-
 def commit_workload(args, rank, local_rank, world, dist, torch):
     """configs[4]: one batch-2 commit of 2^m coefficients (default m as given; 26 for the BASELINE config), sharded by
     leaf index over the ranks behind the C ABI (pk_commit_into on a context that joined the device set: rank g encodes and
@@ -293,13 +283,14 @@ def commit_workload(args, rank, local_rank, world, dist, torch):
     import provekit_amd
     from provekit_amd._lib import lib
 
+    from provekit_amd.device_set import join_device_set, max_over_ranks
+
     m = args.m
     ctx = provekit_amd.Context(local_rank)
+    # RCCL over xGMI, one rank per GPU; PK_BENCH_ONE_GPU=1 (development aid: every rank on GPU 0, where RCCL cannot form a
+    # communicator) takes the library's host transport over the launcher's gloo group instead -- the same sharded commit code
     one_gpu = os.environ.get("PK_BENCH_ONE_GPU") == "1"
-    if one_gpu and world > 1:
-        return commit_workload_gloo(args, rank, local_rank, world, dist, torch, ctx)
-    if world > 1:
-        join_device_set(ctx, rank, world, dist)
+    transport = join_device_set(ctx, rank, world, dist, "host" if one_gpu else "rccl")  # noqa: F841 (kept alive)
     n = 1 << m
     # seeded uniform coefficients generated on the device (identical on every rank: each rank needs the full vectors)
     polys = []
@@ -332,14 +323,12 @@ def commit_workload(args, rank, local_rank, world, dist, torch):
     for _ in range(args.steps):
         commit()  # blocking: returns the root (stream synchronised)
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0, dist, None if one_gpu else f"cuda:{local_rank}")
     prof = ctx.profile_read()
     if rank == 0:
-        emit_commit_line(args, world, m, dt, prof, bytes(root).hex(), "RCCL all-gather of leaf digests behind the C ABI (pk_commit_into)")
+        emit_commit_line(args, world, m, dt, prof, bytes(root).hex(),
+                         ("host-transport (gloo) all-gather of leaf digests, single-GPU development mode" if one_gpu else
+                          "RCCL all-gather of leaf digests") + " behind the C ABI (pk_commit_into)")
     if dist is not None:
         dist.destroy_process_group()
 
@@ -364,47 +353,6 @@ def emit_commit_line(args, world, m, dt, prof, root_hex, how):
                      "algorithmic_bytes_per_launch": lh_bytes},
         "stage_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])},
     })
-
-
-def commit_workload_gloo(args, rank, local_rank, world, dist, torch, ctx):
-    """development aid only (PK_BENCH_ONE_GPU=1: every rank on GPU 0, gloo): RCCL refuses two ranks on one device, so this mode
-    drives the same shard kernels with torch's collective (provekit_amd/distributed.py) to exercise the launcher contract"""
-    from provekit_amd.distributed import HipShardBackend, ShardedCommitter
-
-    m = args.m
-    be = HipShardBackend(ctx)
-    sc = ShardedCommitter(be, rank=rank, world=world)
-    n = 1 << m
-    polys = []
-    for bidx in range(2):
-        t = torch.randint(0, 2**62, (n, 4), dtype=torch.int64, device=f"cuda:{local_rank}", generator=torch.Generator(device=f"cuda:{local_rank}").manual_seed(17 + bidx))
-        t[:, 3] &= (1 << 60) - 1
-        polys.append(t)
-    ptrs = [int(t.data_ptr()) for t in polys]
-
-    def barrier():
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(max(args.warmup, 1)):
-        root, _, leaves = sc.commit(ptrs, m)
-        be.release(leaves)
-    ctx.profile(True)
-    ctx.profile_reset()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        root, _, leaves = sc.commit(ptrs, m)
-        be.release(leaves)
-    barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    if rank == 0:
-        emit_commit_line(args, world, m, dt, ctx.profile_read(), root.tobytes().hex(), "gloo all-gather (single-GPU development mode)")
-    dist.destroy_process_group()
 
 
 _STDOUT_FD = None
@@ -494,11 +442,14 @@ def main():
     # every prover owns an arena of 26 x 32 B x 2^m (+ workspace, R1CS copy): keep the provers within half of the HBM
     per_prover = 40 * 32 * (1 << m)
     conc = max(1, min(conc, int(0.5 * torch.cuda.get_device_properties(local_rank).total_memory / per_prover)))
+    from provekit_amd.device_set import join_device_set, max_over_ranks
+
     workers = []  # (ctx, prover, witness): one independent prover per worker, all on this rank's GPU
+    transports = []
     for w in range(conc):
         c = provekit_amd.Context(local_rank)
         if args.sharded and world > 1:  # this context is one rank of the device set: its commits are sharded from here on
-            join_device_set(c, rank, world, dist)
+            transports.append(join_device_set(c, rank, world, dist, "host" if one_gpu else "rccl"))
         srank = 0 if args.sharded else rank  # the ranks of a sharded prover hold the SAME statement and witness
         r1cs_w, mats, interner, nc, n_in = synth_r1cs(c, m_0, n_wit, seed=1234 + srank)
         d_z, z_host = satisfying_witness(c, r1cs_w, n_wit, nc, n_in, 99 + srank + 1000 * w)
@@ -546,11 +497,7 @@ def main():
     t0 = time.perf_counter()
     run_proofs(1, args.steps * conc)
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(time.perf_counter() - t0, dist, None if one_gpu else f"cuda:{local_rank}")
     prof = ctx.profile_read()
     # untimed extra pass, one proof at a time on worker 0: isolated kernel durations for the roofline
     # (with several provers in flight the per-launch times above include interference from the other streams)

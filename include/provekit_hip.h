@@ -86,12 +86,27 @@ int pk_ctx_set_hash_version(pk_ctx *ctx, int version);
  *                       the launcher broadcasts its 128 bytes, every rank joins.
  *   pk_comm_init_local  the in-process transport on existing contexts (any devices, also all on one device): copies between
  *                       the ranks' buffers and a host barrier; what a single-GPU box can run.
- * PK_ERR_RCCL: librccl could not be loaded (it is resolved with dlopen at first use) or one of its calls failed. */
+ *   pk_comm_init_host   bring-your-own transport: the caller supplies the all-gather over HOST buffers (MPI, gloo, a test
+ *                       harness); the library stages the send block through pinned memory, calls it, and uploads the result.
+ *                       fn(user, send, recv, bytes_per_rank) must fill recv[r*bytes .. (r+1)*bytes) with rank r's send block on
+ *                       every rank and return 0; it is called on the thread that entered the library, in the same order on all
+ *                       ranks.  Slower than RCCL (two PCIe hops) but works wherever a host collective does -- several processes
+ *                       on one GPU included, which is how the multi-process launch is tested on a single-GPU box.
+ * PK_ERR_RCCL: librccl could not be loaded (it is resolved with dlopen at first use), one of its calls failed, a host
+ * transport's callback returned non-zero, or another rank of the set failed (the communicator is then unusable). */
 #define PK_MAX_RANKS 16
 #define PK_COMM_ID_BYTES 128
 #define PK_COMM_NONE 0
 #define PK_COMM_LOCAL 1
 #define PK_COMM_RCCL 2
+#define PK_COMM_HOST 3
+typedef int (*pk_host_all_gather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+int pk_comm_init_host(pk_ctx *ctx, int world, int rank, pk_host_all_gather_fn fn, void *user);
+/* The leaf-index shard map, host only (the same functions the device code is compiled from, csrc/shard_map.hpp): leaf i of a
+ * commit sharded over n_shards ranks lives on rank i mod n_shards at local row i / n_shards; pk_shard_interleave_digests
+ * places an all-gather's output (rank r's local digests as block r) into the leaf layer of the node heap, nodes[rows + i]. */
+int pk_shard_of_leaf(uint64_t leaf, unsigned n_shards, unsigned *rank, uint64_t *local_row);
+int pk_shard_interleave_digests(const uint64_t *gathered, size_t rows, unsigned n_shards, uint64_t *nodes /* 2*rows FEs */);
 int pk_ctx_create_set(const int *devices, int n, pk_ctx **out /* n entries */);
 int pk_comm_unique_id(uint8_t id[PK_COMM_ID_BYTES]);
 int pk_comm_init_rank(pk_ctx *ctx, const uint8_t id[PK_COMM_ID_BYTES], int world, int rank);

@@ -121,6 +121,9 @@ SIGNATURES = {
     "pk_commit": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, C.POINTER(vp)]),
     "pk_commit_sizes": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
     "pk_commit_into": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp, vp, vp, vp]),
+    "pk_comm_init_host": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
+    "pk_shard_of_leaf": (C.c_int, [C.c_uint64, C.c_uint, vp, vp]),
+    "pk_shard_interleave_digests": (C.c_int, [vp, sz, C.c_uint, vp]),
     "pk_commit_open": (C.c_int, [vp, vp, vp, sz, sz, vp, vp, sz, C.c_int, vp, vp, vp]),
     "pk_tree_layout": (C.c_int, [vp, vp]),
     "pk_gather_leaves_enc": (C.c_int, [vp, vp, sz, sz, C.c_int, C.c_int, vp, sz, C.c_int, vp]),

@@ -131,8 +131,14 @@ struct pk_comm {
     int rank = 0, world = 1;
     ncclComm_t nccl = nullptr;
     LocalGroup* grp = nullptr;
-    void* d_tmp = nullptr;  // LOCAL all-reduce staging, grow-only
+    void* d_tmp = nullptr;  // LOCAL / HOST all-reduce staging, grow-only
     size_t tmp_bytes = 0;
+    // HOST transport: the caller's all-gather over host buffers and the pinned staging it runs between
+    pk_host_all_gather_fn host_fn = nullptr;
+    void* host_user = nullptr;
+    char* h_stage = nullptr;
+    size_t stage_bytes = 0;
+    bool failed = false;  // sticky, like LocalGroup::aborted
 };
 
 namespace pk {
@@ -149,6 +155,29 @@ int comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes)
     ProfScope prof(ctx, "comm_all_gather");
     if (c->kind == PK_COMM_RCCL) {
         PK_RCCL(ctx, rccl()->AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, ctx->stream));
+        return PK_OK;
+    }
+    if (c->kind == PK_COMM_HOST) {
+        if (c->failed) return set_err(ctx, PK_ERR_RCCL, "the host transport failed earlier; the communicator is unusable");
+        const size_t need = bytes * ((size_t)c->world + 1);
+        if (c->stage_bytes < need) {
+            if (c->h_stage) (void)hipHostFree(c->h_stage);
+            c->h_stage = nullptr;
+            c->stage_bytes = 0;
+            PK_HIP(ctx, hipHostMalloc((void**)&c->h_stage, need, hipHostMallocDefault));
+            c->stage_bytes = need;
+        }
+        char* h_send = c->h_stage;
+        char* h_recv = c->h_stage + bytes;
+        PK_HIP(ctx, hipMemcpyAsync(h_send, d_send, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const int frc = c->host_fn(c->host_user, h_send, h_recv, bytes);
+        if (frc) {
+            c->failed = true;
+            return set_err(ctx, PK_ERR_RCCL, "the host transport's all-gather returned %d", frc);
+        }
+        PK_HIP(ctx, hipMemcpyAsync(d_recv, h_recv, bytes * (size_t)c->world, hipMemcpyHostToDevice, ctx->stream));
+        PK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the staging area is reused by the next collective
         return PK_OK;
     }
     // a rank that fails must not leave the others waiting at the barrier: it aborts the group, which wakes them with an error
@@ -222,6 +251,7 @@ void comm_release(pk_ctx* ctx) {
         if (last) delete g;
     }
     if (c->d_tmp) (void)hipFree(c->d_tmp);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     delete c;
     ctx->comm = nullptr;
 }
@@ -260,6 +290,22 @@ int pk_comm_init_rank(pk_ctx* ctx, const uint8_t id[PK_COMM_ID_BYTES], int world
         delete c;
         return rccl_fail(ctx, "ncclCommInitRank", r);
     }
+    ctx->comm = c;
+    return PK_OK;
+}
+
+int pk_comm_init_host(pk_ctx* ctx, int world, int rank, pk_host_all_gather_fn fn, void* user) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, fn && world >= 1 && world <= PK_MAX_RANKS && rank >= 0 && rank < world, "bad rank / world / callback");
+    PK_REQUIRE(ctx, is_pow2((size_t)world), "the number of ranks must be a power of two (leaf-index sharding)");
+    PK_REQUIRE(ctx, !ctx->comm, "context already has a communicator");
+    pk_comm* c = new (std::nothrow) pk_comm();
+    if (!c) return PK_ERR_OOM;
+    c->kind = PK_COMM_HOST;
+    c->rank = rank;
+    c->world = world;
+    c->host_fn = fn;
+    c->host_user = user;
     ctx->comm = c;
     return PK_OK;
 }

@@ -15,6 +15,7 @@
 // memory- / latency-bound kernels: their wavefronts issue ahead of the ALU-bound hash / NTT / grinder kernels they share SIMDs with
 #define PK_BASE_PRIO 2
 #include "ctx.hpp"
+#include "shard_map.hpp"
 #include "skyscraper29s.hpp"
 
 using namespace pk;
@@ -91,8 +92,7 @@ __global__ __launch_bounds__(256) void interleave_digests_kernel(const fe* __res
     PK_LATENCY_PRIO();
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
-    const size_t loc = rows / G;
-    fe_store(nodes + rows + i, fe_load(gathered + (i % G) * loc + i / G));
+    fe_store(nodes + rows + i, fe_load(gathered + shard_gathered_slot(i, rows, G)));
 }
 
 // the opened rows this rank owns, gathered leaf-major into a ZEROED device buffer (the rest stays zero: the all-reduce that
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void gather_owned_rows_kernel(const fe* __rest
     if (t >= k * width) return;
     const size_t q = t / width, j = t % width;
     const size_t i = idx[q];
-    if (i % G != shard) return;
-    fe x = fe_load(leaves_local + j * loc + i / G);
+    if (shard_rank_of_leaf(i, G) != shard) return;
+    fe x = fe_load(leaves_local + j * loc + shard_local_row(i, G));
     fe_store(out + t, opened_element(x, scaled, canonical));
 }
 
@@ -304,6 +304,18 @@ int pk_tree_info(const pk_tree* t, size_t* n_leaves, size_t* width, const uint64
     if (width) *width = t->width;
     if (d_leaves) *d_leaves = (const uint64_t*)t->d_leaves;
     if (d_nodes) *d_nodes = (const uint64_t*)t->d_nodes;
+    return PK_OK;
+}
+
+int pk_shard_of_leaf(uint64_t leaf, unsigned n_shards, unsigned* rank, uint64_t* local_row) {
+    if (!n_shards || !is_pow2(n_shards)) return PK_ERR_BAD_ARG;
+    if (rank) *rank = shard_rank_of_leaf((size_t)leaf, n_shards);
+    if (local_row) *local_row = shard_local_row((size_t)leaf, n_shards);
+    return PK_OK;
+}
+int pk_shard_interleave_digests(const uint64_t* gathered, size_t rows, unsigned n_shards, uint64_t* nodes) {
+    if (!gathered || !nodes || !is_pow2(rows) || !n_shards || !is_pow2(n_shards) || rows % n_shards) return PK_ERR_BAD_ARG;
+    for (size_t i = 0; i < rows; i++) memcpy(nodes + 4 * (rows + i), gathered + 4 * shard_gathered_slot(i, rows, n_shards), 32);
     return PK_OK;
 }
 

@@ -1,6 +1,7 @@
 """GPU: the shard kernel of the multi-GPU commit (pk_rs_encode_shard): the G shards, interleaved, must equal the unsharded
-encode bit for bit, and the ShardedCommitter (world of 1 on this box, and G simulated ranks run one after another on the
-same GPU) must reproduce the unsharded Merkle root."""
+encode bit for bit; and bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per
+rank) -- on this one-GPU box with both ranks on GPU 0 over the library's host transport (gloo), on a box with >= 2 GPUs
+(skipped here) with one rank per GPU over RCCL."""
 import ctypes as C
 
 import numpy as np
@@ -31,108 +32,42 @@ def test_shards_interleave_to_unsharded_encode(ctx, oracle, batch, n_vars, rho, 
         assert np.array_equal(got, ref[:, g::G]), (g, G)
 
 
-def test_sharded_committer_simulated_ranks(ctx, oracle):
-    import torch
-
-    from provekit_amd.distributed import HipShardBackend, ShardedCommitter
-    from provekit_amd.field import random_field
-    from provekit_amd.whir import commit_batch
-
-    n_vars, G = 12, 4
-    host = [random_field(1 << n_vars, 90 + b) for b in range(2)]
-    polys = [ctx.upload(p) for p in host]
-    expect = commit_batch(ctx, polys, n_vars).root
-    be = HipShardBackend(ctx)
-    try:
-        # world of 1: the real code path end to end
-        root, nodes, _ = ShardedCommitter(be, rank=0, world=1).commit(polys, n_vars)
-        assert root.tobytes() == expect
-        # G ranks simulated sequentially: gather by hand what all_gather would deliver
-        rows = 1 << (n_vars + 1 - 4)
-        digs = []
-        for g in range(G):
-            _, d = be.encode_and_hash_shard(polys, n_vars, 1, 4, g, G)
-            with be.stream_ctx():
-                digs.append(d.clone())
-        with be.stream_ctx():
-            nodes = be.new_nodes(rows)
-            nodes[rows:] = torch.stack(digs, dim=1).reshape(rows, 4)
-            be.merkle_inner(nodes, rows)
-            assert nodes[1].cpu().numpy().view(np.uint64).tobytes() == expect
-    finally:
-        ctx.set_stream(None)
-
-
-def test_sharded_open_matches_unsharded(ctx, oracle):
-    """ShardedCommitter.open (world 1 on this box): the same triple Commitment.open returns; and pk_gather_leaves on a
-    real shard (rank g of 4) returns rows g, g+4, ... of the unsharded codeword."""
-    from provekit_amd._lib import PK_COL_MAJOR, lib
-    from provekit_amd.distributed import HipShardBackend, ShardedCommitter
-    from provekit_amd.field import random_field
-    from provekit_amd.whir import commit_batch
-
-    n_vars, G = 11, 4
-    polys = [ctx.upload(random_field(1 << n_vars, 190 + b)) for b in range(2)]
-    ref = commit_batch(ctx, polys, n_vars)
-    rows = ref.n_leaves
-    idx = np.array([0, 3, 4, 77, rows // 2 + 1, rows - 1], dtype=np.uint64)
-    lv_ref, sib_ref, paths_ref = ref.open(idx, canonical_leaves=False)
-    be = HipShardBackend(ctx)
-    try:
-        sc = ShardedCommitter(be, rank=0, world=1)
-        root, nodes, local = sc.commit(polys, n_vars)
-        assert root.tobytes() == ref.root
-        lv, sib, paths = sc.open(idx, local, nodes, 32)
-        assert np.array_equal(lv, lv_ref) and np.array_equal(sib, sib_ref) and np.array_equal(paths, paths_ref)
-        all_rows = np.arange(rows, dtype=np.uint64)
-        full, _, _ = ref.open(all_rows, canonical_leaves=False)
-        for g in range(G):
-            shard, _ = be.encode_and_hash_shard(polys, n_vars, 1, 4, g, G)
-            want = np.arange(g, rows, G)
-            local_rows = np.array([1, 0, rows // G - 1, 5], dtype=np.uint64)
-            out = np.zeros((len(local_rows), 32, 4), dtype=np.uint64)
-            ctx._check(lib.pk_gather_leaves(ctx.handle, shard.ptr, rows // G, 32, PK_COL_MAJOR, local_rows.ctypes.data, len(local_rows), 0, out.ctypes.data))
-            assert np.array_equal(out, full[want[local_rows.astype(np.int64)]])
-            be.release(shard)
-    finally:
-        ctx.set_stream(None)
-    ref.close()
-
-
-def test_bench_multirank_control_flow_on_one_gpu(ctx, oracle):
-    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one process per rank), with
-    PK_BENCH_ONE_GPU=1 putting both ranks on GPU 0 over gloo: the sharded commit's root must be the unsharded root, and the
-    prove workload must aggregate over the ranks and print exactly one JSON line."""
+def _launch_bench(extra, one_gpu, nproc=2, timeout=900):
     import json
     import os
+    import socket
     import subprocess
     import sys
 
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("PK_BENCH_ONE_GPU", None)
+    if one_gpu:
+        env["PK_BENCH_ONE_GPU"] = "1"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1", "--master-port",
+           str(port), os.path.join(root_dir, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1"] + extra
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines  # one JSON line on stdout, whatever the libraries print
+    return json.loads(lines[0])
+
+
+def _check_multirank_bench(ctx, one_gpu):
+    """the launcher contract at two ranks: sharded commit root == unsharded root; independent provers aggregate over the ranks;
+    ONE proof sharded over the two ranks (--sharded) runs through join_device_set and prints one line"""
     import torch
 
     from provekit_amd.whir import commit_batch
 
-    import socket
-
-    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PK_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
-
-    def free_port():
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            return sk.getsockname()[1]
-
-    def launch(extra, port):
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-               str(port), os.path.join(root_dir, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + extra
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stderr[-2000:]
-        lines = [l for l in out.stdout.splitlines() if l.strip()]
-        assert len(lines) == 1, lines  # one JSON line on stdout, whatever the libraries print
-        return json.loads(lines[0])
+    def launch(extra):
+        return _launch_bench(extra, one_gpu)
 
     m = 15
-    d = launch(["--workload", "commit", "--log2-size", str(m)], free_port())
+    d = launch(["--workload", "commit", "--log2-size", str(m)])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     polys = []
     for b in range(2):  # the seeded coefficients bench.py's commit workload generates
@@ -143,8 +78,30 @@ def test_bench_multirank_control_flow_on_one_gpu(ctx, oracle):
     ref = commit_batch(ctx, [int(t.data_ptr()) for t in polys], m)
     assert d["config"]["root"] == ref.root.hex()
     ref.close()
-    p = launch(["--workload", "prove", "--log2-size", "13", "--concurrency", "2", "--no-cpu-baseline"], free_port())
+    p = launch(["--workload", "prove", "--log2-size", "13", "--concurrency", "2", "--no-cpu-baseline"])
     assert p["n_gpus"] == 2 and p["steps"] == 2 and p["scaling"] == "weak" and p["value"] > 0
     # whole-job aggregate: one step = one wave of `concurrency` proofs per GPU -> ranks x concurrency x steps proofs / time
     assert p["config"]["proofs_per_step"] == 2 * 2
     assert abs(p["value"] - 2 * 2 * 2 / (p["ms_per_step"] * 2 * 1e-3)) / p["value"] < 1e-6
+    # latency mode: one proof at a time sharded over the two ranks (commits of >= 64 rows per rank split by leaf index)
+    sh = launch(["--workload", "prove", "--sharded", "--log2-size", "15", "--no-cpu-baseline"])
+    assert sh["n_gpus"] == 2 and sh["scaling"] == "strong" and sh["config"]["proofs_per_step"] == 1 and sh["value"] > 0
+
+
+def test_bench_multirank_on_one_gpu_host_transport(ctx, oracle):
+    """PK_BENCH_ONE_GPU=1: both ranks on GPU 0 (RCCL refuses that), joined by the library's host transport over the launcher's
+    gloo group -- the same pk_commit_into / pk_prove sharding code as under RCCL, two real processes"""
+    _check_multirank_bench(ctx, one_gpu=True)
+
+
+def test_bench_multirank_over_rccl_needs_two_gpus(ctx, oracle):
+    """one rank per GPU over RCCL / xGMI, exactly as the driver's SCALE run launches it.  Needs >= 2 GPUs: skipped on this box."""
+    import ctypes as C
+
+    from provekit_amd._lib import lib
+
+    n = C.c_int(0)
+    lib.pk_device_count(C.byref(n))
+    if n.value < 2:
+        pytest.skip(f"needs >= 2 GPUs for RCCL between ranks (this box has {n.value})")
+    _check_multirank_bench(ctx, one_gpu=False)

@@ -212,3 +212,160 @@ def test_sharded_prove_bench_size_transcript_identical(ctx, oracle, rank_sets):
                             c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
 
     assert V.verify(want, ds, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
+
+
+def test_sharded_prove_p256_size_class_eight_ranks(ctx, oracle, rank_sets):
+    """BASELINE configs[3] as far as one GPU can take it: the m = 25 size class proven by EIGHT ranks (in-process transport,
+    all on GPU 0) under the derived schedule -- every rank's transcript is byte-identical to the lone prover's, and the
+    verifier accepts it.  Arenas: 8 x ~21 GiB; the lone prover's scheme is closed before the ranks allocate theirs."""
+    import verifier as V
+    from test_gpu_prove import size_class_instance
+
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS, SparseMatrix
+
+    m, m_0, G = 25, 24, 8
+    nc, nw, mats, interner, z = size_class_instance(oracle, m)
+    cfg_w, cfg_b = WhirConfig.derive(m), blinding_config_for(m_0)
+
+    def prove_on(c):
+        r1cs = R1CS(c, *(SparseMatrix(nc, nw, *t) for t in mats), interner)
+        s = WhirR1CSScheme(c, r1cs, m, m_0, cfg_w, cfg_b)
+        d_z = c.upload(z)
+        proof = s.prove(d_z, seed=25)
+        ds = s.domain_separator
+        s.close()
+        r1cs.close()
+        d_z.free()
+        return proof, ds
+
+    want, ds = prove_on(ctx)
+    for proof, _ in run_ranks(rank_sets(G), lambda r, c: prove_on(c)):
+        assert proof == want, "a rank of the 8-way sharded prover diverged from the lone prover's transcript"
+
+    def vcfg(c):
+        return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
+
+    assert V.verify(want, ds, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
+
+
+# ---- >= 2 GPUs: RCCL between distinct devices.  Skipped on a one-GPU box; the first multi-GPU box runs them unchanged. ----------
+def _gpu_count():
+    from provekit_amd._lib import lib
+
+    n = C.c_int(0)
+    lib.pk_device_count(C.byref(n))
+    return n.value
+
+
+@pytest.fixture()
+def rccl_set():
+    """pk_ctx_create_set over the first 2 (4, 8 when present) distinct GPUs: ncclCommInitAll, one host thread per rank"""
+    n = _gpu_count()
+    if n < 2:
+        pytest.skip(f"needs >= 2 GPUs for RCCL between ranks (this box has {n})")
+    import provekit_amd
+
+    made = []
+
+    def make(G):
+        if G > n:
+            pytest.skip(f"needs {G} GPUs (this box has {n})")
+        cs = provekit_amd.Context.create_set(list(range(G)))
+        assert [c.comm_info() for c in cs] == [(r, G, 2) for r in range(G)]  # kind 2 = PK_COMM_RCCL
+        made.append(cs)
+        return cs
+
+    yield make
+    for cs in made:
+        for c in cs:
+            c.close()
+
+
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_rccl_collectives_between_gpus(rccl_set, G):
+    from provekit_amd._lib import lib
+
+    ctxs = rccl_set(G)
+    n = 100_000
+
+    def fn(r, c):
+        send = np.full((n,), r + 1, np.uint64) * np.arange(1, n + 1, dtype=np.uint64)
+        d_send, d_recv = c.upload(send), c.alloc(8 * n * G)
+        c._check(lib.pk_comm_all_gather(c.handle, d_send.ptr, d_recv.ptr, 8 * n))
+        red = np.zeros(n, np.uint64)
+        red[r::G] = 7 + r
+        d_red = c.upload(red)
+        c._check(lib.pk_comm_all_reduce_sum_u64(c.handle, d_red.ptr, n))
+        c.sync()
+        return c.download(d_recv, (G, n)), c.download(d_red, (n,))
+
+    for got, red in run_ranks(ctxs, fn):
+        for p in range(G):
+            assert np.array_equal(got[p], np.full((n,), p + 1, np.uint64) * np.arange(1, n + 1, dtype=np.uint64))
+        assert np.array_equal(red, np.array([7 + (i % G) for i in range(n)], np.uint64))
+
+
+@pytest.mark.parametrize("G,batch,n_vars", [(2, 2, 16), (2, 2, 21), (4, 2, 21), (8, 2, 23)])
+def test_rccl_sharded_commit_and_openings_match_unsharded(ctx, oracle, rccl_set, G, batch, n_vars):
+    from provekit_amd.field import random_field
+    from provekit_amd.whir import commit_batch
+
+    ctxs = rccl_set(G)
+    polys = [random_field(1 << n_vars, 70 + b + n_vars) for b in range(batch)]
+    ref = commit_batch(ctx, [ctx.upload(p) for p in polys], n_vars)
+    rows = ref.n_leaves
+    rng = np.random.default_rng(G + n_vars)
+    idx = np.unique(np.concatenate([rng.integers(0, rows, size=60), [0, rows - 1]])).astype(np.uint64)
+    want = [ref.open(idx, canonical_leaves=cl) for cl in (True, False)]
+
+    def fn(r, c):
+        com = commit_batch(c, [c.upload(p) for p in polys], n_vars)
+        res = (com.root, [com.open(idx, canonical_leaves=cl) for cl in (True, False)])
+        com.close()
+        return res
+
+    for root, opened in run_ranks(ctxs, fn):
+        assert root == ref.root
+        for got, exp in zip(opened, want):
+            for a, b in zip(got, exp):
+                assert np.array_equal(a, b)
+    ref.close()
+
+
+@pytest.mark.parametrize("G,m", [(2, 17), (2, 21), (8, 21), (8, 25)])
+def test_rccl_sharded_prove_transcript_identical(ctx, oracle, rccl_set, G, m):
+    """one proof sharded over G GPUs (BASELINE configs[3] at m = 25, G = 8): byte-identical to the lone prover's transcript"""
+    import verifier as V
+    from test_gpu_prove import size_class_instance
+
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS, SparseMatrix
+
+    ctxs = rccl_set(G)
+    m_0 = m - 1
+    nc, nw, mats, interner, z = size_class_instance(oracle, m)
+    cfg_w, cfg_b = WhirConfig.derive(m), blinding_config_for(m_0)
+
+    def prove_on(c):
+        r1cs = R1CS(c, *(SparseMatrix(nc, nw, *t) for t in mats), interner)
+        s = WhirR1CSScheme(c, r1cs, m, m_0, cfg_w, cfg_b)
+        proofs = [s.prove(c.upload(z), seed=5), s.prove(c.upload(z))]  # injected seed, then production randomness (rank 0's key)
+        ds = s.domain_separator
+        s.close()
+        r1cs.close()
+        return proofs, ds
+
+    want, ds = prove_on(ctx)
+    got = run_ranks(ctxs, lambda r, c: prove_on(c))
+    for proofs, _ in got:
+        assert proofs[0] == want[0]
+        assert proofs[1] == got[0][0][1] and proofs[1] != want[1]
+
+    def vcfg(c):
+        return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
+
+    assert V.verify(want[0], ds, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
+    assert V.verify(got[0][0][1], ds, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
