@@ -23,6 +23,7 @@
 #include <mutex>
 
 #include "ctx.hpp"
+#include "fe29.hpp"
 
 using namespace pk;
 
@@ -93,6 +94,21 @@ struct LocalGroup {
     hipEvent_t ready[PK_MAX_RANKS] = {};
     int refs = 0;
     bool aborted = false;  // sticky: a rank failed before or inside a collective; every later collective fails on every rank
+    // measurement aid (PK_LOCAL_TURNSTILE=1 at pk_comm_init_local): the ranks of this group share ONE GPU in the test-suite, so
+    // their kernels overlap and per-kernel timings mean little.  With the turnstile a rank holds a token while it enqueues and
+    // runs work inside pk_prove and hands it over at every collective, so the ranks' segments run one after another and
+    // pk_profile_* reports each rank's kernels as if it had the chip to itself.
+    bool turnstile = false, token_busy = false;
+    void token_acquire() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !token_busy || aborted; });
+        token_busy = true;
+    }
+    void token_release() {
+        std::lock_guard<std::mutex> lk(mu);
+        token_busy = false;
+        cv.notify_all();
+    }
     // false = the group was aborted (by this or another rank): nobody waits for a rank that will not come
     bool barrier() {
         std::unique_lock<std::mutex> lk(mu);
@@ -124,6 +140,30 @@ __global__ __launch_bounds__(256) void sum_ranks_u64_kernel(const unsigned long 
     }
 }
 
+// the K partial results of every rank (block r = rank r's K field elements), optionally scaled per rank, summed mod p and
+// written to the pinned result page the host reads after the stream synchronisation
+struct rank_scales {
+    u32 v[PK_MAX_RANKS][8];
+};
+__global__ void sum_ranks_fe_kernel(const fe* __restrict__ gathered, unsigned world, unsigned K, rank_scales sc, int scaled, fe* __restrict__ host_out) {
+    const unsigned k = threadIdx.x;
+    if (k >= K) return;
+    fe acc = fe_zero();
+    for (unsigned r = 0; r < world; r++) {
+        fe x = fe_load(gathered + (size_t)r * K + k);
+        if (scaled) {
+            fe s;
+#pragma unroll
+            for (int i = 0; i < 8; i++) s.v[i] = sc.v[r][i];
+            x = fe_mulx(x, s);
+        }
+        acc = fe_add(acc, x);
+    }
+    unsigned* out = reinterpret_cast<unsigned*>(host_out + k);
+#pragma unroll
+    for (int i = 0; i < 8; i++) __hip_atomic_store(out + i, acc.v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace
 
 struct pk_comm {
@@ -139,6 +179,7 @@ struct pk_comm {
     char* h_stage = nullptr;
     size_t stage_bytes = 0;
     bool failed = false;  // sticky, like LocalGroup::aborted
+    bool holds_token = false;  // LOCAL turnstile: between comm_turn_begin and comm_turn_end
 };
 
 namespace pk {
@@ -190,19 +231,45 @@ int comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes)
     hipError_t e = hipEventRecord(g->ready[c->rank], ctx->stream);  // the send buffer is complete at this point of the stream
     if (e != hipSuccess) return fail(e, "hipEventRecord");
     g->send[c->rank] = d_send;
-    if (!g->barrier()) return set_err(ctx, PK_ERR_RCCL, "%s", peer_failed);
+    const bool turn = g->turnstile && c->holds_token;
+    if (turn) {  // this rank's segment ends here: drain it, then let the next rank run
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
+        g->token_release();
+    }
+    const bool arrived = g->barrier();
+    if (turn) g->token_acquire();
+    if (!arrived) return set_err(ctx, PK_ERR_RCCL, "%s", peer_failed);
     for (int p = 0; p < c->world; p++) {
         if ((e = hipStreamWaitEvent(ctx->stream, g->ready[p], 0)) != hipSuccess) return fail(e, "hipStreamWaitEvent");
         if ((e = hipMemcpyAsync((char*)d_recv + (size_t)p * bytes, g->send[p], bytes, hipMemcpyDefault, ctx->stream)) != hipSuccess)
             return fail(e, "hipMemcpyAsync");
     }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
-    if (!g->barrier()) return set_err(ctx, PK_ERR_RCCL, "%s", peer_failed);  // every rank has read every send buffer: they may be reused
+    if (turn) g->token_release();
+    const bool done = g->barrier();  // every rank has read every send buffer: they may be reused
+    if (turn) g->token_acquire();
+    if (!done) return set_err(ctx, PK_ERR_RCCL, "%s", peer_failed);
     return PK_OK;
 }
 
 // A rank that fails BEFORE reaching a collective (e.g. its encode ran out of memory) calls this so that the ranks already
 // waiting in the collective return an error instead of blocking forever.  RCCL: nothing to do here (its own abort / timeout).
+// pk_prove brackets itself with these; no-ops unless the context's in-process group was created with the turnstile on
+void comm_turn_begin(pk_ctx* ctx) {
+    pk_comm* c = ctx->comm;
+    if (c && c->kind == PK_COMM_LOCAL && c->grp && c->grp->turnstile && !c->holds_token) {
+        c->grp->token_acquire();
+        c->holds_token = true;
+    }
+}
+void comm_turn_end(pk_ctx* ctx) {
+    pk_comm* c = ctx->comm;
+    if (c && c->holds_token) {
+        (void)hipStreamSynchronize(ctx->stream);
+        c->holds_token = false;
+        c->grp->token_release();
+    }
+}
 void comm_abort(pk_ctx* ctx) {
     pk_comm* c = ctx->comm;
     if (c && c->kind == PK_COMM_LOCAL && c->grp) c->grp->abort();
@@ -232,6 +299,31 @@ int comm_all_reduce_sum_u64(pk_ctx* ctx, uint64_t* d_buf, size_t count) {
     sum_ranks_u64_kernel<<<grid_for(ctx, count, 256), 256, 0, ctx->stream>>>((const unsigned long long*)c->d_tmp, (unsigned long long*)d_buf, count,
                                                                              (unsigned)c->world);
     PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
+int red_across_begin(pk_ctx* ctx) {
+    if (!ctx->d_xred) PK_HIP(ctx, hipMalloc(&ctx->d_xred, PK_XRED_OWN_BYTES + (size_t)PK_MAX_RANKS * 8 * 32));
+    int rc = ensure_pinned(ctx);
+    if (rc) return rc;
+    ctx->red_across = true;
+    ctx->red_scales = nullptr;
+    return PK_OK;
+}
+
+int comm_collect_fe(pk_ctx* ctx, int K, uint64_t* host_out) {
+    const unsigned world = (unsigned)comm_world(ctx);
+    fe* own = (fe*)ctx->d_xred;
+    fe* gathered = (fe*)((char*)ctx->d_xred + PK_XRED_OWN_BYTES);
+    int rc = comm_all_gather(ctx, own, gathered, (size_t)K * 32);
+    if (rc) return rc;
+    rank_scales sc{};
+    if (ctx->red_scales) memcpy(sc.v, ctx->red_scales, (size_t)world * 32);
+    sum_ranks_fe_kernel<<<1, 64, 0, ctx->stream>>>(gathered, world, (unsigned)K, sc, ctx->red_scales != nullptr, (fe*)ctx->h_pinned);
+    PK_LAUNCH_CHECK(ctx);
+    rc = sync_stream(ctx);
+    if (rc) return rc;
+    memcpy(host_out, ctx->h_pinned, 32 * (size_t)K);
     return PK_OK;
 }
 
@@ -318,6 +410,10 @@ int pk_comm_init_local(pk_ctx* const* ctxs, int n) {
     if (!g) return PK_ERR_OOM;
     g->world = n;
     g->refs = n;
+    {
+        const char* ts = getenv("PK_LOCAL_TURNSTILE");
+        g->turnstile = ts && ts[0] == '1';
+    }
     pk_comm* cs[PK_MAX_RANKS] = {};
     bool ok = true;
     int caller_device = 0;

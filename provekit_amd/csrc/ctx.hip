@@ -50,6 +50,7 @@ int pk_ctx_destroy(pk_ctx* ctx) {
     pk::comm_release(ctx);
     pk::ntt_release_ctx(ctx);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_xred) (void)hipFree(ctx->d_xred);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);

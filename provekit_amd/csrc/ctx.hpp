@@ -49,7 +49,15 @@ struct pk_ctx {
     size_t mail_bytes = 0, mail_off = 0;
     bool pow_armed = false;  // pow.hip: device-side best/ticket words initialised
     bool red_armed = false;  // reduce.hpp: ticket word zeroed
+    // One proof sharded over a device set (prover.hip): while `red_across` is set, the operands of the reduction kernels
+    // (sumcheck rounds, dot products, Horner) are this rank's shard, their results partial sums -- the finishing workgroup
+    // writes them to the device block d_xred instead of the pinned page, and collect_reduction all-gathers the K x 32 bytes,
+    // adds the ranks' partials mod p (each optionally multiplied by red_scales[rank] first) and only then hands them to the host.
+    bool red_across = false;
+    void* d_xred = nullptr;             // [own results, 2 KiB | gathered blocks of the ranks]
+    const void* red_scales = nullptr;   // host, comm_world(ctx) field elements (Montgomery), or null
 };
+#define PK_XRED_OWN_BYTES 2048
 
 // fixed slots in the 4 KiB h_pinned page: [0,1024) reduction results, word 256 completion flag (reduce.hpp)
 #define PK_PIN_ROOT 2048 /* 32 B: the root of the last Merkle tree built on this context (hash.hip) */
@@ -157,8 +165,13 @@ int comm_rank(const pk_ctx* ctx);
 int comm_world(const pk_ctx* ctx);
 int comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_rank);
 int comm_all_reduce_sum_u64(pk_ctx* ctx, uint64_t* d_buf, size_t count);
+int comm_collect_fe(pk_ctx* ctx, int K, uint64_t* host_out);  // comm.hip: the cross-rank half of collect_reduction
+int red_across_begin(pk_ctx* ctx);                             // allocate d_xred if needed and set red_across
+void comm_turn_begin(pk_ctx* ctx);  // measurement aid of the in-process transport (comm.hip LocalGroup::turnstile)
+void comm_turn_end(pk_ctx* ctx);
 void comm_abort(pk_ctx* ctx);  // wake the ranks waiting in a collective this rank will never reach (in-process transport)
 void comm_release(pk_ctx* ctx);
+int pow_solve_x(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t* nonce, bool striped);  // pow.hip
 void ntt_release_ctx(pk_ctx* ctx);  // ntt.hip: frees the per-context twiddle tables
 
 }  // namespace pk

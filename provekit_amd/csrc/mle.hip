@@ -704,6 +704,7 @@ namespace pk {
 int lincomb2(pk_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* beta, const uint64_t* d_b, size_t n) {
     PK_REQUIRE(ctx, beta && (n == 0 || (d_out && d_a && d_b)), "null pointer");
     if (!n) return PK_OK;
+    ProfScope prof(ctx, "lincomb");
     lincomb_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_out, (const fe*)d_a, (const fe*)d_b, n, to_arg(beta));
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
@@ -712,6 +713,7 @@ int lincomb2(pk_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* 
 int fold_pairs2(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint64_t* d_v1, uint64_t* d_out1, size_t len, const uint64_t* r) {
     PK_REQUIRE(ctx, d_v0 && d_out0 && d_v1 && d_out1 && r, "null pointer");
     PK_REQUIRE(ctx, is_pow2(len) && len >= 2, "size must be a power of two >= 2");
+    ProfScope prof(ctx, "fold_pairs");
     fold_pairs_kernel<<<dim3(grid_for(ctx, len / 2, 256), 2), 256, 0, ctx->stream>>>((const fe*)d_v0, (fe*)d_out0, (const fe*)d_v1, (fe*)d_out1,
                                                                                      len / 2, to_arg(r));
     PK_LAUNCH_CHECK(ctx);
@@ -723,6 +725,10 @@ extern "C" {
 int pk_dot(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, size_t n, uint64_t out[4]) {
     PK_ENTER(ctx);
     PK_REQUIRE(ctx, out && (n == 0 || (d_w && d_f)), "null pointer");
+    if (n == 0 && ctx->red_across) {  // an empty share still takes part in the exchange of the ranks' partial sums
+        PK_HIP(ctx, hipMemsetAsync(ctx->d_xred, 0, 32, ctx->stream));
+        return collect_reduction<1>(ctx, out);
+    }
     if (n == 0) {
         memset(out, 0, 32);
         return PK_OK;
@@ -742,6 +748,10 @@ int pk_dot(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, size_t n, uint
 int pk_dot2(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, const uint64_t* d_g, size_t n, uint64_t out[8]) {
     PK_ENTER(ctx);
     PK_REQUIRE(ctx, out && (n == 0 || (d_w && d_f && d_g)), "null pointer");
+    if (n == 0 && ctx->red_across) {
+        PK_HIP(ctx, hipMemsetAsync(ctx->d_xred, 0, 64, ctx->stream));
+        return collect_reduction<2>(ctx, out);
+    }
     if (n == 0) {
         memset(out, 0, 64);
         return PK_OK;
@@ -831,6 +841,7 @@ int pk_fe_axpy(pk_ctx* ctx, uint64_t* d_y, const uint64_t* beta, const uint64_t*
     PK_ENTER(ctx);
     PK_REQUIRE(ctx, beta && (n == 0 || (d_y && d_x)), "null pointer");
     if (!n) return PK_OK;
+    ProfScope prof(ctx, "lincomb");
     axpy_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_y, (const fe*)d_x, n, to_arg(beta));
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;

@@ -34,9 +34,11 @@ __device__ __forceinline__ fe from_arg(const fe_arg& a) {
 // square is computed once per lane, 13 squarings per hash instead of 14.  The workgroup that draws the last ticket
 // publishes the result (or ~0) to pinned host memory and re-arms both words: a window costs one launch and one stream
 // synchronisation -- no copy operations.
+// (world, rank): nonce ranges striped over the ranks of a device set: this launch tries base + t for t = rank (mod
+// world) only; (1, 0) is the whole window.
 __global__ __launch_bounds__(256) void pow_search_kernel(fe_arg challenge_arg, fe_arg threshold_arg, unsigned long long base,
                                                          unsigned long long count, unsigned long long* best, unsigned* ticket,
-                                                         unsigned long long* host_best) {
+                                                         unsigned long long* host_best, unsigned world, unsigned rank) {
     PK_LATENCY_PRIO();
     const fe29 challenge = to_scaled29(from_arg(challenge_arg));  // generic.rs:81 reduce_partial on arbitrary input
     fe29 s0 = challenge, zero;
@@ -44,8 +46,8 @@ __global__ __launch_bounds__(256) void pow_search_kernel(fe_arg challenge_arg, f
     for (int k = 0; k < 9; k++) zero.v[k] = 0;
     sky_sq_round_s<0>(s0, zero);  // round 0 for r = 0, once per lane: s0 = 32 sq(challenge)
     const fe threshold = from_arg(threshold_arg);
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += stride) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x * world;
+    for (unsigned long long t = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * world + rank; t < count; t += stride) {
         const unsigned long long nonce = base + t;
         if (nonce > __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
         fe r = fe_zero();
@@ -125,6 +127,14 @@ int pk_pow_threshold(double difficulty, uint64_t out[4]) {
 // PowStrategy::solve (provekit/common/src/skyscraper/pow.rs:27-29) -> pow::solve (pow.rs:33-41)
 int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t* nonce) {
     PK_ENTER(ctx);
+    return pk::pow_solve_x(ctx, challenge, bits, nonce, false);
+}
+}  // extern "C"
+namespace pk {
+// striped = every rank of the context's device set is inside this call with the same challenge: the nonce space of each window
+// is striped over the ranks (rank g tries base + t, t = g mod G), then ONE all-gather of the ranks' 8-byte minima; the result is
+// the same smallest valid nonce the lone search returns, on every rank.
+int pow_solve_x(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t* nonce, bool striped) {
     PK_REQUIRE(ctx, challenge && nonce, "null pointer");
     PK_REQUIRE(ctx, bits >= 0.0 && bits < 60.0, "bits must be smaller than 60");  // skyscraper/pow.rs:16
     if (bits == 0.0) {  // pow.rs:34-36
@@ -136,11 +146,13 @@ int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
     if (rc) return set_err(ctx, rc, "threshold");
     unsigned long long *d_best, *h_best;
     unsigned* d_ticket;
-    rc = pow_words(ctx, &d_best, &d_ticket, &h_best);
+    rc = ensure_scratch(ctx, ((size_t)1 << 19) + 8 * (size_t)(PK_MAX_RANKS + 1));  // before pow_words: a re-allocation moves them
+    if (!rc) rc = pow_words(ctx, &d_best, &d_ticket, &h_best);
     if (rc) return rc;
     fe_arg ch, th;
     memcpy(ch.v, challenge, 32);
     memcpy(th.v, thr, 32);
+    const unsigned world = striped ? (unsigned)comm_world(ctx) : 1u, rank = striped ? (unsigned)comm_rank(ctx) : 0u;
     unsigned long long best = ~0ull, base = 0;
     // One launch almost always: the window is 2^(bits+5) nonces (miss probability e^-32) but lanes stop once a smaller valid
     // nonce is known, so the hashes actually computed are ~2^bits plus one stride.  The stride (lanes in flight) is a quarter
@@ -148,6 +160,9 @@ int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
     unsigned wbits = (unsigned)bits + 5;
     if (wbits < 12) wbits = 12;
     if (wbits > 62) wbits = 62;  // bits in [58, 60) would shift by >= 63; the loop below moves the window on a miss
+    // striped: ranks cannot see each other's hits while they search, so the window is what bounds a rank's work: 2^(bits+1)
+    // nonces (miss probability e^-2) = 2^(bits+1) / G hashes per rank at most, then the exchange; a miss moves the window on
+    if (world > 1 && wbits > (unsigned)bits + 1) wbits = (unsigned)bits + 1 < 12 ? 12 : (unsigned)bits + 1;
     unsigned long long window = 1ull << wbits;
     unsigned lbits = (unsigned)bits > 2 ? (unsigned)bits - 2 : 0;
     if (lbits < 12) lbits = 12;
@@ -155,13 +170,25 @@ int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
     unsigned grid = 1u << (lbits - 8);
     const unsigned grid_cap = (unsigned)ctx->num_cus * 4;
     if (grid > grid_cap) grid = grid_cap;
-    ProfScope prof(ctx, "pow_search");
     for (;;) {
-        pow_search_kernel<<<grid, 256, 0, ctx->stream>>>(ch, th, base, window, d_best, d_ticket, h_best);
+        {
+            ProfScope prof(ctx, "pow_search");  // the kernel only: the exchange below waits for the other ranks
+            pow_search_kernel<<<grid, 256, 0, ctx->stream>>>(ch, th, base, window, d_best, d_ticket, h_best, world, rank);
+        }
         PK_LAUNCH_CHECK(ctx);
         rc = sync_stream(ctx);
         if (rc) return rc;
         best = *(volatile unsigned long long*)h_best;
+        if (world > 1) {  // the smallest over the ranks' stripes: 8 bytes per rank
+            unsigned long long* d_x = (unsigned long long*)((char*)ctx->d_scratch + ((size_t)1 << 19));
+            unsigned long long all[PK_MAX_RANKS];
+            PK_HIP(ctx, hipMemcpyAsync(d_x, &best, 8, hipMemcpyHostToDevice, ctx->stream));
+            rc = comm_all_gather(ctx, d_x, d_x + 1, 8);
+            if (rc) return rc;
+            PK_HIP(ctx, hipMemcpyAsync(all, d_x + 1, 8 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
+            PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            for (unsigned r = 0; r < world; r++) best = all[r] < best ? all[r] : best;
+        }
         if (best != ~0ull) break;
         base += window;
         if (base > (1ull << 62)) return set_err(ctx, PK_ERR_BAD_ARG, "proof of work search exhausted");
@@ -169,6 +196,8 @@ int pk_pow_solve(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
     *nonce = best;
     return PK_OK;
 }
+}  // namespace pk
+extern "C" {
 
 // PowStrategy::check (skyscraper/pow.rs:23-25) -> pow::verify (pow.rs:24-26): NO prover bias
 int pk_pow_check(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t nonce, int* ok) {
@@ -189,7 +218,7 @@ int pk_pow_check(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t
     fe_arg ch, th;
     memcpy(ch.v, challenge, 32);
     memcpy(th.v, thr, 32);
-    pow_search_kernel<<<1, 64, 0, ctx->stream>>>(ch, th, nonce, 1, d_best, d_ticket, h_best);
+    pow_search_kernel<<<1, 64, 0, ctx->stream>>>(ch, th, nonce, 1, d_best, d_ticket, h_best, 1, 0);
     PK_LAUNCH_CHECK(ctx);
     rc = sync_stream(ctx);
     if (rc) return rc;

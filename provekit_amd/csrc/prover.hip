@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "ctx.hpp"
+#include "shard_map.hpp"
 #include "transcript.hpp"
 
 using namespace pk;
@@ -34,6 +35,9 @@ unsigned shard_factor(const pk_ctx* ctx, size_t rows);
 size_t commit_scratch_fes(const pk_ctx* ctx, size_t rows, size_t width);
 int lincomb2(pk_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* beta, const uint64_t* d_b, size_t n);
 int fold_pairs2(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint64_t* d_v1, uint64_t* d_out1, size_t len, const uint64_t* r);
+int witness_bounds_strided(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, unsigned m0, unsigned stride, unsigned offset, uint64_t* d_a,
+                           uint64_t* d_b, uint64_t* d_c);
+int external_row_range(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_eq_alpha, size_t first, size_t last, uint64_t* d_out);
 }
 
 struct pk_scheme {
@@ -151,6 +155,79 @@ void expand_from_univariate(const fe& z, unsigned n, fe* out) {
     }
 }
 
+// ------------------------------------------------------------------ one proof over a device set
+// Besides the commits (tree.hip), the linear-size arrays of a sharded proof are split over the G ranks:
+//   * the Spartan sumcheck's a, b, c, eq by the LOW index bits (rank g holds i = g mod G at local index i / G): the leading
+//     variable is folded first and pairs i with i + len/2 (sumcheck.rs:28-33), both on one rank, so the existing kernels run
+//     unchanged on the local arrays;
+//   * the WHIR sumcheck's polynomial and weight tables, the equality weights, the statement weights (external rows) and the
+//     OOD evaluations by contiguous BLOCKS (the high index bits): WHIR folds the lowest variable first (pairs 2i, 2i+1).
+// Per round every rank reduces its share and the 96 bytes are summed over the ranks (ctx->red_across: reduce.hpp,
+// comm_collect_fe); once the local length falls to SHARD_MIN_LOCAL the arrays are all-gathered and the tail of the sumcheck
+// runs replicated.  Every sum is an exact field sum, so the transcript is byte-identical to the lone prover's.
+constexpr size_t SHARD_MIN_LOCAL = (size_t)1 << 12;
+
+struct Across {  // scope in which this context's reductions are partial sums to be added over the ranks
+    pk_ctx* c;
+    bool on;
+    int rc = PK_OK;
+    Across(pk_ctx* ctx, bool enable, const fe* scales = nullptr) : c(ctx), on(enable) {
+        if (on) {
+            rc = red_across_begin(c);
+            c->red_scales = scales;
+        }
+    }
+    ~Across() {
+        if (on) {
+            c->red_across = false;
+            c->red_scales = nullptr;
+        }
+    }
+};
+// eq((x_0 .. x_{lg-1}), bits of g), x_0 <-> the most significant of the lg bits (eval_eq's order, sumcheck.rs:146-171)
+fe eq_bits(const fe* x, unsigned lg, unsigned g) {
+    fe acc = fe_one();
+    for (unsigned t = 0; t < lg; t++) acc = h_mul(acc, ((g >> (lg - 1 - t)) & 1u) ? x[t] : h_sub(fe_one(), x[t]));
+    return acc;
+}
+// all-gather of the ranks' local arrays: gathered[r * len + j]; STRIDED additionally re-interleaves to full[j * G + r]
+__global__ __launch_bounds__(256) void interleave_fe_kernel(const fe* __restrict__ gathered, fe* __restrict__ full, size_t total, unsigned G) {
+    PK_LATENCY_PRIO();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) fe_store(full + i, fe_load(gathered + shard_gathered_slot(i, total, G)));
+}
+int gather_blocks(pk_ctx* ctx, const fe* local, size_t len, fe* full) { return comm_all_gather(ctx, local, full, 32 * len); }
+int gather_strided(pk_ctx* ctx, const fe* local, size_t len, fe* tmp, fe* full) {
+    const unsigned G = (unsigned)comm_world(ctx);
+    int rc = comm_all_gather(ctx, local, tmp, 32 * len);
+    if (rc) return rc;
+    const size_t total = len * G;
+    interleave_fe_kernel<<<(unsigned)((total + 255) / 256), 256, 0, ctx->stream>>>(tmp, full, total, G);
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+// sum_i c[i] z^i, split into the ranks' blocks when the polynomial is long: rank r evaluates its block in z and the ranks'
+// values are combined as sum_r z^(r*B) * partial_r
+int eval_univariate_x(pk_ctx* ctx, const fe* d_poly, size_t n, const fe& z, fe& out) {
+    const unsigned G = (unsigned)comm_world(ctx);
+    uint64_t zz[4], o[4];
+    h_store(zz, z);
+    if (G > 1 && n / G >= 4 * SHARD_MIN_LOCAL) {
+        const size_t B = n / G;
+        fe scales[PK_MAX_RANKS];
+        const fe zB = h_pow(z, B);
+        scales[0] = fe_one();
+        for (unsigned r = 1; r < G; r++) scales[r] = h_mul(scales[r - 1], zB);
+        Across ac(ctx, true, scales);
+        CK(ac.rc);
+        CK(pk_eval_univariate(ctx, U(d_poly + (size_t)comm_rank(ctx) * B), B, zz, o));
+    } else {
+        CK(pk_eval_univariate(ctx, U(d_poly), n, zz, o));
+    }
+    out = h_load(o);
+    return PK_OK;
+}
+
 // ------------------------------------------------------------------ S6: blinding algebra (host, O(m_0^2))
 fe eval_cubic(const fe c[4], const fe& x) {  // provekit/common/src/utils/sumcheck.rs:174-176
     return h_add(c[0], h_mul(x, h_add(c[1], h_mul(x, h_add(c[2], h_mul(x, c[3]))))));
@@ -209,7 +286,7 @@ void pow_round(pk_ctx* ctx, Transcript& T, double bits, int* rc) {
     uint8_t challenge[32];
     T.challenge_bytes(challenge, 32);
     uint64_t nonce = 0;
-    *rc = pk_pow_solve(ctx, challenge, bits, &nonce);
+    *rc = pow_solve_x(ctx, challenge, bits, &nonce, comm_world(ctx) > 1);  // nonce ranges striped over the ranks of a device set
     uint8_t be[8];
     for (int i = 0; i < 8; i++) be[i] = (uint8_t)(nonce >> (56 - 8 * i));  // utilities.go:89-95
     T.add_bytes(be, 8);
@@ -279,12 +356,8 @@ int whir_commit(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, fe* const* pol
     T.challenge_scalars(C.ood_points.data(), C.ood_points.size());
     C.ood_answers.resize((size_t)batch * C.ood_points.size());
     for (unsigned b = 0; b < batch; b++)
-        for (size_t j = 0; j < C.ood_points.size(); j++) {
-            uint64_t z[4], out[4];
-            h_store(z, C.ood_points[j]);
-            CK(pk_eval_univariate(ctx, U(polys[b]), (size_t)1 << cfg.n_vars, z, out));
-            C.ood_answers[b * C.ood_points.size() + j] = h_load(out);
-        }
+        for (size_t j = 0; j < C.ood_points.size(); j++)
+            CK(eval_univariate_x(ctx, polys[b], (size_t)1 << cfg.n_vars, C.ood_points[j], C.ood_answers[b * C.ood_points.size() + j]));
     for (unsigned b = 0; b < batch; b++) T.add_scalars(&C.ood_answers[b * C.ood_points.size()], C.ood_points.size());
     C.beta = T.challenge_scalar();
     return PK_OK;
@@ -292,42 +365,69 @@ int whir_commit(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, fe* const* pol
 
 // whir::Prover::prove with `n_weights` linear statement weights: evaluation tables over the 2^n hypercube of which only the
 // first weight_len[i] entries are stored -- the rest is zero by construction (create_combined_statement_over_two_polynomials
-// zero-extends each row, whir_r1cs.rs:382-412), so nothing is spent on the zero half
+// zero-extends each row, whir_r1cs.rs:382-412), so nothing is spent on the zero half.
+// On a device set (and a polynomial long enough) the sumcheck tables, the weights and the OOD evaluations are split into the
+// ranks' blocks; of a sharded weight only the entries inside this rank's block need to be present in d_weights[i].
+bool whir_sharded(const pk_ctx* ctx, unsigned n_vars) {
+    const size_t G = (size_t)comm_world(ctx);
+    return G > 1 && (((size_t)1 << n_vars) / G) >= 2 * SHARD_MIN_LOCAL;
+}
 int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitment& C, fe* const* d_weights, const size_t* weight_len,
                unsigned n_weights, Transcript& T) {
     const unsigned n = cfg.n_vars, k = cfg.folding_factor;
     const size_t N = (size_t)1 << n;
-    // working polynomial c = sum_b beta^b poly_b (mtUtilities.go:98-114)
+    const unsigned G = (unsigned)comm_world(ctx), lgG = ilog2(G), rank = (unsigned)comm_rank(ctx);
+    bool sharded = whir_sharded(ctx, n);              // the sumcheck tables are this rank's block [off, off + len)
+    const size_t B0 = sharded ? N / G : N, off0 = sharded ? (size_t)rank * B0 : 0;
+    // working polynomial c = sum_b beta^b poly_b (mtUtilities.go:98-114), whole on every rank: it is folded and re-committed
     ALLOC(d_c, N);
-    // sum_b beta^b x_b over coefficient tables or evaluation tables: the first two in one pass, the rest by axpy
-    auto batch_combine = [&](fe* dst, fe* const* x) -> int {
-        if (C.batch == 1) return pk_memcpy_d2d(ctx, dst, x[0], 32 * N);
+    // sum_b beta^b x_b over `cnt` entries from `from` of coefficient tables or evaluation tables: the first two in one pass
+    auto batch_combine = [&](fe* dst, fe* const* x, size_t from, size_t cnt) -> int {
+        if (C.batch == 1) return pk_memcpy_d2d(ctx, dst, x[0] + from, 32 * cnt);
         uint64_t s[4];
         h_store(s, C.beta);
-        int rc = lincomb2(ctx, U(dst), U(x[0]), s, U(x[1]), N);
+        int rc = lincomb2(ctx, U(dst), U(x[0] + from), s, U(x[1] + from), cnt);
         fe bp = h_mul(C.beta, C.beta);
         for (unsigned b = 2; b < C.batch && !rc; b++) {
             h_store(s, bp);
-            rc = pk_fe_axpy(ctx, U(dst), s, U(x[b]), N);
+            rc = pk_fe_axpy(ctx, U(dst), s, U(x[b] + from), cnt);
             bp = h_mul(bp, C.beta);
         }
         return rc;
     };
-    CK(batch_combine(d_c, C.polys));
+    CK(batch_combine(d_c, C.polys, 0, N));
     // sumcheck operands: p = evaluations of c over the hypercube, w = combined weights; ping-pong halves
     fe* bp_[2];
     fe* bw_[2];
-    ALLOC(p0, N);
-    ALLOC(p1, N / 2 ? N / 2 : 1);
-    ALLOC(w0, N);
-    ALLOC(w1, N / 2 ? N / 2 : 1);
+    ALLOC(p0, B0);
+    ALLOC(p1, B0 / 2 ? B0 / 2 : 1);
+    ALLOC(w0, B0);
+    ALLOC(w1, B0 / 2 ? B0 / 2 : 1);
     bp_[0] = p0; bp_[1] = p1; bw_[0] = w0; bw_[1] = w1;
     bool have_evals = true;
     for (unsigned b = 0; b < C.batch; b++) have_evals = have_evals && C.evals[b] != nullptr;
-    if (have_evals)
-        CK(batch_combine(p0, C.evals));  // to_evals is linear: combine the tables the committer kept instead of transforming d_c
-    else
+    if (have_evals) {
+        CK(batch_combine(p0, C.evals, off0, B0));  // to_evals is linear: combine the tables the committer kept instead of transforming d_c
+    } else if (!sharded) {
         CK(pk_to_evals_into(ctx, U(d_c), U(p0), n));
+    } else {
+        ALLOC(d_ev, N);
+        CK(pk_to_evals_into(ctx, U(d_c), U(d_ev), n));
+        CK(pk_memcpy_d2d(ctx, p0, d_ev + off0, 32 * B0));
+    }
+    // equality weights of `q` points (each nv coordinates, variable 0 <-> the top index bit) scaled by scales[j], accumulated
+    // into a weight table: the whole table, or -- sharded -- this rank's block, whose top lgG index bits are the rank: that
+    // factor of eq goes into the scale and the table is built over the remaining variables
+    auto eq_weights = [&](fe* dst, unsigned nv, std::vector<fe>& pts, std::vector<fe>& scales, size_t q, int overwrite) -> int {
+        if (!sharded) return pk_eq_accumulate(ctx, U(dst), nv, (const uint64_t*)pts.data(), (const uint64_t*)scales.data(), (unsigned)q, overwrite);
+        const unsigned nl = nv - lgG;
+        std::vector<fe> lp(q * (nl ? nl : 1)), ls(q ? q : 1);
+        for (size_t j = 0; j < q; j++) {
+            ls[j] = h_mul(scales[j], eq_bits(&pts[j * nv], lgG, rank));
+            for (unsigned t = 0; t < nl; t++) lp[j * nl + t] = pts[j * nv + lgG + t];
+        }
+        return pk_eq_accumulate(ctx, U(dst), nl, (const uint64_t*)lp.data(), (const uint64_t*)ls.data(), (unsigned)q, overwrite);
+    };
     // initial combination randomness; weights = sum gamma^i w_i over [OOD constraints..., statement weights...]
     fe gamma = T.challenge_scalar();
     fe g = fe_one();
@@ -339,21 +439,24 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
             scales[j] = g;
             g = h_mul(g, gamma);
         }
-        CK(pk_eq_accumulate(ctx, U(w0), n, (const uint64_t*)pts.data(), (const uint64_t*)scales.data(), (unsigned)q, /*overwrite=*/1));
+        CK(eq_weights(w0, n, pts, scales, q, /*overwrite=*/1));
         for (unsigned i = 0; i < n_weights; i++) {
             uint64_t s[4];
             h_store(s, g);
-            if (weight_len[i]) CK(pk_fe_axpy(ctx, U(w0), s, U(d_weights[i]), weight_len[i]));
+            const size_t hi = weight_len[i] < off0 + B0 ? weight_len[i] : off0 + B0;  // the part of the weight inside this block
+            if (hi > off0) CK(pk_fe_axpy(ctx, U(w0), s, U(d_weights[i] + off0), hi - off0));
             g = h_mul(g, gamma);
         }
     }
     int cur = 0;
-    size_t len = N;
+    size_t len = B0;         // local length of p and w
     std::vector<fe> all_r;  // every folding challenge, in squeeze order
     auto sumcheck_rounds = [&](unsigned rounds, std::vector<fe>& rs) -> int {
         rs.clear();
         bool have_fold = false;
         fe fold = fe_zero();
+        Across ac(ctx, sharded);  // sharded: h(0), h(1), h(2) are sums over the ranks' blocks
+        CK(ac.rc);
         for (unsigned t = 0; t < rounds; t++) {
             uint64_t out[12], f[4];
             if (!have_fold) {
@@ -380,8 +483,30 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
         }
         return PK_OK;
     };
+    // once a rank's block is short the blocks are all-gathered (block r of the gather IS index range r) and the rest of the
+    // sumcheck runs replicated; a sumcheck_rounds call shrinks the block 2^k-fold, so blocks never run out inside one
+    fe *gp[2] = {nullptr, nullptr}, *gw[2] = {nullptr, nullptr};
+    if (sharded) {
+        const size_t cap = G * SHARD_MIN_LOCAL;
+        ALLOC(gp0, cap);
+        ALLOC(gp1, cap / 2);
+        ALLOC(gw0, cap);
+        ALLOC(gw1, cap / 2);
+        gp[0] = gp0; gp[1] = gp1; gw[0] = gw0; gw[1] = gw1;
+    }
+    auto maybe_gather = [&]() -> int {
+        if (!sharded || len > SHARD_MIN_LOCAL) return PK_OK;
+        CK(gather_blocks(ctx, bp_[cur], len, gp[0]));
+        CK(gather_blocks(ctx, bw_[cur], len, gw[0]));
+        bp_[0] = gp[0]; bp_[1] = gp[1]; bw_[0] = gw[0]; bw_[1] = gw[1];
+        cur = 0;
+        len *= G;
+        sharded = false;
+        return PK_OK;
+    };
     std::vector<fe> rs;
     CK(sumcheck_rounds(k, rs));
+    CK(maybe_gather());
 
     const fe* prev_leaves = C.leaves;
     const fe* prev_nodes = C.nodes;
@@ -423,12 +548,7 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
         std::vector<fe> ood(cfg.ood_samples[r]);
         T.challenge_scalars(ood.data(), ood.size());
         std::vector<fe> ood_ans(ood.size());
-        for (size_t j = 0; j < ood.size(); j++) {
-            uint64_t z[4], out[4];
-            h_store(z, ood[j]);
-            CK(pk_eval_univariate(ctx, U(d_c), (size_t)1 << nv, z, out));
-            ood_ans[j] = h_load(out);
-        }
+        for (size_t j = 0; j < ood.size(); j++) CK(eval_univariate_x(ctx, d_c, (size_t)1 << nv, ood[j], ood_ans[j]));
         T.add_scalars(ood_ans.data(), ood_ans.size());
         // P1
         int prc = PK_OK;
@@ -453,9 +573,10 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
             scales[j] = g;
             g = h_mul(g, gamma);
         }
-        CK(pk_eq_accumulate(ctx, U(bw_[cur]), nv, (const uint64_t*)pts.data(), (const uint64_t*)scales.data(), (unsigned)q, 0));
+        CK(eq_weights(bw_[cur], nv, pts, scales, q, 0));
         // W3
         CK(sumcheck_rounds(k, rs));
+        CK(maybe_gather());
         prev_leaves = leaves;
         prev_nodes = nodes;
         prev_rows = rows;
@@ -466,6 +587,19 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
     }
     // final round: the folded polynomial in the clear, PoW, final STIR openings, final sumcheck
     {
+        if (sharded) {  // a schedule that ends before the blocks got short: finish replicated
+            const size_t cap = len * G;
+            ALLOC(fp0, cap);
+            ALLOC(fp1, cap / 2 ? cap / 2 : 1);
+            ALLOC(fw0, cap);
+            ALLOC(fw1, cap / 2 ? cap / 2 : 1);
+            CK(gather_blocks(ctx, bp_[cur], len, fp0));
+            CK(gather_blocks(ctx, bw_[cur], len, fw0));
+            bp_[0] = fp0; bp_[1] = fp1; bw_[0] = fw0; bw_[1] = fw1;
+            cur = 0;
+            len = cap;
+            sharded = false;
+        }
         const unsigned nv2 = nv - k;
         ALLOC(d_final, (size_t)1 << nv2);
         CK(pk_fold_coeffs(ctx, U(d_c), nv, (const uint64_t*)rs.data(), k, U(d_final)));
@@ -487,14 +621,23 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
     // Round t folds index bit t (LSB first), so the point in eval_eq's MSB-first order is reverse(all_r).
     if (n_weights) {
         std::vector<fe> point(all_r.rbegin(), all_r.rend());
-        ALLOC(d_eq, N);
-        CK(pk_eq_table(ctx, (const uint64_t*)point.data(), n, U(d_eq)));
+        const bool sh = whir_sharded(ctx, n);  // the eq table and the dot products by blocks, like the weights themselves
+        ALLOC(d_eq, B0);
+        if (sh) {
+            const fe sc = eq_bits(point.data(), lgG, rank);
+            CK(pk_eq_accumulate(ctx, U(d_eq), n - lgG, (const uint64_t*)(point.data() + lgG), (const uint64_t*)&sc, 1, 1));
+        } else {
+            CK(pk_eq_table(ctx, (const uint64_t*)point.data(), n, U(d_eq)));
+        }
         std::vector<uint8_t> buf;
         uint64_t cnt = n_weights;
         for (int i = 0; i < 8; i++) buf.push_back((uint8_t)(cnt >> (8 * i)));
+        Across ac(ctx, sh);
+        CK(ac.rc);
         for (unsigned i = 0; i < n_weights; i++) {
             uint64_t out[4];
-            if (weight_len[i]) CK(pk_dot(ctx, U(d_weights[i]), U(d_eq), weight_len[i], out));
+            const size_t hi = weight_len[i] < off0 + B0 ? weight_len[i] : off0 + B0;
+            if (sh || weight_len[i]) CK(pk_dot(ctx, U(d_weights[i] + off0), U(d_eq), hi > off0 ? hi - off0 : 0, out));
             else memset(out, 0, sizeof out);
             fe c = h_to_canon(h_load(out));
             const uint8_t* b = (const uint8_t*)c.v;
@@ -521,8 +664,11 @@ int batch_commit(pk_ctx* ctx, Arena& A, unsigned m, const pk_whir_config& cfg, c
     // f = [witness (zero padded) || mask]   (zk_utils.rs:3-22)
     CK(pk_memset_zero(ctx, f, 32 * half));
     CK(pk_memcpy_d2d(ctx, f, d_evals, 32 * n_evals));
-    random_fe_kernel<<<grid_for(ctx, half, 256), 256, 0, ctx->stream>>>(f + half, half, key, stream_mask);
-    random_fe_kernel<<<grid_for(ctx, N, 256), 256, 0, ctx->stream>>>(g, N, key, stream_g);
+    {
+        ProfScope prof(ctx, "random_fe");
+        random_fe_kernel<<<grid_for(ctx, half, 256), 256, 0, ctx->stream>>>(f + half, half, key, stream_mask);
+        random_fe_kernel<<<grid_for(ctx, N, 256), 256, 0, ctx->stream>>>(g, N, key, stream_g);
+    }
     PK_LAUNCH_CHECK(ctx);
     // f, g hold the evaluation forms (kept for the weighted sums); the coefficient forms go to fc, gc
     CK(pk_to_coeffs_into(ctx, U(f), U(fe_), m));
@@ -653,6 +799,11 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
             PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         }
     }
+    struct Turn {  // see comm.hip: a no-op outside the test-suite's one-GPU timing mode
+        pk_ctx* c;
+        explicit Turn(pk_ctx* ctx) : c(ctx) { comm_turn_begin(c); }
+        ~Turn() { comm_turn_end(c); }
+    } turn(ctx);
     Arena A{s->arena, s->arena_bytes};
     Transcript T(s->domain_separator);
     const bool timing = getenv("PK_PROVE_TIMING") != nullptr;
@@ -677,12 +828,24 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     std::vector<fe> r(m_0);
     T.challenge_scalars(r.data(), m_0);
     const size_t M0 = (size_t)1 << m_0;
-    ALLOC(d_a, M0);
-    ALLOC(d_b, M0);
-    ALLOC(d_cc, M0);
-    ALLOC(d_eq, M0);
-    CK(pk_r1cs_witness_bounds(ctx, s->r1cs, d_witness, m_0, U(d_a), U(d_b), U(d_cc)));  // S1
-    CK(pk_eq_table(ctx, (const uint64_t*)r.data(), m_0, U(d_eq)));                       // S2
+    // On a device set the four sumcheck arrays are split by the LOW index bits: rank g holds the entries i = g (mod G) at local
+    // index i / G (see "one proof over a device set" above).  eq(r, i) factors into eq over the high variables (the local
+    // table) times eq(last lgG variables, bits of g), a scalar that goes in as the table's scale.
+    const unsigned G = (unsigned)comm_world(ctx), lgG = ilog2(G), rank = (unsigned)comm_rank(ctx);
+    bool zk_sharded = G > 1 && M0 / G >= 2 * SHARD_MIN_LOCAL;
+    const size_t Lz = zk_sharded ? M0 / G : M0;
+    ALLOC(d_a, Lz);
+    ALLOC(d_b, Lz);
+    ALLOC(d_cc, Lz);
+    ALLOC(d_eq, Lz);
+    if (zk_sharded) {
+        CK(witness_bounds_strided(ctx, s->r1cs, d_witness, m_0, G, rank, U(d_a), U(d_b), U(d_cc)));  // S1, this rank's rows
+        const fe sc = eq_bits(&r[m_0 - lgG], lgG, rank);
+        CK(pk_eq_accumulate(ctx, U(d_eq), m_0 - lgG, (const uint64_t*)r.data(), (const uint64_t*)&sc, 1, 1));  // S2
+    } else {
+        CK(pk_r1cs_witness_bounds(ctx, s->r1cs, d_witness, m_0, U(d_a), U(d_b), U(d_cc)));  // S1
+        CK(pk_eq_table(ctx, (const uint64_t*)r.data(), m_0, U(d_eq)));                       // S2
+    }
     // blinding univariates: 4 random coefficients per variable [RNG], committed with the small WHIR
     unsigned nb = 0;
     while (((size_t)1 << nb) < 4 * (size_t)m_0) nb++;
@@ -709,15 +872,36 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     std::vector<fe> alpha;
     alpha.reserve(m_0);
     {
-        size_t length = M0;
+        size_t length = Lz;  // local length while sharded
         const fe half = h_half();
+        fe *za = d_a, *zb = d_b, *zc = d_cc, *ze = d_eq;
+        fe* zfull[4] = {nullptr, nullptr, nullptr, nullptr};
+        fe* ztmp = nullptr;
+        if (zk_sharded) {
+            const size_t cap = G * SHARD_MIN_LOCAL;
+            for (int q = 0; q < 4; q++) {
+                ALLOC(zf, cap);
+                zfull[q] = zf;
+            }
+            ALLOC(zt, cap);
+            ztmp = zt;
+        }
         for (unsigned idx = 0; idx < m_0; idx++) {  // the hot loop, whir_r1cs.rs:280-345
             uint64_t out[12], f[4];
+            if (zk_sharded && length <= SHARD_MIN_LOCAL) {  // short shares: gather, re-interleave, finish replicated
+                fe* loc[4] = {za, zb, zc, ze};
+                for (int q = 0; q < 4; q++) CK(gather_strided(ctx, loc[q], length, ztmp, zfull[q]));
+                za = zfull[0]; zb = zfull[1]; zc = zfull[2]; ze = zfull[3];
+                length *= G;
+                zk_sharded = false;
+            }
+            Across ac(ctx, zk_sharded);  // sharded: the three evaluations are sums over the ranks' shares
+            CK(ac.rc);
             if (idx == 0) {
-                CK(pk_sumcheck_cubic_round(ctx, U(d_a), U(d_b), U(d_cc), U(d_eq), length, nullptr, out));
+                CK(pk_sumcheck_cubic_round(ctx, U(za), U(zb), U(zc), U(ze), length, nullptr, out));
             } else {
                 h_store(f, alpha.back());
-                CK(pk_sumcheck_cubic_round(ctx, U(d_a), U(d_b), U(d_cc), U(d_eq), length, f, out));
+                CK(pk_sumcheck_cubic_round(ctx, U(za), U(zb), U(zc), U(ze), length, f, out));
                 length /= 2;
             }
             const fe h0 = h_load(out), hm1 = h_load(out + 4), hinf = h_load(out + 8);
@@ -762,17 +946,24 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     ALLOC(d_eq_alpha, M0);
     CK(pk_eq_table(ctx, (const uint64_t*)alpha.data(), m_0, U(d_eq_alpha)));
     ALLOC(d_rows, 3 * (n_witness ? n_witness : 1));
-    CK(pk_r1cs_external_row(ctx, s->r1cs, U(d_eq_alpha), U(d_rows)));  // S4
+    // sharded witness WHIR: a rank needs (and computes) only the columns of the rows inside its block of the hypercube
+    const bool st_sharded = whir_sharded(ctx, m);
+    const size_t blk = st_sharded ? ((size_t)1 << m) / G : (size_t)1 << m, blk_lo = st_sharded ? (size_t)rank * blk : 0;
+    const size_t col_hi = n_witness < blk_lo + blk ? n_witness : blk_lo + blk, col_n = col_hi > blk_lo ? col_hi - blk_lo : 0;
+    if (st_sharded) CK(external_row_range(ctx, s->r1cs, U(d_eq_alpha), blk_lo, col_hi, U(d_rows)));  // S4, this rank's columns
+    else CK(pk_r1cs_external_row(ctx, s->r1cs, U(d_eq_alpha), U(d_rows)));                            // S4
     fe* wts[3];
     const size_t wlen[3] = {n_witness, n_witness, n_witness};
     std::vector<uint8_t> claimed;
     {
         std::vector<fe> fsum(3), gsum(3);
+        Across ac(ctx, st_sharded);
+        CK(ac.rc);
         for (int k = 0; k < 3; k++) {
             // the statement weight is row k zero-extended to 2^m (whir_r1cs.rs:391-400): only its support is stored and summed
             wts[k] = d_rows + (size_t)k * n_witness;
             uint64_t o[8] = {};
-            if (n_witness) CK(pk_dot2(ctx, U(wts[k]), U(W.f_evals), U(W.g_evals), n_witness, o));  // S5
+            if (st_sharded || n_witness) CK(pk_dot2(ctx, U(wts[k] + blk_lo), U(W.f_evals + blk_lo), U(W.g_evals + blk_lo), col_n, o));  // S5
             fsum[k] = h_load(o);
             gsum[k] = h_load(o + 4);
         }

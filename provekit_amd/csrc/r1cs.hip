@@ -40,18 +40,21 @@ __device__ __forceinline__ fe sparse_row_dot(const uint32_t* __restrict__ ptr, c
 __global__ __launch_bounds__(256) void witness_bounds_kernel(const uint32_t* pa, const uint32_t* ia, const uint32_t* va, const uint32_t* pb,
                                                              const uint32_t* ib, const uint32_t* vb, const fe* __restrict__ interner,
                                                              const fe* __restrict__ z, size_t num_rows, size_t padded, fe* __restrict__ a,
-                                                             fe* __restrict__ b, fe* __restrict__ c) {
+                                                             fe* __restrict__ b, fe* __restrict__ c, size_t stride, size_t offset) {
     PK_LATENCY_PRIO();
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= padded) return;
+    // output j holds row i = j * stride + offset: (1, 0) for the whole table, (G, g) for rank g's share of a sumcheck
+    // sharded by the low index bits (the leading variable's fold pairs i with i + len/2, both on one rank)
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= padded) return;
+    const size_t i = j * stride + offset;
     fe ra = fe_zero(), rb = fe_zero();
     if (i < num_rows) {
         ra = sparse_row_dot(pa, ia, va, interner, z, i);
         rb = sparse_row_dot(pb, ib, vb, interner, z, i);
     }
-    fe_store(a + i, ra);
-    fe_store(b + i, rb);
-    fe_store(c + i, fe_mulx(ra, rb));
+    fe_store(a + j, ra);
+    fe_store(b + j, rb);
+    fe_store(c + j, fe_mulx(ra, rb));
 }
 
 __global__ __launch_bounds__(256) void sparse_gather_kernel(const uint32_t* ptr, const uint32_t* idx, const uint32_t* val,
@@ -84,10 +87,10 @@ struct csc3 {
     const uint32_t *ptr[3], *idx[3], *val[3];
 };
 __global__ __launch_bounds__(256) void sparse_gather3_kernel(csc3 m, const fe* __restrict__ interner, const fe* __restrict__ x, size_t n_out,
-                                                             fe* __restrict__ y) {
+                                                             fe* __restrict__ y, size_t first, size_t last) {
     PK_LATENCY_PRIO();
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_out) return;
+    size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // columns [first, last) only: a rank's block of the rows
+    if (i >= last) return;
 #pragma unroll 1
     for (int k = 0; k < 3; k++) fe_store(y + (size_t)k * n_out + i, sparse_row_dot(m.ptr[k], m.idx[k], m.val[k], interner, x, i));
 }
@@ -287,7 +290,7 @@ int pk_r1cs_witness_bounds(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, u
     ProfScope prof(ctx, "witness_bounds");
     witness_bounds_kernel<<<(unsigned)((padded + 255) / 256), 256, 0, ctx->stream>>>(
         r->csr_ptr[0], r->csr_idx[0], r->csr_val[0], r->csr_ptr[1], r->csr_idx[1], r->csr_val[1], r->d_interner, (const fe*)d_z,
-        r->num_constraints, padded, (fe*)d_a, (fe*)d_b, (fe*)d_c);
+        r->num_constraints, padded, (fe*)d_a, (fe*)d_b, (fe*)d_c, 1, 0);
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
 }
@@ -348,9 +351,42 @@ int pk_r1cs_external_row(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_eq_alp
     }
     ProfScope prof(ctx, "sparse_matvec");
     sparse_gather3_kernel<<<(unsigned)((r->num_witnesses + 255) / 256), 256, 0, ctx->stream>>>(m, r->d_interner, (const fe*)d_eq_alpha, r->num_witnesses,
-                                                                                             (fe*)d_out);
+                                                                                             (fe*)d_out, 0, r->num_witnesses);
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
 }
 
 }  // extern "C"
+
+namespace pk {
+// rank `offset` of `stride` ranks: a, b, c for the rows i = j * stride + offset, j < 2^m0 / stride (prover.hip, sharded sumcheck)
+int witness_bounds_strided(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, unsigned m0, unsigned stride, unsigned offset, uint64_t* d_a,
+                           uint64_t* d_b, uint64_t* d_c) {
+    PK_REQUIRE(ctx, r && d_z && d_a && d_b && d_c, "null pointer");
+    PK_REQUIRE(ctx, m0 <= 30 && r->num_constraints <= ((size_t)1 << m0) && stride && offset < stride, "bad shard of the witness bounds");
+    const size_t padded = ((size_t)1 << m0) / stride;
+    ProfScope prof(ctx, "witness_bounds");
+    witness_bounds_kernel<<<(unsigned)((padded + 255) / 256), 256, 0, ctx->stream>>>(
+        r->csr_ptr[0], r->csr_idx[0], r->csr_val[0], r->csr_ptr[1], r->csr_idx[1], r->csr_val[1], r->d_interner, (const fe*)d_z,
+        r->num_constraints, padded, (fe*)d_a, (fe*)d_b, (fe*)d_c, stride, offset);
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+// columns [first, last) of the three external rows, written at their absolute positions of d_out (3 x num_witnesses)
+int external_row_range(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_eq_alpha, size_t first, size_t last, uint64_t* d_out) {
+    PK_REQUIRE(ctx, r && d_eq_alpha && d_out, "null pointer");
+    if (last > r->num_witnesses) last = r->num_witnesses;
+    if (first >= last) return PK_OK;
+    csc3 m;
+    for (int k = 0; k < 3; k++) {
+        m.ptr[k] = r->csc_ptr[k];
+        m.idx[k] = r->csc_idx[k];
+        m.val[k] = r->csc_val[k];
+    }
+    ProfScope prof(ctx, "sparse_matvec");
+    sparse_gather3_kernel<<<(unsigned)((last - first + 255) / 256), 256, 0, ctx->stream>>>(m, r->d_interner, (const fe*)d_eq_alpha, r->num_witnesses,
+                                                                                         (fe*)d_out, first, last);
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+}  // namespace pk

@@ -193,7 +193,7 @@ inline int reduction_scratch(pk_ctx* ctx) {
 }
 inline fe* red_partials(pk_ctx* ctx) { return (fe*)ctx->d_scratch; }
 inline unsigned* red_ticket(pk_ctx* ctx) { return (unsigned*)((char*)ctx->d_scratch + (size_t)RED_MAX_BLOCKS * 8 * 32 + 8 * 32); }
-inline fe* red_result(pk_ctx* ctx) { return (fe*)ctx->h_pinned; }
+inline fe* red_result(pk_ctx* ctx) { return ctx->red_across ? (fe*)ctx->d_xred : (fe*)ctx->h_pinned; }
 // next sequence number for a reduction launch on this context (never 0)
 inline unsigned next_seq(pk_ctx* ctx) {
     ctx->red_seq++;
@@ -205,6 +205,7 @@ inline unsigned next_seq(pk_ctx* ctx) {
 // loss with several provers per GPU, so the plain synchronisation is kept; the word stays for diagnostics.)
 template <int K>
 inline int collect_reduction(pk_ctx* ctx, uint64_t* host_out) {
+    if (ctx->red_across) return comm_collect_fe(ctx, K, host_out);  // partial sums of a sharded operand: sum over the ranks first
     int rc = sync_stream(ctx);
     if (rc) return rc;
     memcpy(host_out, ctx->h_pinned, 32 * K);

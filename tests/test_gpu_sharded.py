@@ -214,40 +214,93 @@ def test_sharded_prove_bench_size_transcript_identical(ctx, oracle, rank_sets):
     assert V.verify(want, ds, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
 
 
-def test_sharded_prove_p256_size_class_eight_ranks(ctx, oracle, rank_sets):
-    """BASELINE configs[3] as far as one GPU can take it: the m = 25 size class proven by EIGHT ranks (in-process transport,
-    all on GPU 0) under the derived schedule -- every rank's transcript is byte-identical to the lone prover's, and the
-    verifier accepts it.  Arenas: 8 x ~21 GiB; the lone prover's scheme is closed before the ranks allocate theirs."""
-    import verifier as V
+def sharded_profile(ctx, oracle, m, G, seed=25):
+    """One proof of the size class (m, m_0 = m - 1) by the lone prover and by G ranks of the in-process transport on GPU 0 under
+    the TURNSTILE (comm.hip: the ranks' segments run one after another, so pk_profile_* times each rank's kernels as if it had
+    the chip to itself).  Returns (lone transcript, rank transcripts, domain separator, report): report carries the per-kernel
+    milliseconds of the lone prover and of rank 0, each rank's kernel total, and the REPLICATED share derived from them:
+    T_rank = R + (T_lone - R) / G  =>  R = (T_rank - T_lone / G) / (1 - 1 / G)."""
+    import provekit_amd
     from test_gpu_prove import size_class_instance
 
     from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
     from provekit_amd.sparse_matrix import R1CS, SparseMatrix
 
-    m, m_0, G = 25, 24, 8
+    m_0 = m - 1
     nc, nw, mats, interner, z = size_class_instance(oracle, m)
     cfg_w, cfg_b = WhirConfig.derive(m), blinding_config_for(m_0)
+    gate = threading.Barrier(G)
 
-    def prove_on(c):
+    def prove_on(c, wait=None):
         r1cs = R1CS(c, *(SparseMatrix(nc, nw, *t) for t in mats), interner)
         s = WhirR1CSScheme(c, r1cs, m, m_0, cfg_w, cfg_b)
         d_z = c.upload(z)
-        proof = s.prove(d_z, seed=25)
+        s.prove(d_z, seed=seed + 1)  # warm-up: twiddle tables, workspaces
+        c.sync()
+        if wait is not None:
+            wait.wait()
+        c.profile(True)
+        c.profile_reset()
+        proof = s.prove(d_z, seed=seed)
+        prof = c.profile_read()
+        c.profile(False)
         ds = s.domain_separator
         s.close()
         r1cs.close()
         d_z.free()
-        return proof, ds
+        return proof, ds, prof
 
-    want, ds = prove_on(ctx)
-    for proof, _ in run_ranks(rank_sets(G), lambda r, c: prove_on(c)):
+    want, ds, lone = prove_on(ctx)
+    os.environ["PK_LOCAL_TURNSTILE"] = "1"
+    try:
+        ranks = provekit_amd.Context.create_set([0] * G)
+    finally:
+        del os.environ["PK_LOCAL_TURNSTILE"]
+    try:
+        res = run_ranks(ranks, lambda r, c: prove_on(c, gate))
+    finally:
+        for c in ranks:
+            c.close()
+    kernel_ms = lambda prof: sum(v[1] for k, v in prof.items() if not k.startswith("comm_"))
+    t_lone = kernel_ms(lone)
+    t_rank = [kernel_ms(p) for _, _, p in res]
+    worst = max(t_rank)
+    report = {
+        "m": m, "ranks": G, "transport": "in-process, one GPU, turnstile (ranks take turns between collectives)",
+        "lone_kernel_ms": round(t_lone, 3), "rank_kernel_ms": [round(t, 3) for t in t_rank],
+        "rank_over_lone": round(worst / t_lone, 4), "ideal": round(1.0 / G, 4),
+        "replicated_share_of_lone": round((worst - t_lone / G) / (1.0 - 1.0 / G) / t_lone, 4),
+        "amdahl_speedup_bound": round(t_lone / worst, 2),
+        "lone_ms_by_kernel": {k: round(v[1], 3) for k, v in sorted(lone.items(), key=lambda kv: -kv[1][1])},
+        "rank0_ms_by_kernel": {k: round(v[1], 3) for k, v in sorted(res[0][2].items(), key=lambda kv: -kv[1][1])},
+    }
+    return want, [p for p, _, _ in res], ds, report
+
+
+def test_sharded_prove_p256_size_class_eight_ranks(ctx, oracle):
+    """BASELINE configs[3] as far as one GPU can take it: the m = 25 size class proven by EIGHT ranks (in-process transport, all on
+    GPU 0) under the derived schedule -- every rank's transcript is byte-identical to the lone prover's, the verifier accepts it,
+    and the work a rank still does in full (replicated) is under a quarter of the lone prover's kernel time: commits, both
+    sumchecks, the equality weights, the statement weights, OOD evaluations and proof-of-work are all split over the ranks."""
+    import json
+
+    import verifier as V
+
+    from provekit_amd.scheme import WhirConfig, blinding_config_for
+
+    m, G = 25, 8
+    want, got, ds, report = sharded_profile(ctx, oracle, m, G)
+    print("sharded_profile", json.dumps(report))
+    for proof in got:
         assert proof == want, "a rank of the 8-way sharded prover diverged from the lone prover's transcript"
+    assert report["replicated_share_of_lone"] < 0.25, report
+    cfg_w, cfg_b = WhirConfig.derive(m), blinding_config_for(m - 1)
 
     def vcfg(c):
         return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
                             c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
 
-    assert V.verify(want, ds, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
+    assert V.verify(want, ds, m, m - 1, vcfg(cfg_w), vcfg(cfg_b))
 
 
 # ---- >= 2 GPUs: RCCL between distinct devices.  Skipped on a one-GPU box; the first multi-GPU box runs them unchanged. ----------
