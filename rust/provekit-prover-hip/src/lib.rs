@@ -10,14 +10,17 @@
 //! private, its serde impl is public), the two `WhirConfig`s as the plain numbers the prover consumes, the witness per proof
 //! (`&[FieldElement]` is `[u64; 4]` Montgomery limbs, the ABI's element layout), and the proof string back.
 //!
-//! Grain.  `pk_prove` runs the whole of `prove` behind the ABI, including the duplex-sponge transcript, so the bytes of the
-//! proof follow that library's domain-separator labels; the reference's come from `spongefish`/`whir`, which are not in its
-//! tree (Cargo.toml:130-132), so byte-compatibility with a stock verifier is unpinned (DESIGN.md "Oracle and pinning").
-//! Keeping the transcript in `spongefish::ProverState` instead means driving the per-step entry points from Rust
-//! (INTEGRATION.md 4b lists the call for each block of `prove`); the three plug-in shaped pieces that already have a
-//! reference interface are below and work either way: [`compress_many`], [`SkyscraperPoWHip`], [`HipR1CS`].
+//! Two grains.  [`HipProver`] hands the whole of `prove` to `pk_prove`, duplex-sponge transcript included: fastest (one FFI call
+//! per proof), but the bytes follow that library's own domain-separator labels -- the reference's come from `spongefish`/`whir`,
+//! which are not in its tree (Cargo.toml:130-132), so a stock verifier does not accept them (DESIGN.md "Oracle and pinning").
+//! [`stepwise::StepProver`] keeps the transcript in `spongefish::ProverState`, created from the scheme's own `IOPattern`, and
+//! calls one entry point per data-parallel block: byte-compatible by construction for the in-tree half of
+//! `prove`; [`stepwise::HipNoirProofScheme`] puts `NoirProofSchemeProver` (the trait the CLI calls) on top of it.  The three
+//! plug-in shaped pieces that already have a reference interface are below and work either way: [`compress_many`],
+//! [`SkyscraperPoWHip`], [`HipR1CS`].
 #![allow(clippy::missing_safety_doc)]
 
+pub mod stepwise;
 pub mod sys;
 
 use {

@@ -70,9 +70,11 @@ def test_rust_sys_bindings_match_the_header():
     sys_rs = open(os.path.join(ROOT, "rust", "provekit-prover-hip", "src", "sys.rs")).read()
     decls = dict(re.findall(r"pub fn (pk_\w+)\((.*?)\) ->", sys_rs))
     assert sorted(decls) == declared_symbols()
-    lib_rs = open(os.path.join(ROOT, "rust", "provekit-prover-hip", "src", "lib.rs")).read()
+    src_dir = os.path.join(ROOT, "rust", "provekit-prover-hip", "src")
+    # lib.rs (one-call grain) and stepwise.rs (per-step grain: transcript in spongefish)
+    lib_rs = open(os.path.join(src_dir, "lib.rs")).read() + "\n" + open(os.path.join(src_dir, "stepwise.rs")).read()
     calls = re.findall(r"sys::(pk_\w+)\s*\(", lib_rs)
-    assert len(set(calls)) >= 10
+    assert len(set(calls)) >= 30
     for name in set(calls):
         assert name in decls, f"lib.rs calls {name}, which the header does not declare"
     # argument counts of the calls (balanced-parenthesis scan of the call's argument list)
