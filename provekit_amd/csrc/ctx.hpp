@@ -38,6 +38,7 @@ struct pk_ctx {
     size_t pinned_bytes = 0;
     std::map<unsigned, void*> twiddles;  // log2(N) -> device table of w_N^e, N entries (owned; ntt.hip)
     std::map<unsigned, void*> twiddles29[2];  // [0] of twiddles, [1] of twiddles_scaled: 9 x u32 per entry, limbs of 32*value (ntt.hip)
+    std::map<unsigned, void*> twiddles_pass;   // inter-pass twiddles in access order, per (size, pass, variant) (ntt.hip get_pass_table)
     std::map<unsigned, void*> twiddles_scaled;  // log2(N) -> 32 * w_N^e as plain integers: the hash-ready output scaling (ntt.hip)
     unsigned red_seq = 0;  // sequence number of the last reduction launch (completion flag in h_pinned)
     void* d_ws = nullptr;  // large reusable workspace (NTT scratch); grows, never shrinks

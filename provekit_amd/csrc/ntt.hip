@@ -88,6 +88,17 @@ __global__ __launch_bounds__(256) void twiddle_unpack_kernel(const fe* __restric
     for (int l = 0; l < 9; l++) W29[9 * j + l] = t.v[l];
 }
 
+// T[k * row + v] = src29[(mul * k * v) & mask]: an inter-pass twiddle table re-ordered into the order the pass reads it
+__global__ __launch_bounds__(256) void twiddle_pass_table_kernel(const u32* __restrict__ src29, u32* __restrict__ T, size_t rows_k, size_t row, size_t mul,
+                                                                 size_t mask) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows_k * row) return;
+    const size_t k = i / row, v = i % row;
+    const u32* q = src29 + 9 * ((mul * k * v) & mask);
+#pragma unroll
+    for (int l = 0; l < 9; l++) T[9 * i + l] = q[l];
+}
+
 struct PassParams {
     const fe* in;
     fe* out;
@@ -101,6 +112,13 @@ struct PassParams {
     const fe* Wtw;      // table the inter-pass twiddle is read from: W, or its hash-ready variant 32*w_N^e (see ntt_columns)
     const u32* W29;     // W again, every entry already in the multiplier's operand form (9 limbs of 32*w): register-radix kernel
     const u32* Wtw29;   // Wtw likewise
+    const u32* Tpass29; // optional: the inter-pass twiddles of THIS pass in access order, T[k * tp_row + (v0 + b)] = w_N^(tw_mul k (v0+b))
+                        // in operand form (or its hash-ready variant) -- adjacent lanes read adjacent 36-byte entries instead of
+                        // gathering from the size-N table at stride k; null = gather from Wtw29
+    size_t tp_row;      // entries per k of Tpass29 (the extent of the v axis)
+    size_t tiles;       // register-radix kernel: tiles per column, columns, and whether the XCD-aware block order applies
+    unsigned ncols;
+    int xcd_tiles;
     int lazy_store;     // outputs may be stored almost reduced (< 1.6p) instead of canonical: intermediate passes, and the
                         // hash-ready final pass (its consumers reduce anyway)
     size_t n_mask;      // N - 1
@@ -345,7 +363,9 @@ __device__ __forceinline__ void ntt8_round(fe29 (&x)[8], const PassParams& p, co
             const int b = PK_TILE_INDEX(reg) & (BTT - 1);
             const int k = k_hi | (a << KLO);
             fe29 y;
-            if (p.tw_mul) {
+            if (p.tw_mul && p.Tpass29) {
+                y = mont261_29(x[reg], tw29u(p.Tpass29, (size_t)k * p.tp_row + (c.v0 + b)));
+            } else if (p.tw_mul) {
                 size_t ex = (p.tw_mul * (size_t)k * (c.v0 + b)) & p.n_mask;
                 y = mont261_29(x[reg], tw29u(p.Wtw29, ex));
             } else {
@@ -364,8 +384,19 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     constexpr int NR = (LOG_R + 2) / 3;
     extern __shared__ u32 planes[];  // [9][2048]
     const size_t vblocks = ((size_t)1 << p.log_v) >> LOGB;
-    const size_t u = blockIdx.x / vblocks, vb = blockIdx.x % vblocks;
-    const size_t col = blockIdx.y;
+    // block -> (tile, column).  Workgroup b runs on XCD b % 8 (observed placement, used for speed only): an XCD takes the tiles
+    // t = xcd (mod 8) and, for each, all columns back to back, so the tile's inter-pass twiddles (the same rows of the
+    // pass-ordered table for every column) are fetched from HBM once and served from that XCD's L2 for the other columns.
+    size_t tile, col;
+    if (p.xcd_tiles) {
+        const size_t j = blockIdx.x >> 3;
+        col = j % p.ncols;
+        tile = (j / p.ncols) * 8 + (blockIdx.x & 7);
+    } else {
+        tile = blockIdx.x % p.tiles;
+        col = blockIdx.x / p.tiles;
+    }
+    const size_t u = tile / vblocks, vb = tile % vblocks;
     Ntt8Ctx c;
     c.v0 = vb << LOGB;
     c.in = p.in + col * p.in_col_stride + u * p.in_stride_u + c.v0 * p.in_stride_v;
@@ -496,6 +527,24 @@ int get_twiddles29(pk_ctx* ctx, unsigned log_n, int which, const fe* W, const u3
     return PK_OK;
 }
 
+// the pass-ordered table of one (size, pass, variant): key = log_n | pass << 8 | scaled << 12
+int get_pass_table(pk_ctx* ctx, unsigned log_n, unsigned pass, bool scaled, const u32* src29, size_t rows_k, size_t row, size_t mul, const u32** out) {
+    const unsigned key = log_n | (pass << 8) | ((scaled ? 1u : 0u) << 12);
+    auto it = ctx->twiddles_pass.find(key);
+    if (it != ctx->twiddles_pass.end()) {
+        *out = (const u32*)it->second;
+        return PK_OK;
+    }
+    u32* T = nullptr;
+    const size_t n = rows_k * row;
+    PK_HIP(ctx, hipMalloc((void**)&T, 36 * n));
+    twiddle_pass_table_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(src29, T, rows_k, row, mul, ((size_t)1 << log_n) - 1);
+    PK_LAUNCH_CHECK(ctx);
+    ctx->twiddles_pass[key] = T;
+    *out = T;
+    return PK_OK;
+}
+
 // does a pass of radix 2^log_r over a v axis of 2^log_v take the register-radix kernel?
 inline bool pass_is_fast(unsigned log_r, unsigned log_v, size_t N) { return log_r >= 3 && log_v < 62 && log_v >= 11 - log_r && N >= 8; }
 
@@ -507,7 +556,12 @@ int launch_pass_r(pk_ctx* ctx, const PassParams& p, bool in_r_contig, size_t til
         ProfScope prof(ctx, in_r_contig ? "ntt_pass_last" : "ntt_pass");
         const size_t tiles8 = (tiles * BT) >> (11 - LOG_R);
         const size_t lds_bytes = 9 * 2048 * 4;
-        dim3 grid((unsigned)tiles8, ncols);
+        PassParams pp = p;
+        pp.tiles = tiles8;
+        pp.ncols = ncols;
+        pp.xcd_tiles = (tiles8 % 8 == 0) ? 1 : 0;
+        PK_REQUIRE(ctx, tiles8 * ncols < ((size_t)1 << 31), "NTT launch too large");
+        dim3 grid((unsigned)(tiles8 * ncols), 1);
         // the 72 KiB dynamic-LDS opt-in is a per-function, per-device attribute: set it once per device, not per launch
         static std::atomic<unsigned long long> lds_set[2] = {{0}, {0}};
         const unsigned long long dev_bit = 1ull << (ctx->device & 63);
@@ -521,9 +575,9 @@ int launch_pass_r(pk_ctx* ctx, const PassParams& p, bool in_r_contig, size_t til
             lds_set[in_r_contig].fetch_or(dev_bit, std::memory_order_release);
         }
         if (in_r_contig)
-            ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), true><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(p);
+            ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), true><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(pp);
         else
-            ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), false><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(p);
+            ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), false><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(pp);
         PK_LAUNCH_CHECK(ctx);
         return PK_OK;
     }
@@ -570,6 +624,8 @@ void ntt_release_ctx(pk_ctx* ctx) {
         for (auto& kv : c) (void)hipFree(kv.second);
         c.clear();
     }
+    for (auto& kv : ctx->twiddles_pass) (void)hipFree(kv.second);
+    ctx->twiddles_pass.clear();
 }
 
 // Can a transform of this size deliver the hash-ready output (every output = 32 * value as a plain integer < p instead of
@@ -671,8 +727,11 @@ int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero,
         p.Wtw29 = Ws29;
         p.lazy_store = pass_is_fast(l2, l1, N);  // the register-radix kernel takes almost reduced inputs
         p.wr_step = N >> l1;
+        if (pass_is_fast(l1, l2, N) && (rc = get_pass_table(ctx, log_n, 1, scaled_out, Ws29, R1, R2, 1, &p.Tpass29))) return rc;
+        p.tp_row = R2;
         rc = launch_pass(ctx, l1, p, false, R2 / BT, ncols);
         if (rc) return rc;
+        p.Tpass29 = nullptr;
         p.Wtw = W;
         p.Wtw29 = W29;
         p.lazy_store = scaled_out ? 1 : 0;
@@ -706,8 +765,11 @@ int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero,
     p.tw_mul = 1;
     p.lazy_store = pass_is_fast(l2, l3, N);
     p.wr_step = N >> l1;
+    if (pass_is_fast(l1, l2 + l3, N) && (rc = get_pass_table(ctx, log_n, 1, false, W29, R1, R2 * R3, 1, &p.Tpass29))) return rc;
+    p.tp_row = R2 * R3;
     rc = launch_pass(ctx, l1, p, false, (R2 * R3) / BT, ncols);
     if (rc) return rc;
+    p.Tpass29 = nullptr;
     // pass 2: DFT over n2 (stride R3); v = n3; u = k1 (stride R2*R3); in place; twiddle w_N^(R1*k2*n3)
     p.in = scratch;
     p.out = scratch;
@@ -723,8 +785,11 @@ int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero,
     p.Wtw29 = Ws29;
     p.lazy_store = pass_is_fast(l3, l1, N);
     p.wr_step = N >> l2;
+    if (pass_is_fast(l2, l3, N) && (rc = get_pass_table(ctx, log_n, 2, scaled_out, Ws29, R2, R3, R1, &p.Tpass29))) return rc;
+    p.tp_row = R3;
     rc = launch_pass(ctx, l2, p, false, R1 * (R3 / BT), ncols);
     if (rc) return rc;
+    p.Tpass29 = nullptr;
     p.Wtw = W;
     p.Wtw29 = W29;
     p.lazy_store = scaled_out ? 1 : 0;
