@@ -303,6 +303,105 @@ def test_sharded_prove_p256_size_class_eight_ranks(ctx, oracle):
     assert V.verify(want, ds, m, m - 1, vcfg(cfg_w), vcfg(cfg_b))
 
 
+def test_a_failing_rank_wakes_its_peers_instead_of_hanging_them(rank_sets):
+    """a rank that fails before reaching a collective used to leave the others blocked on the barrier.  Here rank 1
+    asks for a commit it cannot do (a null polynomial pointer fails inside commit_into, after the layout was decided and
+    before the all-gather): it aborts the group, rank 0 -- already waiting in the all-gather -- returns PK_ERR_RCCL, and every
+    later collective on the set fails at once on both ranks."""
+    from provekit_amd._lib import ProveKitHipError, lib
+    from provekit_amd.field import random_field
+
+    ctxs = rank_sets(2)
+    n_vars = 14
+    poly = random_field(1 << n_vars, 3)
+
+    def fn(r, c):
+        d = c.upload(poly)
+        ptrs = (C.c_void_p * 1)(d.ptr if r == 0 else None)
+        szs = [C.c_size_t() for _ in range(3)]
+        c._check(lib.pk_commit_sizes(c.handle, 1, n_vars, 1, 4, *[C.byref(x) for x in szs]))
+        leaves, nodes, scratch = (c.alloc_fe(x.value) for x in szs)
+        root = (C.c_uint8 * 32)()
+        rc = lib.pk_commit_into(c.handle, ptrs, 1, n_vars, 1, 4, leaves.ptr, nodes.ptr, scratch.ptr, root, None)
+        x = c.upload(np.arange(8, dtype=np.uint64))
+        y = c.alloc(128)
+        rc2 = lib.pk_comm_all_gather(c.handle, x.ptr, y.ptr, 64)
+        return rc, rc2
+
+    res = run_ranks(ctxs, fn)
+    assert res[1][0] == -1  # PK_ERR_BAD_ARG on the rank that failed
+    assert res[0][0] == -4  # PK_ERR_RCCL on the rank that was waiting for it
+    assert res[0][1] == -4 and res[1][1] == -4  # the communicator stays unusable: nobody waits for anybody
+
+
+def test_host_transport_in_process_and_its_failure_path(ctx):
+    """pk_comm_init_host with a Python callback standing in for MPI / gloo: two contexts of this process exchange through a
+    rendezvous written here; then a callback that reports failure must surface as PK_ERR_RCCL and poison the communicator."""
+    import provekit_amd
+    from provekit_amd._lib import lib
+    from provekit_amd.field import random_field
+    from provekit_amd.whir import commit_batch
+
+    G = 2
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+    gate = threading.Barrier(G)
+    slots = [None] * G
+    fail = {"on": False}
+
+    def make_cb(rank):
+        def cb(_user, send, recv, nbytes):
+            if fail["on"]:
+                return 7
+            slots[rank] = C.string_at(send, nbytes)
+            gate.wait()
+            C.memmove(recv, b"".join(slots), G * nbytes)
+            gate.wait()
+            return 0
+
+        return CB(cb)
+
+    cbs = [make_cb(r) for r in range(G)]
+    ctxs = [provekit_amd.Context(0) for _ in range(G)]
+    try:
+        for r, c in enumerate(ctxs):
+            c._check(lib.pk_comm_init_host(c.handle, G, r, cbs[r], None))
+            assert c.comm_info() == (r, G, 3)  # PK_COMM_HOST
+        n_vars = 14
+        polys = [random_field(1 << n_vars, 40 + b) for b in range(2)]
+        ref = commit_batch(ctx, [ctx.upload(p) for p in polys], n_vars)
+        idx = np.array([0, 5, 77, ref.n_leaves - 1], dtype=np.uint64)
+        want = ref.open(idx, canonical_leaves=True)
+
+        def fn(r, c):
+            com = commit_batch(c, [c.upload(p) for p in polys], n_vars)
+            out = (com.root, com.open(idx, canonical_leaves=True))
+            com.close()
+            return out
+
+        for root, opened in run_ranks(ctxs, fn):
+            assert root == ref.root
+            for a, b in zip(opened, want):
+                assert np.array_equal(a, b)
+        ref.close()
+        fail["on"] = True
+        x = ctxs[0].upload(np.arange(8, dtype=np.uint64))
+        y = ctxs[0].alloc(128)
+        assert lib.pk_comm_all_gather(ctxs[0].handle, x.ptr, y.ptr, 64) == -4
+        fail["on"] = False
+        assert lib.pk_comm_all_gather(ctxs[0].handle, x.ptr, y.ptr, 64) == -4  # sticky
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.parametrize("G,m", [(2, 13), (4, 15), (16, 17), (2, 16)])
+def test_sharded_prove_around_the_sharding_thresholds(ctx, oracle, rank_sets, G, m):
+    """sizes at which some arrays of a proof are sharded and others are not (commits from 64 rows per rank, sumcheck tables from
+    2^13 entries per rank), and the widest set the library takes (16 ranks): transcripts still equal the lone prover's"""
+    _sharded_prove_case(ctx, oracle, rank_sets, G, m=m, m_0=m - 1, nc=(1 << (m - 2)) - 37, n_in=(1 << (m - 3)) - 5, seed=m + G, test_pow=6.0,
+                        verify_r1cs=False)
+
+
 # ---- >= 2 GPUs: RCCL between distinct devices.  Skipped on a one-GPU box; the first multi-GPU box runs them unchanged. ----------
 def _gpu_count():
     from provekit_amd._lib import lib

@@ -98,6 +98,23 @@ __global__ __launch_bounds__(256) void bench(unsigned* out, unsigned seed, unsig
 #define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_mad_u32_u16 %0, %1, %2, %0" : "+v"(lo) : "v"(a), "v"(b)); acc[k] = lo; }
             BODY8(S)
 #undef S
+        } else if (OP == 16) {  // the cross-lane moves a wavefront-cooperative multiplier would be made of
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_mov_b32_dpp %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(lo)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 17) {  // broadcast of one lane through an SGPR into a multiply-add (v_readfirstlane-style m_i broadcast)
+#define S(k) { unsigned s; asm volatile("v_readlane_b32 %0, %2, 0\n\tv_mad_u64_u32 %1, vcc, %0, %3, %1" : "=&s"(s), "+v"(acc[k]) : "v"((unsigned)acc[(k + 1) & 7]), "v"(b) : "vcc"); }
+            BODY8(S)
+#undef S
+        } else if (OP == 18) {  // ONE dependent chain (no ILP): what a latency-bound lane actually sees per v_mad_u64_u32
+            asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+                         "v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_mad_u64_u32 %0, vcc, %1, %2, %0"
+                         : "+v"(acc[0]) : "v"(a), "v"(b) : "vcc");
+        } else if (OP == 19) {  // one dependent chain of plain VALU
+            unsigned lo = (unsigned)acc[0];
+            asm volatile("v_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %1\n\tv_add_u32 %0, %0, %1"
+                         : "+v"(lo) : "v"(b));
+            acc[0] = lo;
         }
     }
     unsigned long long r = 0;
@@ -164,5 +181,12 @@ int main() {
     run<14>("v_dot2_u32_u16", d_out, cus, ghz);
     run<3>("v_fma_f64", d_out, cus, ghz);
     run<11>("v_add_f64", d_out, cus, ghz);
+    // one wavefront per SIMD: the issue costs a latency-bound (tree-top, small-tree) hash sees
+    run<7>("v_add_u32", d_out, cus, ghz, 1);
+    run<19>("v_add_u32 1 chain", d_out, cus, ghz, 1);
+    run<0>("v_mad_u64_u32", d_out, cus, ghz, 1);
+    run<18>("v_mad_u64 1 chain", d_out, cus, ghz, 1);
+    run<16>("v_mov_dpp row_shl", d_out, cus, ghz, 1);
+    run<17>("readlane+mad pair", d_out, cus, ghz, 1);
     return 0;
 }
