@@ -22,7 +22,7 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def ctx():
-    # torch bundles its own HIP runtime: when a test uses both, torch must initialise it first (see provekit_amd/distributed.py)
+    # torch bundles its own HIP runtime: when a test uses both, torch must initialise it first (PyTorch wheels bundle their own HIP runtime; one runtime must serve both)
     import torch
 
     torch.cuda.is_available()
