@@ -95,3 +95,55 @@ def test_commit_2p26_batch2_against_definition_and_sharded_root(ctx, oracle):
         assert np.array_equal(ctx.download_fe(d_nodes.view_fe(1), 1)[0], root)
     finally:
         lib.pk_tree_destroy(ctx.handle, tree)
+
+
+@pytest.mark.parametrize("log_len", [20, 22])
+def test_sumcheck_cubic_rounds_full_size_vs_oracle(ctx, oracle, log_len):
+    """the Spartan sumcheck's hot loop (sumcheck.rs:16-104 with the map of whir_r1cs.rs:284-291) at the sizes the bench and the
+    sha256 size class run it, every round's three evaluations against the oracle and the folded arrays compared at the end
+    (tests/test_gpu_mle.py stops at 2^18)"""
+    from provekit_amd import sumcheck as sc
+    from provekit_amd.field import random_field
+
+    n = 1 << log_len
+    arrs = [random_field(n, 520 + k + log_len) for k in range(4)]
+    d = [ctx.upload(a) for a in arrs]
+    alphas = random_field(log_len, 599)
+    cur, length, fold = [a.copy() for a in arrs], n, None
+    for rnd in range(log_len):
+        got = sc.sumcheck_fold_map_reduce(ctx, *d, length, fold)
+        exp, *cur = oracle.sumcheck_cubic_round(*[c[:length] for c in cur], fold)
+        assert np.array_equal(got, exp), (log_len, rnd)
+        if fold is not None:
+            length //= 2
+            if rnd in (1, 4, 9) or length <= 64:
+                for k in range(4):
+                    assert np.array_equal(ctx.download_fe(d[k], length), cur[k][:length]), (rnd, k)
+        fold = alphas[rnd]
+
+
+@pytest.mark.parametrize("log_len", [21, 23])
+def test_sumcheck_quadratic_rounds_full_size_vs_oracle(ctx, oracle, log_len):
+    """the WHIR sumcheck (whir_utilities.go:102-125) at the witness polynomial's size of the bench (2^21) and of the sha256 size
+    class (2^23): h(0), h(1), h(2) of every round and the folded tables against the oracle"""
+    from provekit_amd import sumcheck as sc
+    from provekit_amd.field import random_field
+
+    n = 1 << log_len
+    f, w = random_field(n, 631 + log_len), random_field(n, 632 + log_len)
+    bufs = [[ctx.upload(f), ctx.alloc_fe(n)], [ctx.upload(w), ctx.alloc_fe(n)]]
+    rs = random_field(log_len, 677)
+    cf, cw, length, fold, cur = f, w, n, None, 0
+    for rnd in range(log_len):
+        if fold is None:
+            got = sc.sumcheck_quadratic_round(ctx, bufs[0][cur], bufs[1][cur], length)
+        else:
+            got = sc.sumcheck_quadratic_round(ctx, bufs[0][cur], bufs[1][cur], length, fold, bufs[0][1 - cur], bufs[1][1 - cur])
+            cur, length = 1 - cur, length // 2
+        full = length * 2 if fold is not None else length
+        exp, cf, cw = oracle.sumcheck_quadratic_round(cf[:full], cw[:full], fold)
+        assert np.array_equal(got, exp), (log_len, rnd)
+        if fold is not None and (rnd in (1, 5) or length <= 64):
+            assert np.array_equal(ctx.download_fe(bufs[0][cur], length), cf[:length])
+            assert np.array_equal(ctx.download_fe(bufs[1][cur], length), cw[:length])
+        fold = rs[rnd]
