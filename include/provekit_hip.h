@@ -402,6 +402,33 @@ int pk_prove(pk_ctx *ctx, pk_scheme *scheme, const uint64_t *d_witness, size_t n
 /* the spongefish-style domain separator the transcript IV is derived from (labels are this library's) */
 int pk_scheme_domain_separator(const pk_scheme *scheme, char *buf, size_t cap, size_t *len);
 
+/* ------------------------------------------------------------------ X4: the R1CS witness builders
+ * R1CSSolver::solve_witness_vec (provekit/prover/src/r1cs.rs:29-40): the loop over &[WitnessBuilder] calling
+ * WitnessBuilderSolver::solve (provekit/prover/src/witness/witness_builder.rs:27-193; digits.rs:12-59; ram.rs:13-47).  ACVM
+ * execution stays on the host; its result (the ACIR witness map, as a dense array indexed by ACIR witness index, Montgomery
+ * elements -- noir_to_native is the identity on the limbs) and the challenges the host transcript draws for the
+ * WitnessBuilder::Challenge entries (in list order; Challenge reads the transcript and nothing else) are the inputs.
+ *   pk_witness_builders_from_postcard   `bytes` = postcard(&Vec<WitnessBuilder>) -- the enum and everything inside it are defined
+ *                                        in the reference tree (provekit/common/src/witness/witness_builder.rs:33-117), and this is
+ *                                        how the list sits inside a .nps.  Decodes, checks (an input no EARLIER builder produced is a
+ *                                        None the reference would unwrap: PK_ERR_BAD_ARG names it; so is a witness written twice),
+ *                                        levels the list by data dependence and uploads it.
+ *   pk_witness_builders_inspect         the same decode + levelling on the host only (no device): shape of the program.
+ *   pk_witness_solve                    d_witness[n_witness] (zeroed, then every solved entry written), d_is_set[n_witness] = 1 where
+ *                                        the reference's Vec<Option<F>> is Some.  The points where the reference panics -- inverse of
+ *                                        zero, "Higher order bits are not zero", a multiplicity / memory index out of range -- return
+ *                                        PK_ERR_UNSATISFIED naming the first builder (in list order) that hits one.
+ * fill_witness (random values for the None entries, prover/src/witness/mod.rs:15-30) stays with the caller. */
+typedef struct pk_witness_program pk_witness_program;
+int pk_witness_builders_from_postcard(pk_ctx *ctx, const uint8_t *bytes, size_t len, pk_witness_program **out,
+                                      size_t *n_witnesses, size_t *n_challenges, size_t *n_acir);
+int pk_witness_builders_inspect(const uint8_t *bytes, size_t len, size_t *n_builders, size_t *n_witnesses,
+                                size_t *n_challenges, size_t *n_acir, size_t *n_levels, size_t *n_items, size_t *consumed,
+                                char *err, size_t err_cap);
+int pk_witness_solve(pk_ctx *ctx, pk_witness_program *prog, const uint64_t *d_acir, size_t n_acir, const uint64_t *challenges,
+                     size_t n_challenges, uint64_t *d_witness, size_t n_witness, uint8_t *d_is_set);
+int pk_witness_program_destroy(pk_ctx *ctx, pk_witness_program *prog);
+
 /* ------------------------------------------------------------------ self-test (host only, no device)
  * Runs the library's __host__ __device__ arithmetic (the same source the kernels compile) on the CPU:
  * op 0: a*b*2^-256 mod p (ark-ff mul)   1: Skyscraper v2 compress   2: v1 compress   3: from Montgomery

@@ -1,0 +1,132 @@
+"""TEST INFRASTRUCTURE ONLY (CPU oracle; never imported by the product).  Pure-Python restatement of the reference's R1CS witness
+solver, builder by builder, in list order, on Python ints mod p:
+    R1CSSolver::solve_witness_vec                provekit/prover/src/r1cs.rs:29-40
+    WitnessBuilderSolver::solve                  provekit/prover/src/witness/witness_builder.rs:27-193
+    DigitalDecompositionWitnessesSolver::solve   provekit/prover/src/witness/digits.rs:12-59  (decompose_into_digits, le_bits_to_field)
+    SpiceWitnessesSolver::solve                  provekit/prover/src/witness/ram.rs:13-47
+Builders are the tuples provekit_amd.witness.WitnessBuilder constructs (same fields, same order as the Rust enum).  A witness is
+None until solved; reading a None raises (the reference's `.unwrap()` panic), as do the reference's other panics.
+Pinned by: the reference's own unit tests of the digit helpers (digits.rs:88-113, restated in tests/test_witness_oracle.py);
+everything else is definition-pinned (the reference holds no vectors for the solver)."""
+P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+BINOP_ATOMIC_BITS = 8  # provekit/common/src/witness/binops.rs:6
+
+
+class SolverPanic(Exception):
+    pass
+
+
+def field_to_le_bits(v):  # digits.rs:62-64: 256 bits, little-endian
+    return [(v >> i) & 1 for i in range(256)]
+
+
+def le_bits_to_field(bits):  # digits.rs:69-86
+    return sum(b << i for i, b in enumerate(bits)) % P
+
+
+def decompose_into_digits(value, log_bases):  # digits.rs:33-59
+    bits = field_to_le_bits(value)
+    digits, start = [], 0
+    for lb in log_bases:
+        if start + lb > 256:
+            raise SolverPanic("range end index out of range for slice")
+        digits.append(le_bits_to_field(bits[start:start + lb]))
+        start += lb
+    if any(bits[start:]):
+        raise SolverPanic("Higher order bits are not zero")
+    return digits
+
+
+def solve_witness_vec(builders, acir, challenges, num_witnesses):
+    w = [None] * num_witnesses
+    ch = iter(challenges)
+
+    def rd(i):
+        if w[i] is None:
+            raise SolverPanic(f"called `Option::unwrap()` on a `None` value (witness {i})")
+        return w[i]
+
+    def cow(x):
+        return x[1] if x[0] == "c" else rd(x[1])
+
+    for b in builders:
+        t = b[0]
+        if t == 0:
+            w[b[1]] = b[2]
+        elif t == 1:
+            w[b[1]] = acir[b[2]]
+        elif t == 2:
+            w[b[1]] = sum((rd(i) if c is None else c * rd(i)) for c, i in b[2]) % P
+        elif t == 3:
+            w[b[1]] = rd(b[2]) * rd(b[3]) % P
+        elif t == 4:
+            _, start, size, values = b
+            mult = [0] * size
+            for i in values:
+                v = rd(i) & (2**64 - 1)
+                if v >= size:
+                    raise SolverPanic("index out of bounds")
+                mult[v] += 1
+            for i, c in enumerate(mult):
+                w[start + i] = c
+        elif t == 5:
+            w[b[1]] = next(ch)
+        elif t == 6:
+            _, idx, sz, coeff, index, rs, value = b
+            w[idx] = (rd(sz) - (coeff * rd(index) + rd(rs) * rd(value))) % P
+        elif t == 7:
+            x = rd(b[2])
+            if x == 0:
+                raise SolverPanic("called `Option::unwrap()` on a `None` value (inverse of zero)")
+            w[b[1]] = pow(x, -1, P)
+        elif t == 8:
+            _, idx, x, a, bb, y, c, d = b
+            w[idx] = (a * rd(x) + bb) * (c * rd(y) + d) % P
+        elif t == 9:
+            _, idx, sz, coeff, value = b
+            w[idx] = (rd(sz) - coeff * rd(value)) % P
+        elif t == 10:
+            _, log_bases, n, values, first, _num = b
+            for i, vi in enumerate(values):
+                for place, dv in enumerate(decompose_into_digits(rd(vi), log_bases)):
+                    w[first + place * len(values) + i] = dv
+        elif t == 11:
+            _, idx, sz, rs, addr, addr_w, value, timer, timer_w = b
+            w[idx] = (rd(sz) - (addr * rd(addr_w) + rd(rs) * rd(value) + rd(rs) * rd(rs) * timer * rd(timer_w))) % P
+        elif t == 12:
+            _, mem_len, init_start, ops, rv_start, rt_start, _first, _num = b
+            rv = w[init_start:init_start + mem_len]
+            rt = [0] * mem_len
+            for k, op in enumerate(ops):
+                a = rd(op[1]) & (2**64 - 1)
+                if a >= mem_len:
+                    raise SolverPanic("index out of bounds")
+                if op[0] == "load":
+                    _, _addr, value, ts = op
+                    w[ts] = rt[a]
+                    rv[a] = w[value]
+                else:
+                    _, _addr, old, new, ts = op
+                    w[old] = rv[a]
+                    w[ts] = rt[a]
+                    rv[a] = w[new]
+                rt[a] = k + 1
+            for i in range(mem_len):
+                w[rv_start + i] = rv[i]
+                w[rt_start + i] = rt[i]
+        elif t == 13:
+            _, idx, sz, rs, rs2, lhs, rhs, outp = b
+            w[idx] = (rd(sz) - (cow(lhs) + rd(rs) * cow(rhs) + rd(rs2) * cow(outp))) % P
+        elif t == 14:
+            _, start, operands = b
+            mult = [0] * (1 << (2 * BINOP_ATOMIC_BITS))
+            for lhs, rhs in operands:
+                i = ((cow(lhs) & (2**64 - 1)) << BINOP_ATOMIC_BITS) + (cow(rhs) & (2**64 - 1))
+                if i >= len(mult):
+                    raise SolverPanic("index out of bounds")
+                mult[i] += 1
+            for i, c in enumerate(mult):
+                w[start + i] = c
+        else:
+            raise ValueError(t)
+    return w

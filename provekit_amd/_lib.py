@@ -121,6 +121,10 @@ SIGNATURES = {
     "pk_commit": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, C.POINTER(vp)]),
     "pk_commit_sizes": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
     "pk_commit_into": (C.c_int, [vp, C.POINTER(vp), C.c_uint, C.c_uint, C.c_uint, C.c_uint, vp, vp, vp, vp, vp]),
+    "pk_witness_builders_from_postcard": (C.c_int, [vp, vp, sz, vp, vp, vp, vp]),
+    "pk_witness_builders_inspect": (C.c_int, [vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, sz]),
+    "pk_witness_solve": (C.c_int, [vp, vp, vp, sz, vp, sz, vp, sz, vp]),
+    "pk_witness_program_destroy": (C.c_int, [vp, vp]),
     "pk_comm_init_host": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "pk_shard_of_leaf": (C.c_int, [C.c_uint64, C.c_uint, vp, vp]),
     "pk_shard_interleave_digests": (C.c_int, [vp, sz, C.c_uint, vp]),

@@ -1,0 +1,71 @@
+"""CPU: the witness-builder oracle (oracle/witness_ref.py) against the reference's own unit tests of the digit helpers
+(provekit/prover/src/witness/digits.rs:88-113), and the postcard codec + levelling of the library on the host
+(pk_witness_builders_inspect: no device)."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import witness_ref as R  # noqa: E402
+
+
+def test_decompose_into_digits_reference_case():  # digits.rs:88-99
+    digits = R.decompose_into_digits(3 + 2 * 256 + 256 * 256, [8, 8, 4])
+    assert digits == [3, 2, 1]
+
+
+def test_field_to_le_bits_reference_case():  # digits.rs:101-111
+    bits = R.field_to_le_bits(5)
+    assert len(bits) == 256 and bits[0] and not bits[1] and bits[2] and not bits[254] and not bits[255]
+
+
+def test_le_bits_to_field_reference_case():  # digits.rs:113-119
+    assert R.le_bits_to_field([1, 0, 1, 0, 0]) == 5
+
+
+def test_higher_order_bits_panic():
+    with pytest.raises(R.SolverPanic, match="Higher order bits are not zero"):
+        R.decompose_into_digits(1 << 20, [8, 8, 4])
+
+
+def test_oracle_solves_a_random_program_and_leaves_unwritten_witnesses_none():
+    from witness_gen import random_program
+
+    builders, acir, ch, n = random_program(1, 300)
+    w = R.solve_witness_vec(builders, acir, ch, n)
+    assert w[0] == 1 and sum(x is None for x in w) >= 2
+    for b in builders:  # spot-check two variants against their definitions
+        if b[0] == 3:
+            assert w[b[1]] == w[b[2]] * w[b[3]] % R.P
+        if b[0] == 7:
+            assert w[b[1]] * w[b[2]] % R.P == 1
+
+
+def test_library_decodes_and_levels_the_postcard_list_on_the_host():
+    from witness_gen import random_program
+
+    from provekit_amd.witness import WitnessBuilder as WB
+    from provekit_amd.witness import encode_witness_builders, inspect_witness_builders
+
+    builders, acir, ch, n = random_program(2, 500)
+    data = encode_witness_builders(builders)
+    info = inspect_witness_builders(data)
+    assert info["n_builders"] == len(builders) and info["consumed"] == len(data)
+    assert info["n_challenges"] == len(ch) and info["n_acir"] == len(acir) and info["n_witnesses"] <= n
+    assert 2 <= info["n_levels"] < len(builders) and info["n_items"] > len(builders)
+    deep = inspect_witness_builders(encode_witness_builders(random_program(3, 400, chain=True, with_big=False)[0]))
+    assert deep["n_levels"] > 100  # a chain: almost every builder is its own level
+    # a list the reference would panic on: reading a witness no earlier builder solved
+    from provekit_amd import ProveKitHipError
+
+    with pytest.raises(ProveKitHipError, match="before it is solved"):
+        inspect_witness_builders(encode_witness_builders([WB.Constant(0, 1), WB.Product(2, 0, 1)]))
+    with pytest.raises(ProveKitHipError, match="written twice"):
+        inspect_witness_builders(encode_witness_builders([WB.Constant(0, 1), WB.Constant(0, 2)]))
+    with pytest.raises(ProveKitHipError, match="malformed"):
+        inspect_witness_builders(data[: len(data) // 2])
+    with pytest.raises(ProveKitHipError, match="malformed"):  # a field element >= p is not a canonical encoding
+        bad = bytearray(encode_witness_builders([WB.Constant(0, 5)]))
+        bad[-32:] = b"\xff" * 32
+        inspect_witness_builders(bytes(bad))
