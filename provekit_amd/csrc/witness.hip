@@ -297,6 +297,7 @@ struct Program {
 
 struct Parsed {  // a builder before levelling
     std::vector<u32> reads, writes;
+    std::vector<u32> copies;  // witnesses copied as Options, not unwrapped (Spice values): None is legal and stays None
     std::vector<WbItem> main, second;  // second = the phase after main (COUNT_OUT)
     int spice = -1;
 };
@@ -522,8 +523,8 @@ bool parse_builder(Reader& rd, Program& P, u32 bi, Parsed& b) {
                 } else {
                     return rd.ok = false;
                 }
-                b.reads.push_back(op.addr);
-                b.reads.push_back(op.value);
+                b.reads.push_back(op.addr);     // witness[*addr].unwrap()
+                b.copies.push_back(op.value);   // rv_final[addr] = witness[*value]: an Option, copied as it is
                 b.writes.push_back(op.out_ts);
                 sb.ops.push_back(op);
             }
@@ -533,7 +534,7 @@ bool parse_builder(Reader& rd, Program& P, u32 bi, Parsed& b) {
             (void)rd.index();  // num_witnesses
             if (!rd.ok) return false;
             for (u32 a = 0; a < sb.memory_length; a++) {
-                b.reads.push_back(sb.initial_start + a);
+                b.copies.push_back(sb.initial_start + a);
                 b.writes.push_back(sb.rv_start + a);
                 b.writes.push_back(sb.rt_start + a);
             }
@@ -587,6 +588,7 @@ bool build_program(const uint8_t* bytes, size_t len, Program& P, size_t* consume
     size_t nw = 0;
     for (auto& b : B) {
         for (u32 w : b.reads) nw = std::max<size_t>(nw, (size_t)w + 1);
+        for (u32 w : b.copies) nw = std::max<size_t>(nw, (size_t)w + 1);
         for (u32 w : b.writes) nw = std::max<size_t>(nw, (size_t)w + 1);
     }
     P.n_witnesses = nw;
@@ -594,12 +596,17 @@ bool build_program(const uint8_t* bytes, size_t len, Program& P, size_t* consume
     // the reference would unwrap (panic): refuse the list instead
     std::vector<int> producer(nw, -1);
     std::vector<u32> level(B.size(), 0);
+    std::vector<std::pair<u32, size_t>> copied_none;  // (witness, builder) copied while still None
     u32 max_level = 0;
     for (size_t i = 0; i < B.size(); i++) {
         u32 lv = 0;
         for (u32 w : B[i].reads) {
             if (producer[w] < 0) return P.error = "builder " + std::to_string(i) + " reads witness " + std::to_string(w) + " before it is solved", false;
             lv = std::max(lv, level[(size_t)producer[w]] + 1);
+        }
+        for (u32 w : B[i].copies) {
+            if (producer[w] < 0) copied_none.push_back({w, i});
+            else lv = std::max(lv, level[(size_t)producer[w]] + 1);
         }
         for (u32 w : B[i].writes) {
             if (producer[w] >= 0) return P.error = "witness " + std::to_string(w) + " is written twice (builders " + std::to_string(producer[w]) + ", " + std::to_string(i) + ")", false;
@@ -609,6 +616,13 @@ bool build_program(const uint8_t* bytes, size_t len, Program& P, size_t* consume
         max_level = std::max(max_level, lv);
         if (B[i].spice >= 0) P.spice[(size_t)B[i].spice].level = lv;
     }
+    // a None copied by a Spice block must still be None when the block runs here, whatever the level order: refuse the (contrived)
+    // list in which a LATER builder solves it
+    for (auto& cn : copied_none)
+        if (producer[cn.first] >= 0)
+            return P.error = "builder " + std::to_string(cn.second) + " copies witness " + std::to_string(cn.first) + " before builder " +
+                             std::to_string(producer[cn.first]) + " solves it",
+                   false;
     // phase = 2 * level (+1 for the second-phase items of multiplicity builders); counting sort of the items by phase
     const size_t n_phases = 2 * ((size_t)max_level + 1);
     std::vector<size_t> cnt(n_phases + 1, 0);
