@@ -450,6 +450,56 @@ pub struct HipNoirProofScheme<'a> {
     pub ctx: &'a HipContext,
 }
 
+/// R1CSSolver::solve_witness_vec (provekit/prover/src/r1cs.rs:29-40) on the device (INTEGRATION.md 4b'): the builder
+/// list goes over once as postcard, each proof sends the ACIR witness map (dense, indexed by ACIR witness index) and the
+/// challenges the transcript draws for the `Challenge` builders, and gets back the witness vector with its `Some` mask.
+pub struct HipWitnessBuilders<'a> {
+    ctx: &'a HipContext,
+    raw: *mut sys::pk_witness_program,
+    n_challenges: usize,
+    n_acir: usize,
+}
+impl<'a> HipWitnessBuilders<'a> {
+    pub fn new(ctx: &'a HipContext, builders: &[provekit_common::witness::WitnessBuilder]) -> Result<Self> {
+        let bytes = postcard::to_allocvec(builders).context("while serialising the witness builders")?;
+        let (mut raw, mut n_wit, mut n_challenges, mut n_acir) = (ptr::null_mut(), 0usize, 0usize, 0usize);
+        ctx.check(unsafe { sys::pk_witness_builders_from_postcard(ctx.raw, bytes.as_ptr(), bytes.len(), &mut raw, &mut n_wit, &mut n_challenges, &mut n_acir) })?;
+        Ok(Self { ctx, raw, n_challenges, n_acir })
+    }
+
+    pub fn solve_witness_vec(&self, acir: &WitnessMap<NoirElement>, num_witnesses: usize, transcript: &mut Merlin) -> Result<Vec<Option<FieldElement>>> {
+        let mut dense = vec![FieldElement::zero(); self.n_acir];
+        for (i, slot) in dense.iter_mut().enumerate() {
+            if let Some(v) = acir.get_index(i as u32) {
+                *slot = provekit_common::utils::noir_to_native(*v);
+            }
+        }
+        let mut challenges = vec![FieldElement::zero(); self.n_challenges];
+        if !challenges.is_empty() {
+            transcript.fill_challenge_scalars(&mut challenges)?; // the builders' Challenge entries, in list order
+        }
+        let (d_acir, d_wit) = (DevVec::from_host(self.ctx, &dense)?, DevVec::zeroed(self.ctx, num_witnesses)?);
+        let mut d_set = ptr::null_mut();
+        self.ctx.check(unsafe { sys::pk_malloc(self.ctx.raw, num_witnesses.max(1), &mut d_set) })?;
+        let rc = unsafe {
+            sys::pk_witness_solve(self.ctx.raw, self.raw, d_acir.ptr, dense.len(), challenges.as_ptr().cast(), challenges.len(), d_wit.ptr, num_witnesses, d_set.cast())
+        };
+        let (mut w, mut set) = (vec![FieldElement::zero(); num_witnesses], vec![0u8; num_witnesses]);
+        let copied = self.ctx.check(rc).and_then(|_| {
+            self.ctx.check(unsafe { sys::pk_memcpy_d2h(self.ctx.raw, w.as_mut_ptr().cast(), d_wit.ptr.cast(), 32 * num_witnesses) })?;
+            self.ctx.check(unsafe { sys::pk_memcpy_d2h(self.ctx.raw, set.as_mut_ptr().cast(), d_set, num_witnesses) })
+        });
+        unsafe { sys::pk_free(self.ctx.raw, d_set) };
+        copied?;
+        Ok(w.into_iter().zip(set).map(|(x, s)| (s != 0).then_some(x)).collect())
+    }
+}
+impl Drop for HipWitnessBuilders<'_> {
+    fn drop(&mut self) {
+        unsafe { sys::pk_witness_program_destroy(self.ctx.raw, self.raw) };
+    }
+}
+
 impl NoirProofSchemeProver for HipNoirProofScheme<'_> {
     fn generate_witness(&self, input_map: &InputMap) -> Result<WitnessMap<NoirElement>> {
         self.scheme.generate_witness(input_map) // ACVM execution: host, unchanged
