@@ -527,6 +527,10 @@ int get_twiddles29(pk_ctx* ctx, unsigned log_n, int which, const fe* W, const u3
     return PK_OK;
 }
 
+// Pass-ordered tables pay where the size-N operand table no longer fits the caches (36 B x 2^20 = 36 MiB > the 32 MiB of L2): there
+// the strided gathers cost 2.6x the data traffic of a pass.  Below that both tables are cache-resident and the gathers are free;
+// measured at the proof's 2^18 the re-ordered table + XCD order ran the strided passes 3-8 % slower, so small sizes keep the gather.
+constexpr unsigned PASS_TABLE_MIN_LOG_N = 20;
 // the pass-ordered table of one (size, pass, variant): key = log_n | pass << 8 | scaled << 12
 int get_pass_table(pk_ctx* ctx, unsigned log_n, unsigned pass, bool scaled, const u32* src29, size_t rows_k, size_t row, size_t mul, const u32** out) {
     const unsigned key = log_n | (pass << 8) | ((scaled ? 1u : 0u) << 12);
@@ -559,7 +563,7 @@ int launch_pass_r(pk_ctx* ctx, const PassParams& p, bool in_r_contig, size_t til
         PassParams pp = p;
         pp.tiles = tiles8;
         pp.ncols = ncols;
-        pp.xcd_tiles = (tiles8 % 8 == 0) ? 1 : 0;
+        pp.xcd_tiles = (p.Tpass29 != nullptr && tiles8 % 8 == 0) ? 1 : 0;  // the XCD order exists to share the pass table's rows
         PK_REQUIRE(ctx, tiles8 * ncols < ((size_t)1 << 31), "NTT launch too large");
         dim3 grid((unsigned)(tiles8 * ncols), 1);
         // the 72 KiB dynamic-LDS opt-in is a per-function, per-device attribute: set it once per device, not per launch
@@ -727,7 +731,7 @@ int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero,
         p.Wtw29 = Ws29;
         p.lazy_store = pass_is_fast(l2, l1, N);  // the register-radix kernel takes almost reduced inputs
         p.wr_step = N >> l1;
-        if (pass_is_fast(l1, l2, N) && (rc = get_pass_table(ctx, log_n, 1, scaled_out, Ws29, R1, R2, 1, &p.Tpass29))) return rc;
+        if (log_n >= PASS_TABLE_MIN_LOG_N && pass_is_fast(l1, l2, N) && (rc = get_pass_table(ctx, log_n, 1, scaled_out, Ws29, R1, R2, 1, &p.Tpass29))) return rc;
         p.tp_row = R2;
         rc = launch_pass(ctx, l1, p, false, R2 / BT, ncols);
         if (rc) return rc;
@@ -765,7 +769,7 @@ int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero,
     p.tw_mul = 1;
     p.lazy_store = pass_is_fast(l2, l3, N);
     p.wr_step = N >> l1;
-    if (pass_is_fast(l1, l2 + l3, N) && (rc = get_pass_table(ctx, log_n, 1, false, W29, R1, R2 * R3, 1, &p.Tpass29))) return rc;
+    if (log_n >= PASS_TABLE_MIN_LOG_N && pass_is_fast(l1, l2 + l3, N) && (rc = get_pass_table(ctx, log_n, 1, false, W29, R1, R2 * R3, 1, &p.Tpass29))) return rc;
     p.tp_row = R2 * R3;
     rc = launch_pass(ctx, l1, p, false, (R2 * R3) / BT, ncols);
     if (rc) return rc;
@@ -785,7 +789,7 @@ int ntt_columns(pk_ctx* ctx, const fe* in, size_t in_col_stride, size_t nonzero,
     p.Wtw29 = Ws29;
     p.lazy_store = pass_is_fast(l3, l1, N);
     p.wr_step = N >> l2;
-    if (pass_is_fast(l2, l3, N) && (rc = get_pass_table(ctx, log_n, 2, scaled_out, Ws29, R2, R3, R1, &p.Tpass29))) return rc;
+    if (log_n >= PASS_TABLE_MIN_LOG_N && pass_is_fast(l2, l3, N) && (rc = get_pass_table(ctx, log_n, 2, scaled_out, Ws29, R2, R3, R1, &p.Tpass29))) return rc;
     p.tp_row = R3;
     rc = launch_pass(ctx, l2, p, false, R1 * (R3 / BT), ncols);
     if (rc) return rc;
