@@ -454,6 +454,13 @@ int pk_selftest_modmul_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, 
  * reduced (< 2^257).  Host: under fesetround(FE_TOWARDZERO); device: MODE.FP_ROUND set by the kernel; _rate_fp52: the same
  * probe as pk_selftest_modmul_rate for this multiplier, so the two can be compared on one box. */
 int pk_selftest_fp52_sqr(const uint64_t *a, uint64_t *out5, size_t n);
+/* PROTOTYPE probe, not on the product path: the wavefront-cooperative Skyscraper square round (limbs in lanes 0..8, v_readlane
+ * broadcasts, DPP window shift) next to the lone lane's round (skyscraper29s.hpp sky_sq_round_s), `iters` rounds each on one
+ * wavefront of an idle GPU: out[36] = coop l, coop r, lane l, lane r (9 x 29-bit limbs each); cycles[0..1] = s_memtime ticks of the
+ * two loops inside one launch, cycles[2..3] = nanoseconds of each loop in a launch of its own (hipEvents).  north_star's
+ * "one-wavefront-per-node Skyscraper rounds", measured. */
+int pk_selftest_coop_round(pk_ctx *ctx, const uint32_t l[9], const uint32_t r[9], unsigned iters, uint32_t out[36],
+                           uint64_t cycles[4]);
 int pk_selftest_fp52_sqr_device(pk_ctx *ctx, const uint64_t *d_a, uint64_t *d_out5, size_t n);
 int pk_selftest_modmul_rate_fp52(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double *modmul_per_s);
 

@@ -150,6 +150,7 @@ SIGNATURES = {
     "pk_selftest_random_fe": (C.c_int, [vp, vp, C.c_uint32, vp, sz]),
     "pk_selftest_arith_device": (C.c_int, [vp, C.c_int, vp, vp, vp, sz]),
     "pk_selftest_modmul_rate": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),
+    "pk_selftest_coop_round": (C.c_int, [vp, vp, vp, C.c_uint, vp, vp]),
     "pk_selftest_fp52_sqr": (C.c_int, [vp, vp, sz]),
     "pk_selftest_fp52_sqr_device": (C.c_int, [vp, vp, vp, sz]),
     "pk_selftest_modmul_rate_fp52": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),

@@ -136,7 +136,127 @@ __global__ __launch_bounds__(256) void modmul_rate_fp52_kernel(const fe* __restr
     if (acc == 0xffffffffffffffffull) out[i] = acc;  // never true (limbs < 2^52); keeps the chains live
 }
 
+// ---- wavefront-cooperative square round, PROTOTYPE (DESIGN.md 4 "Work mapping of the hash") ----------------
+// One node per wavefront: lane j < 9 holds limb j of the scaled state (l, r).  Operand scanning with the accumulator window
+// shifted one lane per Montgomery step: after step i lane j holds column i + 1 + j.  Broadcasts of l_i and m_i go through an SGPR
+// (v_readlane), the window shift is a DPP row_shl.  Same function as sky_sq_round_s<0> (skyscraper29s.hpp): the results agree as
+// integers mod p and in their limb bounds; limbs are carried in three parallel passes instead of a ripple, so individual limbs
+// may differ by a carry.  Timed with s_memtime against the lone lane running the same number of rounds.
+__device__ __forceinline__ u32 coop_shl1(u32 x) {  // lane j <- lane j + 1 within the row of 16; the row's last lane gets 0
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x101, 0xf, 0xf, true);
+}
+__device__ __forceinline__ u32 coop_shr1(u32 x) {  // lane j <- lane j - 1; lane 0 gets 0
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+}
+__device__ __forceinline__ void coop_sq_round(u32& L, u32& R, u32 Pj, u32 RCj, u32 lane0_mask, bool is_top) {
+    u64 A = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const u32 s = (u32)__builtin_amdgcn_readlane((int)L, i);
+        A += (u64)L * s;                                   // l_j * l_i -> column i + j, held by lane j
+        const u32 mloc = ((u32)A * NP29) & M29;
+        const u32 m = (u32)__builtin_amdgcn_readlane((int)mloc, 0);
+        A += (u64)m * Pj;                                  // column i is now a multiple of 2^29
+        const u64 c = A >> 29;
+        const u32 clo = (u32)__builtin_amdgcn_readlane((int)(u32)c, 0), chi = (u32)__builtin_amdgcn_readlane((int)(u32)(c >> 32), 0);
+        A = (u64)coop_shl1((u32)A) | ((u64)coop_shl1((u32)(A >> 32)) << 32);  // window moves up one column
+        A += (u64)(clo & lane0_mask) | ((u64)(chi & lane0_mask) << 32);        // carry of the finished column into the new lane 0
+    }
+    // lanes 0..7: columns 9..16; add r + 32 rc in place (lane 8's share, the top limb, is added after the carries)
+    const u32 q = R + RCj;
+    A += is_top ? 0u : q;
+    // carries, three parallel passes (a carry is < 2^35, then < 2^7, then <= 1)
+    u32 lo = (u32)A & M29;
+    u64 c1 = A >> 29;
+    u64 t = (u64)lo + ((u64)coop_shr1((u32)c1) | ((u64)coop_shr1((u32)(c1 >> 32)) << 32));
+    u32 lo2 = (u32)t & M29, c2 = (u32)(t >> 29);
+    u32 t2 = lo2 + coop_shr1(c2);
+    u32 lo3 = t2 & M29, c3 = t2 >> 29;
+    const u32 cin3 = coop_shr1(c3);
+    u32 sres = lo3 + cin3;
+    // lane 8: every carry out of column 16 (one per pass, unmasked: the top limb holds the rest) plus the top limb of r + 32 rc
+    const u32 top8 = (u32)t + coop_shr1(c2) + cin3 + q;
+    sres = is_top ? top8 : sres;
+    R = L;
+    L = sres;
+}
+__global__ void coop_round_kernel(const u32* __restrict__ in_l, const u32* __restrict__ in_r, unsigned iters, u32* __restrict__ out,
+                                  unsigned long long* __restrict__ cycles, int mode) {
+    const unsigned lane = threadIdx.x;
+    u32 L = lane < 9 ? in_l[lane] : 0u, R = lane < 9 ? in_r[lane] : 0u;
+    const u32 Pj = lane < 9 ? p29((int)(lane < 9 ? lane : 0)) : 0u;
+    u32 RCj = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) RCj = lane == (unsigned)k ? rcs29<0>(k) : RCj;
+    const u32 lane0_mask = lane == 0 ? 0xffffffffu : 0u;
+    const bool is_top = lane == 8;
+    unsigned long long t0 = __builtin_readcyclecounter();
+    if (mode != 2)
+        for (unsigned it = 0; it < iters; it++) coop_sq_round(L, R, Pj, RCj, lane0_mask, is_top);
+    unsigned long long t1 = __builtin_readcyclecounter();
+    if (lane < 9) {
+        out[lane] = L;
+        out[9 + lane] = R;
+    }
+    // the lone lane: the product path's own round, same count
+    // (indexed through the lane id so that the compiler cannot prove the values wave-uniform and move the whole round to the
+    // scalar ALU: the product's lanes hold different nodes)
+    fe29 l, r;
+    const unsigned off = (lane >> 6) * 32;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        l.v[k] = in_l[k + off];
+        r.v[k] = in_r[k + off];
+    }
+    unsigned long long t2 = __builtin_readcyclecounter();
+    if (mode != 1)
+        for (unsigned it = 0; it < iters; it++) sky_sq_round_s<0>(l, r);
+    unsigned long long t3 = __builtin_readcyclecounter();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            out[18 + k] = l.v[k];
+            out[27 + k] = r.v[k];
+        }
+        cycles[0] = t1 - t0;
+        cycles[1] = t3 - t2;
+    }
+}
+
 extern "C" {
+
+// PROTOTYPE probe: `iters` square rounds (round constant 0) of the scaled Skyscraper state (l, r: 9 limbs of 29 bits each) by the
+// wavefront-cooperative round and by the lone lane, one wavefront on an idle GPU.  out: 36 words = coop l, coop r, lane l, lane r;
+// cycles: s_memtime ticks of the two loops.
+int pk_selftest_coop_round(pk_ctx* ctx, const uint32_t l[9], const uint32_t r[9], unsigned iters, uint32_t out[36], uint64_t cycles[4]) {
+    if (!ctx || !l || !r || !out || !cycles) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
+    int rc = ensure_scratch(ctx, 4096);
+    if (rc) return rc;
+    u32* d = (u32*)ctx->d_scratch;
+    PK_HIP(ctx, hipMemcpyAsync(d, l, 36, hipMemcpyHostToDevice, ctx->stream));
+    PK_HIP(ctx, hipMemcpyAsync(d + 16, r, 36, hipMemcpyHostToDevice, ctx->stream));
+    coop_round_kernel<<<1, 64, 0, ctx->stream>>>(d, d + 16, iters, d + 64, (unsigned long long*)(d + 128), 0);
+    PK_LAUNCH_CHECK(ctx);
+    PK_HIP(ctx, hipMemcpyAsync(out, d + 64, 144, hipMemcpyDeviceToHost, ctx->stream));
+    PK_HIP(ctx, hipMemcpyAsync(cycles, d + 128, 16, hipMemcpyDeviceToHost, ctx->stream));
+    rc = sync_stream(ctx);
+    if (rc) return rc;
+    // the same two loops timed from outside (hipEvents), each in its own launch: nanoseconds per round in cycles[2], cycles[3]
+    // (PK_COOP_GRID: the same single-wavefront workgroup replicated over the chip -- every copy writes the same words -- to see
+    // what the clock does when the GPU is not idle around the measured wavefront)
+    const char* ge = getenv("PK_COOP_GRID");
+    const unsigned grid = ge ? (unsigned)atoi(ge) : 1u;
+    for (int mode = 1; mode <= 2; mode++) {
+        float ms = 0;
+        if ((rc = pk_timer_start(ctx))) return rc;
+        coop_round_kernel<<<grid ? grid : 1u, 64, 0, ctx->stream>>>(d, d + 16, iters, d + 256, (unsigned long long*)(d + 384), mode);
+        PK_LAUNCH_CHECK(ctx);
+        if ((rc = pk_timer_stop(ctx, &ms))) return rc;
+        cycles[1 + mode] = (uint64_t)(1e6 * (double)ms);  // ns for `iters` rounds (plus one launch)
+    }
+    return PK_OK;
+}
 
 // x (n field elements, 4 x u64, any value < 2^256) -> the five 52-bit limbs of sqr260_52(x) = x^2 * 2^-260 mod p, lazily reduced
 // (value < 2^257).  Host execution of the shared code under fesetround(FE_TOWARDZERO).

@@ -46,3 +46,27 @@ def test_fp52_prototype_device_equals_host_and_definition(ctx):
     ctx._check(lib.pk_memcpy_d2h(ctx.handle, dev.ctypes.data, do.ptr, dev.nbytes))
     assert np.array_equal(dev, host)
     check_fp52(vals[:5000], dev)
+
+
+def test_cooperative_square_round_prototype_matches_the_lane(ctx):
+    """north_star's "one-wavefront-per-node Skyscraper rounds" as a prototype (csrc/selftest.hip coop_sq_round: limbs in lanes,
+    v_readlane broadcasts, DPP window shift) against the product's lone-lane round: equal mod p over the round counts a compression
+    runs between reductions, limbs within the bounds the next round needs.  (Its speed is measured by tools/coop_round.py:
+    profiles/r03_coop_round.json, DESIGN.md 4 -- slower than the lane.)"""
+    import ctypes as C
+    import random
+
+    from provekit_amd._lib import lib
+
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    limbs = lambda v: [(v >> (29 * k)) & ((1 << 29) - 1) if k < 8 else v >> 232 for k in range(9)]
+    value = lambda ls: sum(int(x) << (29 * k) for k, x in enumerate(ls))
+    rnd = random.Random(9)
+    for v in [(0, 0), (1, 0), (P - 1, P - 1), ((1 << 254) - 1, 5)] + [(rnd.randrange(P), rnd.randrange(P)) for _ in range(12)]:
+        L, R = (C.c_uint32 * 9)(*limbs(v[0])), (C.c_uint32 * 9)(*limbs(v[1]))
+        out, cyc = (C.c_uint32 * 36)(), (C.c_uint64 * 4)()
+        for n in (1, 2, 3, 6):
+            ctx._check(lib.pk_selftest_coop_round(ctx.handle, L, R, n, out, cyc))
+            o = list(out)
+            assert value(o[0:9]) % P == value(o[18:27]) % P and value(o[9:18]) % P == value(o[27:36]) % P, (v, n)
+            assert max(o[0:8]) <= 1 << 29
