@@ -390,6 +390,8 @@ bool parse_builder(Reader& rd, Program& P, u32 bi, Parsed& b) {
             const u32 start = rd.index(), range = rd.index();
             const uint64_t n = rd.varint();
             if (!rd.ok || n > rd.n - rd.off) return rd.ok = false;
+            // the table is expanded to one work item per entry: an absurd size from untrusted bytes must not drive host allocations
+            if (range > (1u << 26) || P.n_counts + range > (1ull << 28)) return rd.ok = false;
             const u32 base = (u32)P.n_counts;
             P.n_counts += range;
             for (uint64_t i = 0; i < n; i++) {
@@ -504,6 +506,7 @@ bool parse_builder(Reader& rd, Program& P, u32 bi, Parsed& b) {
             sb.builder = bi;
             sb.memory_length = rd.index();
             sb.initial_start = rd.index();
+            if (sb.memory_length > (1u << 28)) return rd.ok = false;  // three reads / writes per cell are recorded below
             const uint64_t n = rd.varint();
             if (!rd.ok || n > rd.n - rd.off) return rd.ok = false;
             for (uint64_t i = 0; i < n; i++) {
@@ -555,6 +558,7 @@ bool parse_builder(Reader& rd, Program& P, u32 bi, Parsed& b) {
             const u32 start = rd.index();
             const uint64_t n = rd.varint();
             if (!rd.ok || n > rd.n - rd.off) return rd.ok = false;
+            if (P.n_counts + 65536 > (1ull << 28)) return rd.ok = false;
             const u32 base = (u32)P.n_counts;
             P.n_counts += 65536;  // 2^(2 * BINOP_ATOMIC_BITS)
             for (uint64_t i = 0; i < n; i++) {
