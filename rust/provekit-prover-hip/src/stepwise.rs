@@ -15,7 +15,7 @@
 //! | `run_zk_whir_pcs_prover` -> `whir::Prover::prove` | [`StepProver::whir_prove`]             |
 //! | `compute_blinding_coefficients_for_round` & co    | used from the reference (host scalars) |
 //!
-//! The first four are in-tree in the reference and are followed line for line.  `whir::Prover::prove` and
+//! The first four are in-tree in the reference and are followed step by step.  `whir::Prover::prove` and
 //! `CommitmentWriter::commit_batch` are NOT (external crate `whir` @3e7f8c2): a GPU commit cannot be handed to whir's prover,
 //! whose `Witness` wants an `ark_crypto_primitives::MerkleTree` on the host, so their transcript interactions are restated
 //! here in the order the in-tree Go verifier consumes them (recursive-verifier/app/circuit/whir.go:51-220, mtUtilities.go:51-76)
@@ -161,7 +161,7 @@ impl<'a> StepProver<'a> {
         })
     }
 
-    /// run_zk_sumcheck_prover (whir_r1cs.rs:228-369), line for line; returns alpha.
+    /// run_zk_sumcheck_prover (whir_r1cs.rs:228-369), step by step; returns alpha.
     fn zk_sumcheck(&self, d_z: &DevVec, merlin: &mut Merlin) -> Result<Vec<FieldElement>> {
         let (m_0, ctx) = (self.scheme.m_0, self.ctx);
         let mut r = vec![FieldElement::zero(); m_0];
