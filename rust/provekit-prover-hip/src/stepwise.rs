@@ -40,7 +40,7 @@ use {
     },
     spongefish_pow::PoWChallenge,
     std::ptr,
-    whir::whir::utils::{get_challenge_stir_queries, DigestToUnitSerialize},
+    whir::whir::utils::{get_challenge_stir_queries, DigestToUnitSerialize, HintSerialize},
 };
 
 type Merlin = ProverState<SkyscraperSponge, FieldElement>;
