@@ -172,6 +172,8 @@ void comm_turn_begin(pk_ctx* ctx);  // measurement aid of the in-process transpo
 void comm_turn_end(pk_ctx* ctx);
 void comm_abort(pk_ctx* ctx);  // wake the ranks waiting in a collective this rank will never reach (in-process transport)
 void comm_release(pk_ctx* ctx);
+int eval_univariate_multi(pk_ctx* ctx, const uint64_t* const* d_polys, unsigned np, size_t n, const uint64_t z[4], uint64_t* out);  // mle.hip
+int dot_rows(pk_ctx* ctx, const uint64_t* d_w, size_t row_stride, unsigned nrows, const uint64_t* d_f, const uint64_t* d_g, size_t n, uint64_t* out);
 int pow_solve_x(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t* nonce, bool striped);  // pow.hip
 void ntt_release_ctx(pk_ctx* ctx);  // ntt.hip: frees the per-context twiddle tables
 

@@ -453,25 +453,58 @@ __global__ __launch_bounds__(RED_THREADS) void dot_kernel(const fe* __restrict__
     grid_finish_fe<NV>(acc, smem, partials, ticket, result, seq);
 }
 
+// NR weight rows (row k at w + k * row_stride) against f (and g): <w_k, f>, <w_k, g> for every k in ONE pass over f and g -- the
+// three statement weights of whir_r1cs.rs:382-412 share their polynomials, so this is one launch and one round trip instead of three
+template <int NR, int NV>
+__global__ __launch_bounds__(RED_THREADS) void dot_rows_kernel(const fe* __restrict__ w, size_t row_stride, const fe* __restrict__ f,
+                                                               const fe* __restrict__ g, size_t n, fe* __restrict__ partials,
+                                                               unsigned* __restrict__ ticket, fe* __restrict__ result, unsigned seq) {
+    PK_LATENCY_PRIO();
+    __shared__ uint4 smem[NR * NV * 16];
+    fe acc[NR * NV];
+#pragma unroll
+    for (int k = 0; k < NR * NV; k++) acc[k] = fe_zero();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const fe fi = fe_load(f + i);
+        fe gi = fi;
+        if (NV == 2) gi = fe_load(g + i);
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const fe wi = fe_load(w + (size_t)k * row_stride + i);
+            acc[NV * k] = fe_add(acc[NV * k], fe_mulx(wi, fi));
+            if (NV == 2) acc[NV * k + 1] = fe_add(acc[NV * k + 1], fe_mulx(wi, gi));
+        }
+    }
+    grid_finish_fe<NR * NV>(acc, smem, partials, ticket, result, seq);
+}
+
 // ---------------------------------------------------------------- E1: univariate evaluation
 // sum_i c[i] z^i with T = gridDim*blockDim lanes: lane g Horner-evaluates the stride-T subsequence c[g], c[g+T], ...
 // in z^T (so every load is coalesced across the wave), scales by z^g and the grid reduces.
 struct pow2_args {
     fe_arg p[18];  // z^(2^i)
 };
-__global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restrict__ c, size_t n, pow2_args zp, fe_arg zT_arg,
+// NP polynomials of the same length at the same point in one launch (a batch commitment's OOD answers, mtUtilities.go:51-76)
+template <int NP>
+__global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restrict__ c, const fe* __restrict__ c_second, size_t n, pow2_args zp, fe_arg zT_arg,
                                                              fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                              fe* __restrict__ result, unsigned seq) {
     PK_LATENCY_PRIO();
-    __shared__ uint4 smem[16];
+    __shared__ uint4 smem[NP * 16];
     const fe zT = from_arg(zT_arg);
     const size_t T = (size_t)gridDim.x * blockDim.x;
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    fe acc[1] = {fe_zero()};
+    fe acc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; q++) acc[q] = fe_zero();
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+    const fe* cq = q == 0 ? c : c_second;
     if (g < n) {
         size_t cnt = (n - g + T - 1) / T;  // elements g, g+T, ..., g+(cnt-1)T
-        fe h = fe_load(c + g + (cnt - 1) * T);
-        for (size_t j = cnt - 1; j-- > 0;) h = fe_add(fe_mulx(h, zT), fe_load(c + g + j * T));
+        fe h = fe_load(cq + g + (cnt - 1) * T);
+        for (size_t j = cnt - 1; j-- > 0;) h = fe_add(fe_mulx(h, zT), fe_load(cq + g + j * T));
         // z^g from the host's table of z^(2^i): the 8 lane bits by select, the block bits under a uniform branch
         // (g < 2^18: at most 1024 blocks of 256 lanes)
 #pragma unroll
@@ -483,9 +516,10 @@ __global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restric
         }
         for (int i = 8; i < 18; i++)
             if ((blockIdx.x >> (i - 8)) & 1u) h = fe_mulx(h, from_arg(zp.p[i]));
-        acc[0] = h;
+        acc[q] = h;
     }
-    grid_finish_fe<1>(acc, smem, partials, ticket, result, seq);
+    }
+    grid_finish_fe<NP>(acc, smem, partials, ticket, result, seq);
 }
 
 // ---------------------------------------------------------------- W1: coefficient fold
@@ -771,8 +805,20 @@ int pk_dot2(pk_ctx* ctx, const uint64_t* d_w, const uint64_t* d_f, const uint64_
 int pk_eval_univariate(pk_ctx* ctx, const uint64_t* d_coeffs, size_t n, const uint64_t z[4], uint64_t out[4]) {
     PK_ENTER(ctx);
     PK_REQUIRE(ctx, out && z && (n == 0 || d_coeffs), "null pointer");
+    const uint64_t* polys[1] = {d_coeffs};
+    return pk::eval_univariate_multi(ctx, polys, 1, n, z, out);
+}
+}  // extern "C"
+namespace pk {
+// np (1 or 2) polynomials of n coefficients each at the same z, one launch: out[4 * q] = poly_q(z)
+int eval_univariate_multi(pk_ctx* ctx, const uint64_t* const* d_polys, unsigned np, size_t n, const uint64_t z[4], uint64_t* out) {
+    PK_REQUIRE(ctx, np == 1 || np == 2, "one or two polynomials");
     if (n == 0) {
-        memset(out, 0, 32);
+        if (ctx->red_across) {
+            PK_HIP(ctx, hipMemsetAsync(ctx->d_xred, 0, 32 * np, ctx->stream));
+            return np == 1 ? collect_reduction<1>(ctx, out) : collect_reduction<2>(ctx, out);
+        }
+        memset(out, 0, 32 * np);
         return PK_OK;
     }
     int rc = reduction_scratch(ctx);
@@ -801,11 +847,45 @@ int pk_eval_univariate(pk_ctx* ctx, const uint64_t* d_coeffs, size_t n, const ui
     memcpy(zTa.v, zT.v, 32);
     {
         ProfScope prof(ctx, "eval_univariate");
-        horner_kernel<<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_coeffs, n, zp, zTa, red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
+        if (np == 1)
+            horner_kernel<1><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_polys[0], nullptr, n, zp, zTa, red_partials(ctx), red_ticket(ctx),
+                                                                     red_result(ctx), next_seq(ctx));
+        else
+            horner_kernel<2><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_polys[0], (const fe*)d_polys[1], n, zp, zTa, red_partials(ctx),
+                                                                     red_ticket(ctx), red_result(ctx), next_seq(ctx));
     }
     PK_LAUNCH_CHECK(ctx);
-    return collect_reduction<1>(ctx, out);
+    return np == 1 ? collect_reduction<1>(ctx, out) : collect_reduction<2>(ctx, out);
 }
+// nrows (1..3) weight rows against f and (nv == 2) g in one pass: out[4 * (nv * k + v)]
+int dot_rows(pk_ctx* ctx, const uint64_t* d_w, size_t row_stride, unsigned nrows, const uint64_t* d_f, const uint64_t* d_g, size_t n, uint64_t* out) {
+    const int nv = d_g ? 2 : 1;
+    PK_REQUIRE(ctx, nrows == 3 && out && (n == 0 || (d_w && d_f)), "three weight rows");
+    if (n == 0) {
+        if (ctx->red_across) {
+            PK_HIP(ctx, hipMemsetAsync(ctx->d_xred, 0, 32 * 3 * nv, ctx->stream));
+            return nv == 2 ? collect_reduction<6>(ctx, out) : collect_reduction<3>(ctx, out);
+        }
+        memset(out, 0, 32 * 3 * (size_t)nv);
+        return PK_OK;
+    }
+    int rc = reduction_scratch(ctx);
+    if (rc) return rc;
+    unsigned blocks = reduction_blocks(ctx, n);
+    {
+        ProfScope prof(ctx, "dot");
+        if (nv == 2)
+            dot_rows_kernel<3, 2><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_w, row_stride, (const fe*)d_f, (const fe*)d_g, n, red_partials(ctx),
+                                                                          red_ticket(ctx), red_result(ctx), next_seq(ctx));
+        else
+            dot_rows_kernel<3, 1><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_w, row_stride, (const fe*)d_f, nullptr, n, red_partials(ctx),
+                                                                          red_ticket(ctx), red_result(ctx), next_seq(ctx));
+    }
+    PK_LAUNCH_CHECK(ctx);
+    return nv == 2 ? collect_reduction<6>(ctx, out) : collect_reduction<3>(ctx, out);
+}
+}  // namespace pk
+extern "C" {
 
 int pk_fold_coeffs(pk_ctx* ctx, const uint64_t* d_coeffs, unsigned n_vars, const uint64_t* r, unsigned k, uint64_t* d_out) {
     PK_ENTER(ctx);

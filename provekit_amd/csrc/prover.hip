@@ -208,25 +208,29 @@ int gather_strided(pk_ctx* ctx, const fe* local, size_t len, fe* tmp, fe* full) 
 }
 // sum_i c[i] z^i, split into the ranks' blocks when the polynomial is long: rank r evaluates its block in z and the ranks'
 // values are combined as sum_r z^(r*B) * partial_r
-int eval_univariate_x(pk_ctx* ctx, const fe* d_poly, size_t n, const fe& z, fe& out) {
+int eval_univariate_multi_x(pk_ctx* ctx, const fe* const* d_polys, unsigned np, size_t n, const fe& z, fe* out) {
     const unsigned G = (unsigned)comm_world(ctx);
-    uint64_t zz[4], o[4];
+    uint64_t zz[4], o[8];
     h_store(zz, z);
+    const uint64_t* ptrs[2] = {nullptr, nullptr};
     if (G > 1 && n / G >= 4 * SHARD_MIN_LOCAL) {
         const size_t B = n / G;
         fe scales[PK_MAX_RANKS];
         const fe zB = h_pow(z, B);
         scales[0] = fe_one();
         for (unsigned r = 1; r < G; r++) scales[r] = h_mul(scales[r - 1], zB);
+        for (unsigned q = 0; q < np; q++) ptrs[q] = U(d_polys[q] + (size_t)comm_rank(ctx) * B);
         Across ac(ctx, true, scales);
         CK(ac.rc);
-        CK(pk_eval_univariate(ctx, U(d_poly + (size_t)comm_rank(ctx) * B), B, zz, o));
+        CK(eval_univariate_multi(ctx, ptrs, np, B, zz, o));
     } else {
-        CK(pk_eval_univariate(ctx, U(d_poly), n, zz, o));
+        for (unsigned q = 0; q < np; q++) ptrs[q] = U(d_polys[q]);
+        CK(eval_univariate_multi(ctx, ptrs, np, n, zz, o));
     }
-    out = h_load(o);
+    for (unsigned q = 0; q < np; q++) out[q] = h_load(o + 4 * q);
     return PK_OK;
 }
+int eval_univariate_x(pk_ctx* ctx, const fe* d_poly, size_t n, const fe& z, fe& out) { return eval_univariate_multi_x(ctx, &d_poly, 1, n, z, &out); }
 
 // ------------------------------------------------------------------ S6: blinding algebra (host, O(m_0^2))
 fe eval_cubic(const fe c[4], const fe& x) {  // provekit/common/src/utils/sumcheck.rs:174-176
@@ -355,9 +359,15 @@ int whir_commit(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, fe* const* pol
     C.ood_points.resize(cfg.commitment_ood_samples);
     T.challenge_scalars(C.ood_points.data(), C.ood_points.size());
     C.ood_answers.resize((size_t)batch * C.ood_points.size());
-    for (unsigned b = 0; b < batch; b++)
-        for (size_t j = 0; j < C.ood_points.size(); j++)
-            CK(eval_univariate_x(ctx, polys[b], (size_t)1 << cfg.n_vars, C.ood_points[j], C.ood_answers[b * C.ood_points.size() + j]));
+    for (size_t j = 0; j < C.ood_points.size(); j++) {
+        // the polynomials of a batch are evaluated at the same point: two per launch (and per host round trip)
+        for (unsigned b = 0; b < batch; b += 2) {
+            const unsigned np = batch - b >= 2 ? 2 : 1;
+            fe ans[2];
+            CK(eval_univariate_multi_x(ctx, polys + b, np, (size_t)1 << cfg.n_vars, C.ood_points[j], ans));
+            for (unsigned q = 0; q < np; q++) C.ood_answers[(b + q) * C.ood_points.size() + j] = ans[q];
+        }
+    }
     for (unsigned b = 0; b < batch; b++) T.add_scalars(&C.ood_answers[b * C.ood_points.size()], C.ood_points.size());
     C.beta = T.challenge_scalar();
     return PK_OK;
@@ -634,11 +644,21 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
         for (int i = 0; i < 8; i++) buf.push_back((uint8_t)(cnt >> (8 * i)));
         Across ac(ctx, sh);
         CK(ac.rc);
+        uint64_t outs[4 * 8] = {};
+        const bool rows3 = n_weights == 3 && weight_len[0] == weight_len[1] && weight_len[1] == weight_len[2] && d_weights[1] > d_weights[0] &&
+                           d_weights[1] - d_weights[0] == d_weights[2] - d_weights[1];
+        if (rows3) {  // the three external rows against the eq table in one pass
+            const size_t hi = weight_len[0] < off0 + B0 ? weight_len[0] : off0 + B0;
+            if (sh || weight_len[0])
+                CK(dot_rows(ctx, U(d_weights[0] + off0), (size_t)(d_weights[1] - d_weights[0]), 3, U(d_eq), nullptr, hi > off0 ? hi - off0 : 0, outs));
+        }
         for (unsigned i = 0; i < n_weights; i++) {
-            uint64_t out[4];
+            uint64_t* out = outs + 4 * (i < 8 ? i : 7);
             const size_t hi = weight_len[i] < off0 + B0 ? weight_len[i] : off0 + B0;
-            if (sh || weight_len[i]) CK(pk_dot(ctx, U(d_weights[i] + off0), U(d_eq), hi > off0 ? hi - off0 : 0, out));
-            else memset(out, 0, sizeof out);
+            if (!rows3) {
+                if (sh || weight_len[i]) CK(pk_dot(ctx, U(d_weights[i] + off0), U(d_eq), hi > off0 ? hi - off0 : 0, out));
+                else memset(out, 0, 32);
+            }
             fe c = h_to_canon(h_load(out));
             const uint8_t* b = (const uint8_t*)c.v;
             buf.insert(buf.end(), b, b + 32);
@@ -959,13 +979,14 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
         std::vector<fe> fsum(3), gsum(3);
         Across ac(ctx, st_sharded);
         CK(ac.rc);
+        // the statement weights are the rows zero-extended to 2^m (whir_r1cs.rs:391-400): only their support is stored and summed;
+        // the three rows share f and g, so all six sums come from one pass (S5)
+        for (int k = 0; k < 3; k++) wts[k] = d_rows + (size_t)k * n_witness;
+        uint64_t o[24] = {};
+        if (st_sharded || n_witness) CK(dot_rows(ctx, U(d_rows + blk_lo), n_witness, 3, U(W.f_evals + blk_lo), U(W.g_evals + blk_lo), col_n, o));
         for (int k = 0; k < 3; k++) {
-            // the statement weight is row k zero-extended to 2^m (whir_r1cs.rs:391-400): only its support is stored and summed
-            wts[k] = d_rows + (size_t)k * n_witness;
-            uint64_t o[8] = {};
-            if (st_sharded || n_witness) CK(pk_dot2(ctx, U(wts[k] + blk_lo), U(W.f_evals + blk_lo), U(W.g_evals + blk_lo), col_n, o));  // S5
-            fsum[k] = h_load(o);
-            gsum[k] = h_load(o + 4);
+            fsum[k] = h_load(o + 8 * k);
+            gsum[k] = h_load(o + 8 * k + 4);
         }
         // hint::<(Vec<F>, Vec<F>)>: two ark-serialize vectors (u64 length + canonical elements)
         for (const std::vector<fe>* v : {&fsum, &gsum}) {
