@@ -117,10 +117,42 @@ int main(int argc, char** argv) {
             std::vector<uint8_t> mp = tree.generate_multi_proof({1, 2}, &opened);
             if (opened.size() != 10 || mp.size() < 8 * 4 + 32 * 2) throw Error(-103, "generate_multi_proof shape");
         }
+        // the witness builders (R1CSSolver::solve_witness_vec): a four-builder list written as postcard by hand --
+        // Constant(0, 1), Acir(1, 0), Product(2, 1, 1), Inverse(3, 2) -- must give w2 = x^2 and w3 * w2 = 1, leave w4 unset
+        {
+            std::vector<uint8_t> pc = {4};  // Vec length
+            auto varint = [&](uint64_t v) {
+                do {
+                    uint8_t b = v & 0x7f;
+                    v >>= 7;
+                    pc.push_back(v ? b | 0x80 : b);
+                } while (v);
+            };
+            varint(0); varint(0); varint(32);  // Constant(ConstantTerm(0, 1)): serde_ark = bytes(32), canonical little-endian
+            pc.push_back(1);
+            for (int i = 1; i < 32; i++) pc.push_back(0);
+            varint(1); varint(1); varint(0);              // Acir(1, 0)
+            varint(3); varint(2); varint(1); varint(1);   // Product(2, 1, 1)
+            varint(7); varint(3); varint(2);              // Inverse(3, 2)
+            WitnessBuilders wb(ctx, pc);
+            const FieldElement x = z[1];
+            auto w = wb.solve_witness_vec({x}, {}, 5);
+            DeviceVec d_a(ctx, std::vector<FieldElement>{x, *w[3]}), d_b(ctx, std::vector<FieldElement>{x, *w[2]}), d_o(ctx, 2);
+            ctx.check(pk_fe_mul(ctx.get(), d_a.data(), d_b.data(), d_o.data(), 2));
+            const auto prod = d_o.to_host();
+            if (!w[0] || *w[0] != interner[0] || !w[1] || *w[1] != x || !w[2] || *w[2] != prod[0] || prod[1] != interner[0] || w[4])
+                throw Error(-104, "witness builders: Constant / Acir / Product / Inverse / None pattern");
+            try {  // a list the reference would panic on: Product reads witness 9, which nobody solves
+                std::vector<uint8_t> bad = {1, 3, 2, 9, 9};
+                WitnessBuilders refuse(ctx, bad);
+            } catch (const Error& e) {
+                seen += std::string(e.what()).find("before it is solved") != std::string::npos;
+            }
+        }
         SkyscraperPoW pow(ctx, std::array<uint8_t, 32>{1, 2, 3}, 10.0);
         const uint64_t nonce = *pow.solve();
         seen += pow.check(nonce) ? 1 : 0;
-        if (seen != 4) throw Error(-101, "error-path checks: " + std::to_string(seen) + " of 4");
+        if (seen != 5) throw Error(-101, "error-path checks: " + std::to_string(seen) + " of 5");
 
         std::ofstream(prefix + ".transcript", std::ios::binary).write((const char*)proof.transcript.data(), (std::streamsize)proof.transcript.size());
         const std::string ds = scheme.domain_separator();

@@ -17,6 +17,8 @@
 //                                 (common/src/skyscraper/whir.rs:30-86); digests are canonical 32-byte values
 //   provekit::SkyscraperPoW       spongefish_pow::PowStrategy {new, check, solve} (common/src/skyscraper/pow.rs:14-30)
 //   provekit::compress_many       skyscraper::CompressManyFn (skyscraper/core/src/lib.rs:26)
+//   provekit::WitnessBuilders     R1CSSolver::solve_witness_vec over a postcard-encoded &[WitnessBuilder]
+//                                 (prover/src/r1cs.rs:29-40, prover/src/witness/witness_builder.rs:27-193)
 #pragma once
 #include <array>
 #include <cstdint>
@@ -333,6 +335,50 @@ class SkyscraperPoW {
     const Context* c_;
     std::array<uint8_t, 32> challenge_;
     double bits_;
+};
+
+// R1CSSolver::solve_witness_vec (prover/src/r1cs.rs:29-40): the builder list is handed over once (postcard of
+// Vec<WitnessBuilder>, the form it has inside a .nps), levelled by data dependence and kept on the device; a proof supplies the
+// ACIR witness map as a dense vector and the challenges the transcript draws for the Challenge builders, in list order.
+// A list the reference would panic on at creation ("reads witness .. before it is solved") or while solving ("inverse of zero",
+// "Higher order bits are not zero", an index out of range) throws Error with that text.
+class WitnessBuilders {
+   public:
+    WitnessBuilders(const Context& c, const std::vector<uint8_t>& postcard_builders) : c_(&c) {
+        c.check(pk_witness_builders_from_postcard(c.get(), postcard_builders.data(), postcard_builders.size(), &p_, &n_witnesses_, &n_challenges_, &n_acir_));
+    }
+    ~WitnessBuilders() {
+        if (p_) pk_witness_program_destroy(c_->get(), p_);
+    }
+    WitnessBuilders(const WitnessBuilders&) = delete;
+    WitnessBuilders& operator=(const WitnessBuilders&) = delete;
+    size_t num_challenges() const { return n_challenges_; }
+    size_t num_acir_witnesses() const { return n_acir_; }
+    size_t num_witnesses_touched() const { return n_witnesses_; }
+    // -> Vec<Option<FieldElement>> of length num_witnesses (fill_witness's random filling of the None entries stays with the caller)
+    std::vector<std::optional<FieldElement>> solve_witness_vec(const std::vector<FieldElement>& acir_witness_values,
+                                                               const std::vector<FieldElement>& challenges, size_t num_witnesses) const {
+        if (num_witnesses < n_witnesses_) num_witnesses = n_witnesses_;
+        DeviceVec acir(*c_, acir_witness_values), wit(*c_, num_witnesses);
+        void* d_set = nullptr;
+        c_->check(pk_malloc(c_->get(), num_witnesses ? num_witnesses : 1, &d_set));
+        int rc = pk_witness_solve(c_->get(), p_, acir.data(), acir_witness_values.size(), challenges.empty() ? nullptr : challenges[0].data(),
+                                  challenges.size(), wit.data(), num_witnesses, static_cast<uint8_t*>(d_set));
+        std::vector<uint8_t> set(num_witnesses);
+        if (!rc && num_witnesses) rc = pk_memcpy_d2h(c_->get(), set.data(), d_set, num_witnesses);
+        pk_free(c_->get(), d_set);
+        c_->check(rc);
+        const std::vector<FieldElement> w = wit.to_host();
+        std::vector<std::optional<FieldElement>> out(num_witnesses);
+        for (size_t i = 0; i < num_witnesses; i++)
+            if (set[i]) out[i] = w[i];
+        return out;
+    }
+
+   private:
+    const Context* c_;
+    pk_witness_program* p_ = nullptr;
+    size_t n_witnesses_ = 0, n_challenges_ = 0, n_acir_ = 0;
 };
 
 // skyscraper::CompressManyFn = fn(&[u8] /*64 n*/, &mut [u8] /*32 n*/); the reference panics on a length mismatch
