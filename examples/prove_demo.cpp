@@ -142,6 +142,21 @@ int main(int argc, char** argv) {
             const auto prod = d_o.to_host();
             if (!w[0] || *w[0] != interner[0] || !w[1] || *w[1] != x || !w[2] || *w[2] != prod[0] || prod[1] != interner[0] || w[4])
                 throw Error(-104, "witness builders: Constant / Acir / Product / Inverse / None pattern");
+            // NoirProofSchemeProver::prove after ACVM: with every witness an ACIR value (Constant(0, 1), Acir(j, j - 1)) nothing is
+            // filled, so the one-call form must reproduce scheme.prove's seeded transcript byte for byte
+            pc.clear();
+            varint(nw);
+            varint(0); varint(0); varint(32);
+            pc.push_back(1);
+            for (int i = 1; i < 32; i++) pc.push_back(0);
+            for (size_t j = 1; j < nw; j++) { varint(1); varint(j); varint(j - 1); }
+            WitnessBuilders all_acir(ctx, pc);
+            const std::vector<FieldElement> zh = d_z.to_host();
+            DeviceVec d_acir(ctx, std::vector<FieldElement>(zh.begin() + 1, zh.end()));
+            if (noir_prove(scheme, all_acir, d_acir, {0, 1}, &seed).transcript != proof.transcript)
+                throw Error(-105, "noir_prove differs from prove on the same witness and seed");
+            if (witness_challenges(nc, nw, {z[1], z[2]}, 2) == witness_challenges(nc, nw, {z[1], z[1]}, 2))
+                throw Error(-106, "the witness transcript ignores a public input");
             try {  // a list the reference would panic on: Product reads witness 9, which nobody solves
                 std::vector<uint8_t> bad = {1, 3, 2, 9, 9};
                 WitnessBuilders refuse(ctx, bad);

@@ -429,6 +429,28 @@ int pk_witness_solve(pk_ctx *ctx, pk_witness_program *prog, const uint64_t *d_ac
                      size_t n_challenges, uint64_t *d_witness, size_t n_witness, uint8_t *d_is_set);
 int pk_witness_program_destroy(pk_ctx *ctx, pk_witness_program *prog);
 
+/* NoirProofSchemeProver::prove after ACVM execution (provekit/prover/src/noir_proof_scheme.rs:63-92):
+ *   pk_witness_challenges  HOST ONLY.  The witness transcript: create_witness_io_pattern (noir_proof_scheme.rs:94-109;
+ *                          witness_io_pattern.rs:18-41 -- "📜", add_scalars(2, "shape"), add_scalars(n, "pub_inputs") when n > 0,
+ *                          challenge_scalars(k, "wb:challenges") when k > 0) over the Skyscraper sponge, seed_witness_merlin
+ *                          (noir_proof_scheme.rs:111-133: absorb num_constraints, num_witnesses, then the public input values in
+ *                          index order), then one challenge scalar per WitnessBuilder::Challenge in list order
+ *                          (witness_builder.rs:94-98).  public_inputs / challenges: Montgomery elements.
+ *   pk_witness_fill        fill_witness (prover/src/witness/mod.rs:15-30): every entry with d_is_set == 0 takes
+ *                          FieldElement::from(u128 drawn from the proof RNG) -- ChaCha12 under rng_seed32, or under a fresh
+ *                          OS-CSPRNG key when NULL (the reference's rng()); *n_filled (may be NULL) = how many.
+ *   pk_noir_prove          the three steps and pk_prove in one call, the witness never leaving the device: public values =
+ *                          d_acir[public_acir_idx[i]] (Circuit::public_inputs().indices(), ascending), challenges, builders
+ *                          (PK_ERR_UNSATISFIED where the reference panics), fill, WhirR1CSProver::prove.  `builders` must not write
+ *                          past the scheme's num_witnesses.  rng_seed32 as pk_prove's (NULL in production). */
+int pk_witness_challenges(size_t num_constraints, size_t num_witnesses, const uint64_t *public_inputs, size_t n_public,
+                          uint64_t *challenges, size_t n_challenges);
+int pk_witness_fill(pk_ctx *ctx, uint64_t *d_witness, const uint8_t *d_is_set, size_t n, const uint8_t *rng_seed32,
+                    size_t *n_filled);
+int pk_noir_prove(pk_ctx *ctx, pk_scheme *scheme, pk_witness_program *builders, const uint64_t *d_acir, size_t n_acir,
+                  const uint32_t *public_acir_idx, size_t n_public, const uint8_t *rng_seed32, uint8_t *transcript_out,
+                  size_t cap, size_t *len);
+
 /* ------------------------------------------------------------------ self-test (host only, no device)
  * Runs the library's __host__ __device__ arithmetic (the same source the kernels compile) on the CPU:
  * op 0: a*b*2^-256 mod p (ark-ff mul)   1: Skyscraper v2 compress   2: v1 compress   3: from Montgomery

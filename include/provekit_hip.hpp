@@ -238,6 +238,8 @@ class WhirR1CSScheme {
         c_->check(pk_prove(c_->get(), h_, d_witness.data(), d_witness.size(), seed ? seed->data() : nullptr, buf.data(), buf.size(), &len));
         return len;
     }
+    pk_scheme* get() const { return h_; }
+    const Context& context() const { return *c_; }
     std::string domain_separator() const {
         size_t n = 0;
         pk_scheme_domain_separator(h_, nullptr, 0, &n);
@@ -355,6 +357,7 @@ class WitnessBuilders {
     size_t num_challenges() const { return n_challenges_; }
     size_t num_acir_witnesses() const { return n_acir_; }
     size_t num_witnesses_touched() const { return n_witnesses_; }
+    pk_witness_program* get() const { return p_; }
     // -> Vec<Option<FieldElement>> of length num_witnesses (fill_witness's random filling of the None entries stays with the caller)
     std::vector<std::optional<FieldElement>> solve_witness_vec(const std::vector<FieldElement>& acir_witness_values,
                                                                const std::vector<FieldElement>& challenges, size_t num_witnesses) const {
@@ -380,6 +383,32 @@ class WitnessBuilders {
     pk_witness_program* p_ = nullptr;
     size_t n_witnesses_ = 0, n_challenges_ = 0, n_acir_ = 0;
 };
+
+// the witness transcript (create_witness_io_pattern + seed_witness_merlin, prover/src/noir_proof_scheme.rs:94-133) and the
+// challenge each WitnessBuilder::Challenge draws from it, in list order.  Host only.
+inline std::vector<FieldElement> witness_challenges(size_t num_constraints, size_t num_witnesses, const std::vector<FieldElement>& public_inputs,
+                                                    size_t n_challenges) {
+    std::vector<FieldElement> out(n_challenges);
+    int rc = pk_witness_challenges(num_constraints, num_witnesses, public_inputs.empty() ? nullptr : public_inputs[0].data(), public_inputs.size(),
+                                   n_challenges ? out[0].data() : nullptr, n_challenges);
+    if (rc) throw Error(rc, "pk_witness_challenges");
+    return out;
+}
+
+// NoirProofSchemeProver::prove after ACVM execution (noir_proof_scheme.rs:69-91) in one call: witness transcript, witness builders,
+// fill_witness, WhirR1CSProver::prove -- the R1CS witness is born and stays on the device.  acir_witness_values: the ACIR witness
+// map as a dense vector indexed by ACIR witness index; public_acir_idx: Circuit::public_inputs().indices().
+inline WhirR1CSProof noir_prove(const WhirR1CSScheme& scheme, const WitnessBuilders& builders, const DeviceVec& acir_witness_values,
+                                const std::vector<uint32_t>& public_acir_idx, const WhirR1CSScheme::TestSeed* seed = nullptr) {
+    WhirR1CSProof p;
+    p.transcript.resize((size_t)4 << 20);
+    size_t len = 0;
+    scheme.context().check(pk_noir_prove(scheme.context().get(), scheme.get(), builders.get(), acir_witness_values.data(), acir_witness_values.size(),
+                                         public_acir_idx.data(), public_acir_idx.size(), seed ? seed->data() : nullptr, p.transcript.data(),
+                                         p.transcript.size(), &len));
+    p.transcript.resize(len);
+    return p;
+}
 
 // skyscraper::CompressManyFn = fn(&[u8] /*64 n*/, &mut [u8] /*32 n*/); the reference panics on a length mismatch
 // (generic.rs:18-25), this throws

@@ -130,3 +130,27 @@ def solve_witness_vec(builders, acir, challenges, num_witnesses):
         else:
             raise ValueError(t)
     return w
+
+
+def witness_io_pattern(n_public, n_challenges):  # noir_proof_scheme.rs:94-109; witness_io_pattern.rs:18-41
+    d = "\U0001F4DC".encode() + b"\0A2shape"
+    if n_public:
+        d += b"\0A%dpub_inputs" % n_public
+    if n_challenges:
+        d += b"\0S%dwb:challenges" % n_challenges
+    return d
+
+
+def witness_challenges(num_constraints, num_witnesses, public_values, n_challenges):
+    """create_witness_io_pattern().to_prover_state(), seed_witness_merlin (noir_proof_scheme.rs:111-133: shape, then the public
+    input values) and the n_challenges single-scalar squeezes of WitnessBuilder::Challenge (witness_builder.rs:94-98), over the
+    Skyscraper duplex sponge of oracle/verifier.py (the prover's absorb of a scalar it writes = the verifier's absorb of the
+    scalar it reads)."""
+    from verifier import Arthur
+
+    scalars = [num_constraints, num_witnesses] + [v % P for v in public_values]
+    A = Arthur(witness_io_pattern(len(public_values), n_challenges), b"".join(v.to_bytes(32, "little") for v in scalars))
+    A.next_scalars(2)
+    if public_values:
+        A.next_scalars(len(public_values))
+    return [A.challenge_scalars(1)[0] for _ in range(n_challenges)]

@@ -38,6 +38,7 @@ int fold_pairs2(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint6
 int witness_bounds_strided(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, unsigned m0, unsigned stride, unsigned offset, uint64_t* d_a,
                            uint64_t* d_b, uint64_t* d_c);
 int external_row_range(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_eq_alpha, size_t first, size_t last, uint64_t* d_out);
+void witness_program_shape(const pk_witness_program* p, size_t* n_witnesses, size_t* n_challenges, size_t* n_acir);  // witness.hip
 }
 
 struct pk_scheme {
@@ -48,6 +49,7 @@ struct pk_scheme {
     char* arena = nullptr;
     size_t arena_bytes = 0;
     std::string domain_separator;
+    char* noir_witness = nullptr;  // pk_noir_prove: num_witnesses elements + num_witnesses is-set bytes, allocated on first use
 };
 
 namespace {
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void random_fe_kernel(fe* __restrict__ out, si
     }
 }
 // draws of one proof (the `stream` word of the nonce)
-enum { RNG_MASK = 1, RNG_G = 2, RNG_BLIND = 3, RNG_MASK_B = 4, RNG_G_B = 5 };
+enum { RNG_MASK = 1, RNG_G = 2, RNG_BLIND = 3, RNG_MASK_B = 4, RNG_G_B = 5, RNG_FILL = 6 };
 
 struct Arena {
     char* base;
@@ -702,6 +704,84 @@ int batch_commit(pk_ctx* ctx, Arena& A, unsigned m, const pk_whir_config& cfg, c
     return rc;
 }
 
+// 256-bit key of one proof's random draws: fresh from the OS CSPRNG (the reference's thread_rng) unless injected.  One proof
+// sharded over a device set: every rank must mask with the SAME polynomials -- rank 0's key goes to everybody.
+int proof_key(pk_ctx* ctx, const uint8_t* rng_seed32, RngKey& key) {
+    if (rng_seed32) {
+        memcpy(key.k, rng_seed32, 32);
+        return PK_OK;
+    }
+    size_t got = 0;
+    while (got < 32) {
+        ssize_t r = getrandom((char*)key.k + got, 32 - got, 0);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            return set_err(ctx, PK_ERR_HIP, "getrandom failed: %s", strerror(errno));
+        }
+        got += (size_t)r;
+    }
+    if (comm_world(ctx) > 1) {
+        int rc = ensure_scratch(ctx, ((size_t)1 << 19) + 32 * (size_t)(PK_MAX_RANKS + 1));
+        if (rc) return rc;
+        char* d_key = (char*)ctx->d_scratch + ((size_t)1 << 19);  // clear of the reduction area (head) and the PoW words (tail)
+        PK_HIP(ctx, hipMemcpyAsync(d_key, key.k, 32, hipMemcpyHostToDevice, ctx->stream));
+        rc = comm_all_gather(ctx, d_key, d_key + 32, 32);
+        if (rc) return rc;
+        PK_HIP(ctx, hipMemcpyAsync(key.k, d_key + 32, 32, hipMemcpyDeviceToHost, ctx->stream));
+        PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PK_OK;
+}
+
+// fill_witness (provekit/prover/src/witness/mod.rs:15-30): every None entry takes FieldElement::from(rng.random::<u128>()).
+// Entry i reads the (i mod 4)-th 128-bit word of ChaCha block i / 4 of stream RNG_FILL, so the result does not depend on the
+// launch shape.  *n_filled counts them (the reference logs the count).
+__global__ __launch_bounds__(256) void fill_witness_kernel(fe* __restrict__ w, const uint8_t* __restrict__ is_set, size_t n, RngKey key, u32 stream,
+                                                           unsigned long long* n_filled) {
+    PK_LATENCY_PRIO();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    unsigned mine = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (is_set[i]) continue;
+        u32 blk[16];
+        chacha_block(key, (u64)(i >> 2), stream, 0, PK_RNG_ROUNDS, blk);
+        fe x = fe_zero();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 v = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v = (i & 3) == (size_t)q ? blk[4 * q + k] : v;
+            x.v[k] = v;
+        }
+        fe_store(w + i, fe_to_montx(x));
+        mine++;
+    }
+    if (mine) atomicAdd(n_filled, (unsigned long long)mine);
+}
+
+// public inputs of the witness transcript: the ACIR witness values at the circuit's public indices
+__global__ void gather_fe_kernel(const fe* __restrict__ src, const uint32_t* __restrict__ idx, size_t n, fe* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fe_store(dst + i, fe_load(src + idx[i]));
+}
+
+// create_witness_io_pattern (provekit/prover/src/noir_proof_scheme.rs:94-109) with witness_io_pattern.rs:18-41: the spongefish
+// op list "<domain>\0A2shape[\0A<n>pub_inputs][\0S<n>wb:challenges]"
+std::string witness_io_pattern(size_t n_public, size_t n_challenges) {
+    std::string d = "\xF0\x9F\x93\x9C";  // "📜"
+    d.push_back('\0');
+    d += "A2shape";
+    if (n_public) {
+        d.push_back('\0');
+        d += "A" + std::to_string(n_public) + "pub_inputs";
+    }
+    if (n_challenges) {
+        d.push_back('\0');
+        d += "S" + std::to_string(n_challenges) + "wb:challenges";
+    }
+    return d;
+}
+
 std::string domain_separator_for(const pk_scheme& s) {
     // spongefish-style op list ("\0"-separated <A|S|H><count><label>); labels are ours (unpinned)
     auto whir_commit_ops = [](const pk_whir_config& c) {
@@ -730,6 +810,7 @@ int pk_scheme_destroy(pk_ctx* ctx, pk_scheme* s) {
     if (!s) return PK_OK;
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(s->arena);
+    (void)hipFree(s->noir_witness);
     delete s;
     return PK_OK;
 }
@@ -793,31 +874,10 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     PK_ENTER(ctx);
     PK_REQUIRE(ctx, s && d_witness && len, "null pointer");
     PK_REQUIRE(ctx, n_witness == s->num_witnesses, "Unexpected witness length for R1CS instance");  // whir_r1cs.rs:43-46
-    // 256-bit key of this proof's random draws: fresh from the OS CSPRNG (the reference's thread_rng) unless injected
     RngKey key;
-    if (rng_seed32) {
-        memcpy(key.k, rng_seed32, 32);
-    } else {
-        size_t got = 0;
-        while (got < 32) {
-            ssize_t r = getrandom((char*)key.k + got, 32 - got, 0);
-            if (r < 0) {
-                if (errno == EINTR) continue;
-                return set_err(ctx, PK_ERR_HIP, "getrandom failed: %s", strerror(errno));
-            }
-            got += (size_t)r;
-        }
-        // one proof sharded over a device set: every rank must mask with the SAME polynomials -- rank 0's key goes to everybody
-        if (comm_world(ctx) > 1) {
-            int rc = ensure_scratch(ctx, ((size_t)1 << 19) + 32 * (size_t)(PK_MAX_RANKS + 1));
-            if (rc) return rc;
-            char* d_key = (char*)ctx->d_scratch + ((size_t)1 << 19);  // clear of the reduction area (head) and the PoW words (tail)
-            PK_HIP(ctx, hipMemcpyAsync(d_key, key.k, 32, hipMemcpyHostToDevice, ctx->stream));
-            rc = comm_all_gather(ctx, d_key, d_key + 32, 32);
-            if (rc) return rc;
-            PK_HIP(ctx, hipMemcpyAsync(key.k, d_key + 32, 32, hipMemcpyDeviceToHost, ctx->stream));
-            PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        }
+    {
+        int rc = proof_key(ctx, rng_seed32, key);
+        if (rc) return rc;
     }
     struct Turn {  // see comm.hip: a no-op outside the test-suite's one-GPU timing mode
         pk_ctx* c;
@@ -1086,6 +1146,80 @@ int pk_selftest_random_fe(pk_ctx* ctx, const uint8_t seed32[32], uint32_t stream
     random_fe_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_out, n, k, stream);
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
+}
+
+/* ---- NoirProofSchemeProver::prove after ACVM execution (provekit/prover/src/noir_proof_scheme.rs:63-92) ---- */
+
+// the witness transcript (host only): IOPattern + seed_witness_merlin (noir_proof_scheme.rs:111-133), then one
+// fill_challenge_scalars per WitnessBuilder::Challenge (witness_builder.rs:94-98)
+int pk_witness_challenges(size_t num_constraints, size_t num_witnesses, const uint64_t* public_inputs, size_t n_public, uint64_t* challenges,
+                          size_t n_challenges) {
+    if ((n_public && !public_inputs) || (n_challenges && !challenges)) return PK_ERR_BAD_ARG;
+    Transcript T(witness_io_pattern(n_public, n_challenges));
+    T.add_scalar(h_from_u64(num_constraints));
+    T.add_scalar(h_from_u64(num_witnesses));
+    for (size_t i = 0; i < n_public; i++) T.add_scalar(h_load(public_inputs + 4 * i));
+    for (size_t i = 0; i < n_challenges; i++) h_store(challenges + 4 * i, T.challenge_scalar());
+    return PK_OK;
+}
+
+int pk_witness_fill(pk_ctx* ctx, uint64_t* d_witness, const uint8_t* d_is_set, size_t n, const uint8_t* rng_seed32, size_t* n_filled) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, n == 0 || (d_witness && d_is_set), "null pointer");
+    if (n_filled) *n_filled = 0;
+    if (!n) return PK_OK;
+    RngKey key;
+    int rc = proof_key(ctx, rng_seed32, key);
+    if (rc) return rc;
+    unsigned long long* m_count = nullptr;
+    rc = mail_alloc(ctx, 8, (void**)&m_count);
+    if (rc) return rc;
+    *m_count = 0;
+    fill_witness_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_witness, d_is_set, n, key, RNG_FILL, m_count);
+    PK_LAUNCH_CHECK(ctx);
+    if (n_filled) {
+        PK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the count is read before sync_stream rewinds the mailbox
+        *n_filled = (size_t)*m_count;
+        return sync_stream(ctx);
+    }
+    return PK_OK;
+}
+
+int pk_noir_prove(pk_ctx* ctx, pk_scheme* s, pk_witness_program* builders, const uint64_t* d_acir, size_t n_acir, const uint32_t* public_acir_idx,
+                  size_t n_public, const uint8_t* rng_seed32, uint8_t* transcript_out, size_t cap, size_t* len) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, s && builders && len && (d_acir || n_acir == 0) && (public_acir_idx || n_public == 0), "null pointer");
+    size_t touched = 0, n_chal = 0, acir_read = 0;
+    witness_program_shape(builders, &touched, &n_chal, &acir_read);
+    PK_REQUIRE(ctx, touched <= s->num_witnesses, "the witness builders write past the R1CS's witness vector");
+    for (size_t i = 0; i < n_public; i++) PK_REQUIRE(ctx, public_acir_idx[i] < n_acir, "public input index outside the ACIR witness vector");
+    const size_t nw = s->num_witnesses;
+    if (!s->noir_witness) PK_HIP(ctx, hipMalloc((void**)&s->noir_witness, 33 * nw));
+    uint64_t* d_w = (uint64_t*)s->noir_witness;
+    uint8_t* d_set = (uint8_t*)s->noir_witness + 32 * nw;
+    // public values -> host
+    std::vector<uint64_t> pub(4 * n_public), chal(4 * n_chal);
+    if (n_public) {
+        uint32_t* m_idx = nullptr;
+        int rc = mail_alloc(ctx, 4 * n_public, (void**)&m_idx);
+        if (rc) return rc;
+        memcpy(m_idx, public_acir_idx, 4 * n_public);
+        gather_fe_kernel<<<(unsigned)((n_public + 255) / 256), 256, 0, ctx->stream>>>((const fe*)d_acir, m_idx, n_public, (fe*)d_w);
+        PK_LAUNCH_CHECK(ctx);
+        PK_HIP(ctx, hipMemcpyAsync(pub.data(), d_w, 32 * n_public, hipMemcpyDeviceToHost, ctx->stream));
+        rc = sync_stream(ctx);
+        if (rc) return rc;
+    }
+    int rc = pk_witness_challenges(s->num_constraints, nw, pub.data(), n_public, chal.data(), n_chal);
+    if (rc) return set_err(ctx, rc, "witness transcript");
+    rc = pk_witness_solve(ctx, builders, d_acir, n_acir, chal.data(), n_chal, d_w, nw, d_set);
+    if (rc) return rc;
+    RngKey key;  // one key for the fill and the proof's masks (distinct streams)
+    rc = proof_key(ctx, rng_seed32, key);
+    if (rc) return rc;
+    rc = pk_witness_fill(ctx, d_w, d_set, nw, (const uint8_t*)key.k, nullptr);
+    if (rc) return rc;
+    return pk_prove(ctx, s, d_w, nw, (const uint8_t*)key.k, transcript_out, cap, len);
 }
 
 int pk_scheme_domain_separator(const pk_scheme* s, char* buf, size_t cap, size_t* len) {

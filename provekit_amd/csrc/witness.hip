@@ -663,6 +663,14 @@ struct pk_witness_program {
     size_t sort_tmp_bytes = 0;
 };
 
+namespace pk {
+void witness_program_shape(const pk_witness_program* p, size_t* n_witnesses, size_t* n_challenges, size_t* n_acir) {
+    *n_witnesses = p->P.n_witnesses;
+    *n_challenges = p->P.n_challenges;
+    *n_acir = p->P.n_acir;
+}
+}  // namespace pk
+
 extern "C" {
 
 int pk_witness_program_destroy(pk_ctx* ctx, pk_witness_program* p) {

@@ -132,3 +132,16 @@ class WhirR1CSScheme:
         self.ctx._check(lib.pk_prove(self.ctx.handle, self.handle, ptr, self.r1cs.num_witnesses, self._seed_arg(seed), self._buf, len(self._buf),
                                      C.byref(n)))
         return n.value
+
+    def noir_prove(self, builders, d_acir, n_acir: int, public_acir_idx=(), seed=None) -> bytes:
+        """NoirProofSchemeProver::prove after ACVM execution (noir_proof_scheme.rs:63-92): witness transcript -> witness builders ->
+        fill_witness -> prove, all on the device.  builders: provekit_amd.witness.WitnessProgram; d_acir: the ACIR witness map
+        as a dense device array (Montgomery) indexed by ACIR witness index; public_acir_idx: Circuit::public_inputs().indices()."""
+        import numpy as np
+
+        idx = np.ascontiguousarray(public_acir_idx, dtype=np.uint32)
+        n = C.c_size_t()
+        ptr = d_acir.ptr if isinstance(d_acir, DeviceBuffer) else d_acir
+        self.ctx._check(lib.pk_noir_prove(self.ctx.handle, self.handle, builders.handle, ptr, n_acir, idx.ctypes.data if len(idx) else None, len(idx),
+                                          self._seed_arg(seed), self._buf, len(self._buf), C.byref(n)))
+        return bytes(self._buf[: n.value])

@@ -121,6 +121,28 @@ def inspect_witness_builders(data: bytes) -> dict:
     return {k: v.value for k, v in zip(keys, vals)}
 
 
+def witness_challenges(num_constraints: int, num_witnesses: int, public_inputs: np.ndarray, n_challenges: int) -> np.ndarray:
+    """the witness transcript (create_witness_io_pattern + seed_witness_merlin, noir_proof_scheme.rs:94-133) and the challenge each
+    WitnessBuilder::Challenge draws from it, in list order.  public_inputs: (n, 4) uint64 Montgomery -> (n_challenges, 4) Montgomery.
+    Host only."""
+    pub = np.ascontiguousarray(public_inputs, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((n_challenges, 4), dtype=np.uint64)
+    rc = lib.pk_witness_challenges(num_constraints, num_witnesses, pub.ctypes.data if len(pub) else None, len(pub),
+                                   out.ctypes.data if n_challenges else None, n_challenges)
+    if rc:
+        raise ValueError(f"pk_witness_challenges: {rc}")
+    return out
+
+
+def fill_witness(ctx, d_witness, d_is_set, n: int, seed=None) -> int:
+    """fill_witness (prover/src/witness/mod.rs:15-30) on the device: unset entries take a random u128; -> how many were filled"""
+    from .scheme import WhirR1CSScheme
+
+    cnt = C.c_size_t()
+    ctx._check(lib.pk_witness_fill(ctx.handle, d_witness.ptr, d_is_set.ptr, n, WhirR1CSScheme._seed_arg(seed), C.byref(cnt)))
+    return cnt.value
+
+
 class WitnessProgram:
     """a builder list levelled and resident on the device (one per scheme)"""
 

@@ -15,7 +15,9 @@
 //! which are not in its tree (Cargo.toml:130-132), so a stock verifier does not accept them (DESIGN.md "Oracle and pinning").
 //! [`stepwise::StepProver`] keeps the transcript in `spongefish::ProverState`, created from the scheme's own `IOPattern`, and
 //! calls one entry point per data-parallel block: byte-compatible by construction for the in-tree half of
-//! `prove`; [`stepwise::HipNoirProofScheme`] puts `NoirProofSchemeProver` (the trait the CLI calls) on top of it.  The three
+//! `prove`; [`stepwise::HipNoirProofScheme`] puts `NoirProofSchemeProver` (the trait the CLI calls) on top of it.
+//! [`HipNoirProver`] widens the one-call grain to everything after ACVM execution (`pk_noir_prove`: witness transcript, witness
+//! builders, `fill_witness`, prove -- the witness vector is born on the device).  The three
 //! plug-in shaped pieces that already have a reference interface are below and work either way: [`compress_many`],
 //! [`SkyscraperPoWHip`], [`HipR1CS`].
 #![allow(clippy::missing_safety_doc)]
@@ -184,6 +186,56 @@ impl WhirR1CSProver for HipProver<'_> {
         })?;
         transcript.truncate(len);
         Ok(WhirR1CSProof { transcript })
+    }
+}
+
+/// `NoirProofSchemeProver::prove` after ACVM execution in one FFI call (`pk_noir_prove`; noir_proof_scheme.rs:69-91): the witness
+/// transcript and its challenges, `solve_witness_vec`, `fill_witness` and `WhirR1CSProver::prove` run inside the library, the R1CS
+/// witness never exists on the host.  Built once per `NoirProofScheme` (builder list and R1CS uploaded), used per proof with the
+/// ACIR witness map `generate_witness` returned.
+pub struct HipNoirProver<'a> {
+    prover: HipProver<'a>,
+    builders: *mut sys::pk_witness_program,
+    n_acir: usize,
+    public_idx: Vec<u32>,
+}
+
+impl<'a> HipNoirProver<'a> {
+    pub fn new(ctx: &'a HipContext, scheme: &'a provekit_common::NoirProofScheme) -> Result<Self> {
+        let prover = HipProver::new(ctx, &scheme.whir_for_witness, &scheme.r1cs)?;
+        let bytes = postcard::to_allocvec(&scheme.witness_builders)?;
+        let (mut builders, mut n_wit, mut n_chal, mut n_acir) = (ptr::null_mut(), 0usize, 0usize, 0usize);
+        ctx.check(unsafe { sys::pk_witness_builders_from_postcard(ctx.raw, bytes.as_ptr(), bytes.len(), &mut builders, &mut n_wit, &mut n_chal, &mut n_acir) })?;
+        // Circuit::public_inputs().indices(): ascending ACIR witness indices (noir_proof_scheme.rs:96-97, 121-123)
+        let public_idx: Vec<u32> = scheme.program.functions[0].public_inputs().indices();
+        let n_acir = n_acir.max(public_idx.iter().map(|&i| i as usize + 1).max().unwrap_or(0));
+        Ok(Self { prover, builders, n_acir, public_idx })
+    }
+
+    pub fn prove(&self, acir: &acir::native_types::WitnessMap<provekit_common::NoirElement>) -> Result<provekit_common::NoirProof> {
+        let ctx = self.prover.ctx;
+        let mut dense = vec![FieldElement::from(0u64); self.n_acir];
+        for (i, slot) in dense.iter_mut().enumerate() {
+            if let Some(v) = acir.get_index(i as u32) {
+                *slot = provekit_common::utils::noir_to_native(*v);
+            }
+        }
+        for &i in &self.public_idx {
+            ensure!(acir.get_index(i).is_some(), "missing public input"); // noir_proof_scheme.rs:126
+        }
+        let d_acir = ctx.upload(&dense)?;
+        let mut transcript = vec![0u8; 8 << 20];
+        let mut len = 0usize;
+        ctx.check(unsafe {
+            sys::pk_noir_prove(ctx.raw, self.prover.raw, self.builders, d_acir.ptr, d_acir.len, self.public_idx.as_ptr(), self.public_idx.len(), ptr::null(), transcript.as_mut_ptr(), transcript.len(), &mut len)
+        })?;
+        transcript.truncate(len);
+        Ok(provekit_common::NoirProof { whir_r1cs_proof: WhirR1CSProof { transcript } })
+    }
+}
+impl Drop for HipNoirProver<'_> {
+    fn drop(&mut self) {
+        unsafe { sys::pk_witness_program_destroy(self.prover.ctx.raw, self.builders) };
     }
 }
 

@@ -100,3 +100,123 @@ def test_a_poseidon_sized_list(ctx, oracle):
 
     builders, acir, ch, nw = random_program(99, 1 << 17)
     _check(ctx, oracle, builders, acir, ch, nw)
+
+
+def _noir_instance(oracle, seed, n_in=6, n_prod=40):
+    """a builder list that derives a whole R1CS witness and the R1CS it satisfies: z0 = 1, inputs from ACIR, two challenges drawn
+    from the witness transcript, then products / sums / inverses / a challenge-dependent linear operation, each with its constraint;
+    the last three witnesses are written by nobody (fill_witness) and constrained by nothing"""
+    import witness_ref as R
+
+    from provekit_amd.witness import WitnessBuilder as WB
+
+    rng = np.random.default_rng(seed)
+    acir = [int.from_bytes(rng.bytes(32), "little") % R.P for _ in range(n_in + 3)]  # ACIR indices 3.. hold the inputs
+    b = [WB.Constant(0, 1)] + [WB.Acir(1 + i, 3 + i) for i in range(n_in)] + [WB.Challenge(1 + n_in), WB.Challenge(2 + n_in)]
+    nxt = 3 + n_in
+    coeffs = [1, R.P - 1, 5]
+    A, B, Cm = ([], [], []), ([], [], []), ([], [], [])
+
+    def row(a_terms, b_terms, c_terms):
+        i = (A[0][-1] + 1) if A[0] else 0
+        for M, terms in ((A, a_terms), (B, b_terms), (Cm, c_terms)):
+            for col, v in sorted(terms):
+                M[0].append(i); M[1].append(col); M[2].append(v)
+
+    for k in range(n_prod):
+        x, y = (int(v) for v in rng.integers(1, nxt, size=2))
+        kind = k % 4
+        if (kind == 2 and x == y) or (kind == 3 and x == 1 + n_in):
+            kind = 0
+        if kind == 0:
+            b.append(WB.Product(nxt, x, y)); row([(x, 0)], [(y, 0)], [(nxt, 0)])
+        elif kind == 1:
+            b.append(WB.Inverse(nxt, x)); row([(x, 0)], [(nxt, 0)], [(0, 0)])
+        elif kind == 2:
+            b.append(WB.Sum(nxt, [(None, x), (5, y)])); row([(x, 0), (y, 2)], [(0, 0)], [(nxt, 0)])
+        else:  # x + the first challenge
+            b.append(WB.Sum(nxt, [(None, x), (None, 1 + n_in)])); row([(x, 0), (1 + n_in, 0)], [(0, 0)], [(nxt, 0)])
+        nxt += 1
+    nw = nxt + 3
+    return b, acir, [0, 4], nw, coeffs, (A, B, Cm)
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_noir_prove_is_challenges_then_builders_then_fill_then_prove(ctx, oracle, seed):
+    """pk_noir_prove (NoirProofSchemeProver::prove after ACVM, noir_proof_scheme.rs:63-92) = its four steps called one by one, byte
+    for byte; the witness is the sequential solver's on the transcript's challenges; the proof is accepted by the verifier"""
+    import verifier as V
+    import witness_ref as R
+    from test_gpu_prove import to_sparse
+
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS
+    from provekit_amd.witness import WitnessProgram, fill_witness, witness_challenges
+    from provekit_amd._lib import lib
+
+    builders, acir, pub_idx, nw, coeffs, trips = _noir_instance(oracle, seed)
+    nc = trips[0][0][-1] + 1
+    m, m_0 = 10, 6
+    assert nw <= 1 << (m - 1) and nc <= 1 << m_0
+    r1cs = R1CS(ctx, *(to_sparse(nc, nw, t) for t in trips), oracle.to_mont(oracle.ints_to_limbs(coeffs)))
+    cfg_w, cfg_b = WhirConfig.for_size(m, 4.0), blinding_config_for(m_0, 4.0)
+    scheme = WhirR1CSScheme(ctx, r1cs, m, m_0, cfg_w, cfg_b)
+    prog = WitnessProgram(ctx, builders)
+    d_acir = ctx.upload(_mont(oracle, acir))
+    proof = scheme.noir_prove(prog, d_acir, len(acir), pub_idx, seed=seed)
+    assert proof == scheme.noir_prove(prog, d_acir, len(acir), pub_idx, seed=seed)
+
+    # step by step, with the oracle beside every step
+    pub = [acir[i] for i in pub_idx]
+    ch = R.witness_challenges(nc, nw, pub, 2)
+    got_ch = witness_challenges(nc, nw, _mont(oracle, pub), 2)
+    assert oracle.limbs_to_ints(oracle.from_mont(got_ch)) == ch
+    want = R.solve_witness_vec(builders, acir, ch, nw)
+    assert sum(x is None for x in want) == 3
+    d_w, d_set = ctx.alloc_fe(nw), ctx.alloc(nw)
+    ctx._check(lib.pk_witness_solve(ctx.handle, prog.handle, d_acir.ptr, len(acir), got_ch.ctypes.data, 2, d_w.ptr, nw, d_set.ptr))
+    assert fill_witness(ctx, d_w, d_set, nw, seed=seed) == 3
+    z = oracle.limbs_to_ints(oracle.from_mont(ctx.download_fe(d_w, nw)))
+    for i, x in enumerate(want):
+        assert (z[i] == x) if x is not None else (0 < z[i] < 1 << 128), f"witness {i}"
+    assert len({z[i] for i, x in enumerate(want) if x is None}) == 3
+    assert r1cs.test_witness_satisfaction(d_w) is None
+    assert scheme.prove(d_w, seed=seed) == proof
+
+    def vcfg(c):
+        return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
+
+    mats = [(t[0], t[1], [coeffs[v] for v in t[2]]) for t in trips]
+    assert V.verify(proof, scheme.domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b), r1cs=(nc, nw, mats))
+    # fresh OS randomness: another transcript, same statement, still accepted
+    fresh = scheme.noir_prove(prog, d_acir, len(acir), pub_idx)
+    assert fresh != proof and V.verify(fresh, scheme.domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b), r1cs=(nc, nw, mats))
+    prog.close()
+    scheme.close()
+
+
+def test_fill_witness_draws_one_u128_per_unset_entry(ctx, oracle):
+    """fill_witness (mod.rs:15-30): set entries untouched, unset ones = word (i mod 4) of ChaCha12 block i / 4, stream 6 (the block
+    function is RFC-pinned in test_gpu_rng), as a field element; the count is the reference's log line"""
+    import ctypes as C
+
+    from provekit_amd._lib import lib
+    from provekit_amd.witness import fill_witness
+
+    n = 1000
+    rng = np.random.default_rng(5)
+    is_set = rng.integers(0, 2, size=n).astype(np.uint8)
+    vals = [int(x) for x in rng.integers(1, 2**62, size=n)]
+    d_w, d_set = ctx.upload(_mont(oracle, vals)), ctx.alloc(n)
+    ctx._check(lib.pk_memcpy_h2d(ctx.handle, d_set.ptr, is_set.ctypes.data, n))
+    seed = bytes(range(32))
+    assert fill_witness(ctx, d_w, d_set, n, seed=seed) == int((is_set == 0).sum())
+    got = oracle.limbs_to_ints(oracle.from_mont(ctx.download_fe(d_w, n)))
+    blk = (C.c_uint8 * 64)()
+    for i in range(n):
+        if is_set[i]:
+            assert got[i] == vals[i]
+        else:
+            assert lib.pk_selftest_chacha((C.c_uint8 * 32).from_buffer_copy(seed), i >> 2, 6, 0, 12, blk) == 0
+            assert got[i] == int.from_bytes(bytes(blk)[16 * (i & 3): 16 * (i & 3) + 16], "little"), i

@@ -69,3 +69,32 @@ def test_library_decodes_and_levels_the_postcard_list_on_the_host():
         bad = bytearray(encode_witness_builders([WB.Constant(0, 5)]))
         bad[-32:] = b"\xff" * 32
         inspect_witness_builders(bytes(bad))
+
+
+@pytest.mark.parametrize("n_public,n_challenges", [(0, 0), (0, 3), (2, 1), (5, 4)])
+def test_witness_transcript_challenges_match_the_oracle(oracle, n_public, n_challenges):
+    """pk_witness_challenges (host only: create_witness_io_pattern + seed_witness_merlin + one squeeze per Challenge) against
+    oracle/witness_ref.witness_challenges over oracle/verifier.py's sponge; the IO pattern's labels are the reference's
+    (witness_io_pattern.rs:24-40)"""
+    import numpy as np
+
+    from provekit_amd.witness import witness_challenges
+
+    rng = np.random.default_rng(100 + 7 * n_public + n_challenges)
+    pub = [int.from_bytes(rng.bytes(32), "little") % R.P for _ in range(n_public)]
+    nc, nw = 786429, 1048571
+    want = R.witness_challenges(nc, nw, pub, n_challenges)
+    pub_m = oracle.to_mont(oracle.ints_to_limbs(pub)) if pub else np.zeros((0, 4), np.uint64)
+    got = witness_challenges(nc, nw, pub_m, n_challenges)
+    assert oracle.limbs_to_ints(oracle.from_mont(got)) == want if n_challenges else got.shape == (0, 4)
+    if n_challenges:
+        assert len(set(want)) == n_challenges
+        # the shape and every public value are bound into the challenges
+        assert R.witness_challenges(nc + 1, nw, pub, n_challenges) != want
+        if pub:
+            assert R.witness_challenges(nc, nw, pub[:-1] + [(pub[-1] + 1) % R.P], n_challenges) != want
+
+
+def test_witness_io_pattern_is_the_references():
+    assert R.witness_io_pattern(0, 0) == "📜".encode() + b"\0A2shape"
+    assert R.witness_io_pattern(3, 2) == "📜".encode() + b"\0A2shape\0A3pub_inputs\0S2wb:challenges"
