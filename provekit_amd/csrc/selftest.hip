@@ -3,6 +3,7 @@
 #include "ctx.hpp"
 #include "reduce.hpp"
 #include "fe52.hpp"
+#include "feinv.hpp"
 #include "skyscraper29s.hpp"
 #include "transcript.hpp"
 
@@ -66,6 +67,8 @@ PK_HD fe selftest_op(int op, const fe& x, const fe& y) {
             r = dot29_result(d);
             break;
         }
+        case 21: r = fe_inverse_mont(x); break;   // feinv.hpp: Montgomery in, Montgomery out (0 -> 0)
+        case 22: r = fe_inverse_plain(x); break;  // plain integers mod p
         default: break;
     }
     return r;
@@ -181,7 +184,7 @@ __device__ __forceinline__ void coop_sq_round(u32& L, u32& R, u32 Pj, u32 RCj, u
     L = sres;
 }
 __global__ void coop_round_kernel(const u32* __restrict__ in_l, const u32* __restrict__ in_r, unsigned iters, u32* __restrict__ out,
-                                  unsigned long long* __restrict__ cycles, int mode) {
+                                  unsigned long long* __restrict__ cycles, int mode, unsigned long long active) {
     const unsigned lane = threadIdx.x;
     u32 L = lane < 9 ? in_l[lane] : 0u, R = lane < 9 ? in_r[lane] : 0u;
     const u32 Pj = lane < 9 ? p29((int)(lane < 9 ? lane : 0)) : 0u;
@@ -209,7 +212,7 @@ __global__ void coop_round_kernel(const u32* __restrict__ in_l, const u32* __res
         r.v[k] = in_r[k + off];
     }
     unsigned long long t2 = __builtin_readcyclecounter();
-    if (mode != 1)
+    if (mode != 1 && ((active >> lane) & 1ull))  // PK_COOP_ACTIVE: which lanes of the wavefront run the lone-lane loop
         for (unsigned it = 0; it < iters; it++) sky_sq_round_s<0>(l, r);
     unsigned long long t3 = __builtin_readcyclecounter();
     if (lane == 0) {
@@ -236,7 +239,9 @@ int pk_selftest_coop_round(pk_ctx* ctx, const uint32_t l[9], const uint32_t r[9]
     u32* d = (u32*)ctx->d_scratch;
     PK_HIP(ctx, hipMemcpyAsync(d, l, 36, hipMemcpyHostToDevice, ctx->stream));
     PK_HIP(ctx, hipMemcpyAsync(d + 16, r, 36, hipMemcpyHostToDevice, ctx->stream));
-    coop_round_kernel<<<1, 64, 0, ctx->stream>>>(d, d + 16, iters, d + 64, (unsigned long long*)(d + 128), 0);
+    const char* ae = getenv("PK_COOP_ACTIVE");  // hex lane mask of the lone-lane loop (default: all 64)
+    const unsigned long long active = ae ? strtoull(ae, nullptr, 16) : ~0ull;
+    coop_round_kernel<<<1, 64, 0, ctx->stream>>>(d, d + 16, iters, d + 64, (unsigned long long*)(d + 128), 0, ~0ull);
     PK_LAUNCH_CHECK(ctx);
     PK_HIP(ctx, hipMemcpyAsync(out, d + 64, 144, hipMemcpyDeviceToHost, ctx->stream));
     PK_HIP(ctx, hipMemcpyAsync(cycles, d + 128, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -250,7 +255,7 @@ int pk_selftest_coop_round(pk_ctx* ctx, const uint32_t l[9], const uint32_t r[9]
     for (int mode = 1; mode <= 2; mode++) {
         float ms = 0;
         if ((rc = pk_timer_start(ctx))) return rc;
-        coop_round_kernel<<<grid ? grid : 1u, 64, 0, ctx->stream>>>(d, d + 16, iters, d + 256, (unsigned long long*)(d + 384), mode);
+        coop_round_kernel<<<grid ? grid : 1u, 64, 0, ctx->stream>>>(d, d + 16, iters, d + 256, (unsigned long long*)(d + 384), mode, active);
         PK_LAUNCH_CHECK(ctx);
         if ((rc = pk_timer_stop(ctx, &ms))) return rc;
         cycles[1 + mode] = (uint64_t)(1e6 * (double)ms);  // ns for `iters` rounds (plus one launch)
@@ -363,7 +368,7 @@ int pk_selftest_arith(int op, const uint64_t* a, const uint64_t* b, uint64_t* ou
     if (!a || !out || (!b && (op == 0 || op == 1 || op == 2 || op == 4 || op == 15 || op == 16 || op == 19 || op == 20))) return PK_ERR_BAD_ARG;
     for (size_t i = 0; i < n; i++) {
         fe x = load_host(a + 4 * i), y = b ? load_host(b + 4 * i) : x;
-        if (op < 0 || op > 20) return PK_ERR_BAD_ARG;
+        if (op < 0 || op > 22) return PK_ERR_BAD_ARG;
         fe r = selftest_op(op, x, y);
         store_host(out + 4 * i, r);
     }

@@ -29,6 +29,7 @@
 #define PK_BASE_PRIO 2
 #include "ctx.hpp"
 #include "fe29.hpp"
+#include "feinv.hpp"
 
 using namespace pk;
 
@@ -84,18 +85,9 @@ __device__ __forceinline__ bool bits_above_zero(const fe& canon, u32 from) {  //
     }
     return true;
 }
-// x^(p-2): square-and-multiply over the bits of p - 2, top bit first
-__device__ __forceinline__ fe fe_inverse(const fe& x) {
-    // p - 2, little-endian words
-    const u32 e[8] = {PK_P0 - 2u, PK_P1, PK_P2, PK_P3, PK_P4, PK_P5, PK_P6, PK_P7};
-    fe acc = x;  // bit 253 of p is its top bit (p < 2^254): start from it
-#pragma unroll 1
-    for (int bit = 252; bit >= 0; bit--) {
-        acc = fe_sqrx(acc);
-        if ((e[bit >> 5] >> (bit & 31)) & 1u) acc = fe_mulx(acc, x);
-    }
-    return acc;
-}
+// operand.inverse() (witness_builder.rs:66-69): safegcd on one lane, ~7x shorter than x^(p-2) (feinv.hpp); a level of the list
+// costs at least one inversion's latency, so this is what the deep-but-wide lists are bound by
+__device__ __forceinline__ fe fe_inverse(const fe& x) { return fe_inverse_mont(x); }
 __device__ __forceinline__ fe cow(const fe* __restrict__ W, const fe* __restrict__ K, u32 packed) {
     return (packed & COW_CONST) ? fe_load(K + (packed & ~COW_CONST)) : fe_load(W + packed);
 }
@@ -643,6 +635,11 @@ bool build_program(const uint8_t* bytes, size_t len, Program& P, size_t* consume
         for (auto& it : B[i].main) P.items[cur[2 * level[i]]++] = it;
         for (auto& it : B[i].second) P.items[cur[2 * level[i] + 1]++] = it;
     }
+    // items of one phase are independent: grouped by variant, a wavefront runs one case of wb_eval's switch instead of all of them
+    // one after the other (and an Inverse's 40 us are not paid by 63 lanes that only needed a product)
+    for (size_t ph = 0; ph + 1 < P.phase_begin.size(); ph++)
+        std::stable_sort(P.items.begin() + P.phase_begin[ph], P.items.begin() + P.phase_begin[ph + 1],
+                         [](const WbItem& a, const WbItem& b) { return a.op < b.op; });
     std::stable_sort(P.spice.begin(), P.spice.end(), [](const SpiceBlock& a, const SpiceBlock& b) { return a.level < b.level; });
     return true;
 }

@@ -190,3 +190,17 @@ def test_grouped_dot_product(oracle):
     rinv = pow(1 << 256, -1, P)
     a, b = oracle.ints_to_limbs(xs), oracle.ints_to_limbs(ys)
     assert oracle.limbs_to_ints(run(20, a, b)) == [(3 * x * y + x * x + y * y) * rinv % P for x, y in zip(xs, ys)]
+
+
+def test_safegcd_inverse_is_the_field_inverse(oracle):
+    """feinv.hpp (the witness builders' Inverse, witness_builder.rs:66-69) against pow(x, -1, p): plain integers (op 22) and
+    Montgomery in / Montgomery out (op 21); edge values, every bit length, 20 k random elements; 0 -> 0"""
+    import random
+
+    rnd = random.Random(1)
+    vals = [0, 1, 2, 3, P - 1, P - 2, (P + 1) // 2, (P - 1) // 2, 1 << 253, 1 << 128, (1 << 30) - 1, 1 << 30]
+    vals += [rnd.randrange(1 << k) for k in range(1, 254)] + [P - 1 - rnd.randrange(1 << k) for k in range(1, 250, 7)] + rand_fe(20000, 77)
+    want = [pow(v, -1, P) if v else 0 for v in vals]
+    a = oracle.ints_to_limbs(vals)
+    assert oracle.limbs_to_ints(run(22, a)) == want
+    assert oracle.limbs_to_ints(oracle.from_mont(run(21, oracle.to_mont(a)))) == want
