@@ -521,3 +521,48 @@ def test_rccl_sharded_prove_transcript_identical(ctx, oracle, rccl_set, G, m):
 
     assert V.verify(want[0], ds, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
     assert V.verify(got[0][0][1], ds, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
+
+
+def test_noir_prove_on_a_device_set(ctx, oracle, rank_sets):
+    """pk_noir_prove with every rank of a set calling it (witness builders replicated, the proof sharded): seeded transcripts equal
+    the lone prover's; with OS randomness rank 0's key reaches every rank BEFORE fill_witness, so the ranks fill the three unset
+    witnesses alike and still agree byte for byte; the verifier accepts both"""
+    import verifier as V
+    from test_gpu_prove import to_sparse
+    from test_gpu_witness import _mont, _noir_instance
+
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS
+    from provekit_amd.witness import WitnessProgram
+
+    builders, acir, pub_idx, nw, coeffs, trips = _noir_instance(oracle, 77, n_in=6, n_prod=20000)
+    nc = trips[0][0][-1] + 1
+    m, m_0 = 16, 15
+    assert nw <= 1 << (m - 1) and nc <= 1 << m_0
+    interner = oracle.to_mont(oracle.ints_to_limbs(coeffs))
+    cfg_w, cfg_b = WhirConfig.for_size(m, 6.0), blinding_config_for(m_0, 6.0)
+    acir_m = _mont(oracle, acir)
+
+    def prove_on(c):
+        r1cs = R1CS(c, *(to_sparse(nc, nw, t) for t in trips), interner)
+        s = WhirR1CSScheme(c, r1cs, m, m_0, cfg_w, cfg_b)
+        prog = WitnessProgram(c, builders)
+        d_acir = c.upload(acir_m)
+        out = (s.noir_prove(prog, d_acir, len(acir), pub_idx, seed=9), s.noir_prove(prog, d_acir, len(acir), pub_idx), s.domain_separator)
+        prog.close()
+        s.close()
+        r1cs.close()
+        return out
+
+    seeded, lone_fresh, ds = prove_on(ctx)
+    got = run_ranks(rank_sets(2), lambda r, c: prove_on(c))
+    assert all(g[0] == seeded for g in got), "a rank diverged from the lone prover's seeded transcript"
+    assert got[0][1] == got[1][1] and got[0][1] not in (seeded, lone_fresh)
+
+    def vcfg(c):
+        return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
+
+    mats = [(t[0], t[1], [coeffs[v] for v in t[2]]) for t in trips]
+    for proof in (seeded, got[0][1]):
+        assert V.verify(proof, ds, m, m_0, vcfg(cfg_w), vcfg(cfg_b), r1cs=(nc, nw, mats))
