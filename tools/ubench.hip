@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void bench(unsigned* out, unsigned seed, unsig
         acc[k] = (unsigned long long)a * (k + 3) + b;
         facc[k] = (double)(a & 0xfffff) + k;
     }
+    unsigned long long mask = __ballot((a & 1) != 0);
     double fa = (double)(a & 0xffff) + 1.0, fb = (double)(b & 0xffff) + 3.0;
     for (int it = 0; it < ITERS; it++) {
         if (OP == 0) {
@@ -104,6 +105,42 @@ __global__ __launch_bounds__(256) void bench(unsigned* out, unsigned seed, unsig
 #undef S
         } else if (OP == 17) {  // broadcast of one lane through an SGPR into a multiply-add (v_readfirstlane-style m_i broadcast)
 #define S(k) { unsigned s; asm volatile("v_readlane_b32 %0, %2, 0\n\tv_mad_u64_u32 %1, vcc, %0, %3, %1" : "=&s"(s), "+v"(acc[k]) : "v"((unsigned)acc[(k + 1) & 7]), "v"(b) : "vcc"); }
+            BODY8(S)
+#undef S
+        } else if (OP == 20) {  // the carry extraction of the 29-bit-limb multiplier as one 64-bit shift ...
+#define S(k) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(acc[k]));
+            BODY8(S)
+#undef S
+        } else if (OP == 21) {  // ... or as its 32-bit halves
+#define S(k) { unsigned lo = (unsigned)acc[k], hi = (unsigned)(acc[k] >> 32); asm volatile("v_alignbit_b32 %0, %1, %0, 29" : "+v"(lo) : "v"(hi)); acc[k] = lo | ((unsigned long long)hi << 32); }
+            BODY8(S)
+#undef S
+        } else if (OP == 22) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_lshrrev_b32 %0, 29, %0" : "+v"(lo)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 23) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(lo)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 24) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(lo) : "v"(a), "v"(b)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 25) {
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(lo) : "v"(a), "v"(b)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 26) {  // compare + select through VCC, as a conditional subtraction compiles
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_cmp_gt_u32 vcc, %1, %0\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(lo) : "v"(a), "v"(b) : "vcc"); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 27) {  // select through an SGPR pair (VOP3)
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(lo) : "v"(b), "s"(mask)); acc[k] = lo; }
+            BODY8(S)
+#undef S
+        } else if (OP == 28) {  // compare alone
+#define S(k) { unsigned lo = (unsigned)acc[k]; asm volatile("v_cmp_gt_u32 vcc, %1, %0" : : "v"(lo), "v"(a) : "vcc"); acc[k] = lo; }
             BODY8(S)
 #undef S
         } else if (OP == 18) {  // ONE dependent chain (no ILP): what a latency-bound lane actually sees per v_mad_u64_u32
@@ -179,6 +216,15 @@ int main() {
     run<15>("v_mad_u32_u16", d_out, cus, ghz);
     run<10>("v_dot4_u32_u8", d_out, cus, ghz);
     run<14>("v_dot2_u32_u16", d_out, cus, ghz);
+    run<20>("v_lshrrev_b64", d_out, cus, ghz);
+    run<21>("v_alignbit_b32", d_out, cus, ghz);
+    run<22>("v_lshrrev_b32", d_out, cus, ghz);
+    run<23>("v_and_b32", d_out, cus, ghz);
+    run<24>("v_add3_u32", d_out, cus, ghz);
+    run<25>("v_bfi_b32", d_out, cus, ghz);
+    run<26>("v_cmp+v_cndmask", d_out, cus, ghz);
+    run<27>("v_cndmask sgpr", d_out, cus, ghz);
+    run<28>("v_cmp_gt_u32", d_out, cus, ghz);
     run<3>("v_fma_f64", d_out, cus, ghz);
     run<11>("v_add_f64", d_out, cus, ghz);
     // one wavefront per SIMD: the issue costs a latency-bound (tree-top, small-tree) hash sees
