@@ -98,3 +98,42 @@ def test_witness_transcript_challenges_match_the_oracle(oracle, n_public, n_chal
 def test_witness_io_pattern_is_the_references():
     assert R.witness_io_pattern(0, 0) == "📜".encode() + b"\0A2shape"
     assert R.witness_io_pattern(3, 2) == "📜".encode() + b"\0A2shape\0A3pub_inputs\0S2wb:challenges"
+
+
+def test_postcard_decoder_survives_mutated_input():
+    """pk_witness_builders_inspect (host decode + levelling) on corrupted postcard: truncations, bit flips, spliced varints and
+    huge counts must come back as an error or a well-formed program -- never a crash, hang or giant allocation"""
+    import random
+
+    from witness_gen import random_program
+
+    from provekit_amd.witness import encode_witness_builders, inspect_witness_builders
+
+    builders, _, _, _ = random_program(3, 400)
+    good = encode_witness_builders(builders)
+    assert inspect_witness_builders(good)["n_builders"] == len(builders)
+    rnd = random.Random(9)
+    outcomes = {"ok": 0, "err": 0}
+    for trial in range(1000):
+        b = bytearray(good)
+        kind = trial % 5
+        if kind == 0:
+            b = b[: rnd.randrange(len(b))]
+        elif kind == 1:
+            for _ in range(rnd.randrange(1, 4)):
+                b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        elif kind == 2:
+            pos = rnd.randrange(len(b))
+            b[pos:pos] = bytes([0xff] * rnd.randrange(1, 11))  # an over-long / huge varint
+        elif kind == 3:
+            pos = rnd.randrange(len(b))
+            del b[pos : pos + rnd.randrange(1, 40)]
+        else:
+            b = bytearray(rnd.randbytes(rnd.randrange(0, 200)))
+        try:
+            info = inspect_witness_builders(bytes(b))
+            assert info["n_items"] < 10_000_000
+            outcomes["ok"] += 1
+        except Exception:
+            outcomes["err"] += 1
+    assert outcomes["err"] > 300 and outcomes["ok"] + outcomes["err"] == 1000
