@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void spice_resolve_kernel(const SpiceOp* __res
 }
 
 // ---- postcard(Vec<WitnessBuilder>) ---------------------------------------------------------------------------------------------
+constexpr uint64_t PK_MAX_WITNESS_INDEX = 1ull << 27;
 struct Reader {
     const uint8_t* p;
     size_t n, off = 0;
@@ -255,9 +256,10 @@ struct Reader {
         }
         return ok = false, 0;
     }
-    u32 index() {  // a usize that must fit a witness index
+    u32 index() {  // a usize that must be a witness index, an ACIR index or a table size: below 2^27 (a scheme holds at most 2^26
+                   // witnesses, pk_scheme_create), so a corrupted list cannot ask for tables of gigabytes
         const uint64_t v = varint();
-        if (v >= 0x7fffffffull) ok = false;
+        if (v >= PK_MAX_WITNESS_INDEX) ok = false;
         return (u32)v;
     }
     // serde_ark: bytes(32) = varint(32) | canonical little-endian (provekit/common/src/utils/serde_ark.rs:11-30)

@@ -191,6 +191,28 @@ def test_r1cs_from_postcard_matches_direct_upload(ctx, oracle):
     for bad in (blob[: len(blob) // 2], blob[:1] + b"\xff\xff\xff\xff\xff\xff\xff\xff\xff\x7f" + blob[2:], b""):
         with pytest.raises(ProveKitHipError):
             R1CS.from_postcard(ctx, bad if bad else b"\x00")
+    # mutated bytes: an error or a well-formed R1CS, quickly and without giant allocations
+    import random
+    import time
+
+    rnd = random.Random(4)
+    t0, seen = time.time(), {"ok": 0, "err": 0}
+    for trial in range(400):
+        m = bytearray(blob)
+        if trial % 3 == 0:
+            m[rnd.randrange(len(m))] ^= 1 << rnd.randrange(8)
+        elif trial % 3 == 1:
+            pos = rnd.randrange(len(m))
+            m[pos:pos] = bytes([0xff] * rnd.randrange(1, 10))
+        else:
+            pos = rnd.randrange(len(m))
+            del m[pos : pos + rnd.randrange(1, 30)]
+        try:
+            R1CS.from_postcard(ctx, bytes(m)).close()
+            seen["ok"] += 1
+        except ProveKitHipError:
+            seen["err"] += 1
+    assert seen["err"] > 100 and time.time() - t0 < 60, seen
     direct.close()
     viapc.close()
 

@@ -114,7 +114,7 @@ def test_postcard_decoder_survives_mutated_input():
     assert inspect_witness_builders(good)["n_builders"] == len(builders)
     rnd = random.Random(9)
     outcomes = {"ok": 0, "err": 0}
-    for trial in range(1000):
+    for trial in range(3000):
         b = bytearray(good)
         kind = trial % 5
         if kind == 0:
@@ -136,4 +136,4 @@ def test_postcard_decoder_survives_mutated_input():
             outcomes["ok"] += 1
         except Exception:
             outcomes["err"] += 1
-    assert outcomes["err"] > 300 and outcomes["ok"] + outcomes["err"] == 1000
+    assert outcomes["err"] > 1000 and outcomes["ok"] + outcomes["err"] == 3000
