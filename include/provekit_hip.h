@@ -418,7 +418,9 @@ int pk_scheme_domain_separator(const pk_scheme *scheme, char *buf, size_t cap, s
  *                                        the reference's Vec<Option<F>> is Some.  The points where the reference panics -- inverse of
  *                                        zero, "Higher order bits are not zero", a multiplicity / memory index out of range -- return
  *                                        PK_ERR_UNSATISFIED naming the first builder (in list order) that hits one.
- * fill_witness (random values for the None entries, prover/src/witness/mod.rs:15-30) stays with the caller. */
+ * fill_witness (random values for the None entries, prover/src/witness/mod.rs:15-30): pk_witness_fill below, or the caller.
+ * A pk_witness_program belongs to the context that created it and keeps per-solve state on the device (histograms, the error
+ * word): one program per prover thread, like the scheme. */
 typedef struct pk_witness_program pk_witness_program;
 int pk_witness_builders_from_postcard(pk_ctx *ctx, const uint8_t *bytes, size_t len, pk_witness_program **out,
                                       size_t *n_witnesses, size_t *n_challenges, size_t *n_acir);
@@ -438,7 +440,8 @@ int pk_witness_program_destroy(pk_ctx *ctx, pk_witness_program *prog);
  *                          (witness_builder.rs:94-98).  public_inputs / challenges: Montgomery elements.
  *   pk_witness_fill        fill_witness (prover/src/witness/mod.rs:15-30): every entry with d_is_set == 0 takes
  *                          FieldElement::from(u128 drawn from the proof RNG) -- ChaCha12 under rng_seed32, or under a fresh
- *                          OS-CSPRNG key when NULL (the reference's rng()); *n_filled (may be NULL) = how many.
+ *                          OS-CSPRNG key when NULL (the reference's rng(); on a device set rank 0's key reaches every rank through one
+ *                          32-byte all-gather, so all ranks must make the call); *n_filled (may be NULL) = how many.
  *   pk_noir_prove          the three steps and pk_prove in one call, the witness never leaving the device: public values =
  *                          d_acir[public_acir_idx[i]] (Circuit::public_inputs().indices(), ascending), challenges, builders
  *                          (PK_ERR_UNSATISFIED where the reference panics), fill, WhirR1CSProver::prove.  `builders` must not write
