@@ -6,15 +6,34 @@
 // -- in the reference's own CSR form (new_row_indices / col_indices / interned value indices,
 // sparse_matrix.rs:12-27) plus a CSC copy built here -- and both products become atomic-free
 // gathers: one lane per output row (A*z) or per output column (eq^T * A).
+//
+// Heavy lines.  Real constraint systems have a few very long lines -- the column of the constant-one witness is touched by every
+// constraint with a constant term, a LogUp grand sum is one row with a term per lookup -- and a lane that walks 10^5 entries holds
+// the kernel for 10^5 dependent products.  Lines longer than HEAVY_DEGREE are therefore found once per R1CS, cut into chunks of
+// HEAVY_CHUNK entries, and summed by a workgroup per chunk before the gather runs; the gather's lane then reads the finished sum.
+// Field addition is exact, so the order of summation does not show in the result.
+#include <algorithm>
 #include <vector>
 
 // memory- / latency-bound kernels: their wavefronts issue ahead of the ALU-bound hash / NTT / grinder kernels they share SIMDs with
 #define PK_BASE_PRIO 2
 #include "ctx.hpp"
 #include "fe29.hpp"
+#include "reduce.hpp"
 
 using namespace pk;
 
+namespace pk {
+int witness_bounds_strided(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, unsigned m0, unsigned stride, unsigned offset, uint64_t* d_a,
+                           uint64_t* d_b, uint64_t* d_c);
+int external_row_range(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_eq_alpha, size_t first, size_t last, uint64_t* d_out);
+}
+
+constexpr uint32_t HEAVY_DEGREE = 64;    // longer lines are summed by workgroups
+constexpr uint32_t HEAVY_CHUNK = 2048;   // entries per workgroup
+struct heavy_chunk {
+    uint32_t slot, begin, end;  // entries [begin, end) of the line set's arrays belong to heavy line number `slot` (R1CS-wide numbering)
+};
 struct pk_r1cs {
     size_t num_constraints = 0, num_witnesses = 0, n_interned = 0;
     fe* d_interner = nullptr;
@@ -22,23 +41,73 @@ struct pk_r1cs {
     uint32_t *csr_ptr[3] = {}, *csr_idx[3] = {}, *csr_val[3] = {};
     uint32_t *csc_ptr[3] = {}, *csc_idx[3] = {}, *csc_val[3] = {};
     size_t nnz[3] = {};
+    // heavy lines of the six line sets (0..2: rows of A, B, C; 3..5: their columns): sorted line indices per set, slots numbered
+    // through all sets, the chunks of set s at d_chunks[chunk0[s] .. chunk0[s] + n_chunks[s])
+    uint32_t* d_heavy_lines[6] = {};
+    uint32_t n_heavy[6] = {}, slot0[6] = {}, chunk0[6] = {}, n_chunks[6] = {};
+    heavy_chunk* d_chunks = nullptr;
+    uint32_t *d_slot_chunk0 = nullptr, *d_slot_nchunks = nullptr;  // per slot: its chunks (absolute indices into d_chunks)
+    size_t n_slots = 0, n_chunks_total = 0;
 };
 
 namespace {
 
-__device__ __forceinline__ fe sparse_row_dot(const uint32_t* __restrict__ ptr, const uint32_t* __restrict__ idx,
-                                             const uint32_t* __restrict__ val, const fe* __restrict__ interner,
-                                             const fe* __restrict__ x, size_t i) {
+struct line_set {  // one of the six (ptr, idx, val) triples with its heavy lines
+    const uint32_t *ptr, *idx, *val;
+    const uint32_t* heavy_lines;  // sorted
+    uint32_t n_heavy, slot0;
+};
+__device__ __forceinline__ fe sparse_row_dot(const line_set& L, const fe* __restrict__ interner, const fe* __restrict__ x,
+                                             const fe* __restrict__ heavy_vals, size_t i) {
+    uint32_t k = L.ptr[i];
+    const uint32_t e = L.ptr[i + 1];
+    if (e - k > HEAVY_DEGREE) {  // summed beforehand (heavy_dot_kernel / heavy_sum_kernel): find the line's slot
+        uint32_t lo = 0, hi = L.n_heavy;
+        while (lo + 1 < hi) {
+            const uint32_t mid = (lo + hi) / 2;
+            if (L.heavy_lines[mid] <= (uint32_t)i) lo = mid;
+            else hi = mid;
+        }
+        return fe_load(heavy_vals + L.slot0 + lo);
+    }
     // the row's products share Montgomery reductions (fe29.hpp dot29): one per DOT29_GROUP entries
     dot29 d;
     dot29_init(d);
-    for (uint32_t k = ptr[i], e = ptr[i + 1]; k < e; k++) dot29_add(d, unpack29<0>(fe_load(interner + val[k])), unpack29<5>(fe_load(x + idx[k])));
+    for (; k < e; k++) dot29_add(d, unpack29<0>(fe_load(interner + L.val[k])), unpack29<5>(fe_load(x + L.idx[k])));
     return dot29_result(d);
+}
+// one workgroup per chunk of a heavy line: partial[chunk] = sum over its entries
+__global__ __launch_bounds__(RED_THREADS) void heavy_dot_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val,
+                                                                const heavy_chunk* __restrict__ chunks, const fe* __restrict__ interner,
+                                                                const fe* __restrict__ x, fe* __restrict__ partials) {
+    PK_LATENCY_PRIO();
+    __shared__ uint4 smem[16];
+    const heavy_chunk c = chunks[blockIdx.x];
+    dot29 d;
+    dot29_init(d);
+    for (uint32_t k = c.begin + threadIdx.x; k < c.end; k += RED_THREADS) dot29_add(d, unpack29<0>(fe_load(interner + val[k])), unpack29<5>(fe_load(x + idx[k])));
+    wide w[1] = {wide_zero()};
+    wide_add_fe(w[0], dot29_result(d));
+    const fe sum = block_reduce_wide<1>(w, smem);
+    if (threadIdx.x == 0) fe_store(partials + blockIdx.x, sum);
+}
+// one workgroup per heavy line: the sum of its chunks' partials
+__global__ __launch_bounds__(RED_THREADS) void heavy_sum_kernel(const uint32_t* __restrict__ slot_chunk0, const uint32_t* __restrict__ slot_nchunks,
+                                                                uint32_t first_slot, uint32_t first_chunk, const fe* __restrict__ partials,
+                                                                fe* __restrict__ heavy_vals) {
+    PK_LATENCY_PRIO();
+    __shared__ uint4 smem[16];
+    const uint32_t slot = first_slot + blockIdx.x, c0 = slot_chunk0[slot] - first_chunk, n = slot_nchunks[slot];
+    fe acc = fe_zero();
+    for (uint32_t j = threadIdx.x; j < n; j += RED_THREADS) acc = fe_add(acc, fe_load(partials + c0 + j));
+    wide w[1] = {wide_zero()};
+    wide_add_fe(w[0], acc);
+    const fe sum = block_reduce_wide<1>(w, smem);
+    if (threadIdx.x == 0) fe_store(heavy_vals + slot, sum);
 }
 
 // calculate_witness_bounds (provekit/common/src/utils/sumcheck.rs:181-193): a = A z, b = B z, c = a o b, zero-padded
-__global__ __launch_bounds__(256) void witness_bounds_kernel(const uint32_t* pa, const uint32_t* ia, const uint32_t* va, const uint32_t* pb,
-                                                             const uint32_t* ib, const uint32_t* vb, const fe* __restrict__ interner,
+__global__ __launch_bounds__(256) void witness_bounds_kernel(line_set A, line_set B, const fe* __restrict__ interner, const fe* __restrict__ heavy_vals,
                                                              const fe* __restrict__ z, size_t num_rows, size_t padded, fe* __restrict__ a,
                                                              fe* __restrict__ b, fe* __restrict__ c, size_t stride, size_t offset) {
     PK_LATENCY_PRIO();
@@ -49,55 +118,81 @@ __global__ __launch_bounds__(256) void witness_bounds_kernel(const uint32_t* pa,
     const size_t i = j * stride + offset;
     fe ra = fe_zero(), rb = fe_zero();
     if (i < num_rows) {
-        ra = sparse_row_dot(pa, ia, va, interner, z, i);
-        rb = sparse_row_dot(pb, ib, vb, interner, z, i);
+        ra = sparse_row_dot(A, interner, z, heavy_vals, i);
+        rb = sparse_row_dot(B, interner, z, heavy_vals, i);
     }
     fe_store(a + j, ra);
     fe_store(b + j, rb);
     fe_store(c + j, fe_mulx(ra, rb));
 }
 
-__global__ __launch_bounds__(256) void sparse_gather_kernel(const uint32_t* ptr, const uint32_t* idx, const uint32_t* val,
-                                                            const fe* __restrict__ interner, const fe* __restrict__ x, size_t n_out,
-                                                            fe* __restrict__ y) {
+__global__ __launch_bounds__(256) void sparse_gather_kernel(line_set L, const fe* __restrict__ interner, const fe* __restrict__ heavy_vals,
+                                                            const fe* __restrict__ x, size_t n_out, fe* __restrict__ y) {
     PK_LATENCY_PRIO();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
-    fe_store(y + i, sparse_row_dot(ptr, idx, val, interner, x, i));
+    fe_store(y + i, sparse_row_dot(L, interner, x, heavy_vals, i));
 }
 
 // R1CS::test_witness_satisfaction (provekit/prover/src/r1cs.rs:41-60): (A z)_i (B z)_i == (C z)_i for every row; the first
 // failing row (the one the reference's "Constraint {row} failed" names) is reduced with an atomic min.
-__global__ __launch_bounds__(256) void satisfaction_kernel(const uint32_t* pa, const uint32_t* ia, const uint32_t* va, const uint32_t* pb,
-                                                           const uint32_t* ib, const uint32_t* vb, const uint32_t* pc, const uint32_t* ic,
-                                                           const uint32_t* vc, const fe* __restrict__ interner, const fe* __restrict__ z,
-                                                           size_t num_rows, unsigned long long* __restrict__ first_bad) {
+__global__ __launch_bounds__(256) void satisfaction_kernel(line_set A, line_set B, line_set Cm, const fe* __restrict__ interner,
+                                                           const fe* __restrict__ heavy_vals, const fe* __restrict__ z, size_t num_rows,
+                                                           unsigned long long* __restrict__ first_bad) {
     PK_LATENCY_PRIO();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= num_rows) return;
-    fe ra = sparse_row_dot(pa, ia, va, interner, z, i);
-    fe rb = sparse_row_dot(pb, ib, vb, interner, z, i);
-    fe rc = sparse_row_dot(pc, ic, vc, interner, z, i);
+    fe ra = sparse_row_dot(A, interner, z, heavy_vals, i);
+    fe rb = sparse_row_dot(B, interner, z, heavy_vals, i);
+    fe rc = sparse_row_dot(Cm, interner, z, heavy_vals, i);
     if (!fe_eq(fe_mulx(ra, rb), rc)) atomicMin(first_bad, (unsigned long long)i);
 }
 
 // eq^T A, eq^T B, eq^T C in one launch: lane j walks column j of all three matrices.  Column degrees vary (lanes of a
 // wavefront wait for the longest column), and the sum of three degrees varies relatively less than each one alone.
 struct csc3 {
-    const uint32_t *ptr[3], *idx[3], *val[3];
+    line_set m[3];
 };
-__global__ __launch_bounds__(256) void sparse_gather3_kernel(csc3 m, const fe* __restrict__ interner, const fe* __restrict__ x, size_t n_out,
-                                                             fe* __restrict__ y, size_t first, size_t last) {
+__global__ __launch_bounds__(256) void sparse_gather3_kernel(csc3 m, const fe* __restrict__ interner, const fe* __restrict__ heavy_vals,
+                                                             const fe* __restrict__ x, size_t n_out, fe* __restrict__ y, size_t first, size_t last) {
     PK_LATENCY_PRIO();
     size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // columns [first, last) only: a rank's block of the rows
     if (i >= last) return;
 #pragma unroll 1
-    for (int k = 0; k < 3; k++) fe_store(y + (size_t)k * n_out + i, sparse_row_dot(m.ptr[k], m.idx[k], m.val[k], interner, x, i));
+    for (int k = 0; k < 3; k++) fe_store(y + (size_t)k * n_out + i, sparse_row_dot(m.m[k], interner, x, heavy_vals, i));
 }
 
 int upload_u32(pk_ctx* ctx, const std::vector<uint32_t>& v, uint32_t** out) {
     PK_HIP(ctx, hipMalloc((void**)out, (v.size() ? v.size() : 1) * 4));
     if (!v.empty()) PK_HIP(ctx, hipMemcpy(*out, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    return PK_OK;
+}
+
+line_set set_of(const pk_r1cs* r, int s) {  // s: 0..2 rows of A, B, C; 3..5 their columns
+    const int m = s % 3;
+    const bool t = s >= 3;
+    return line_set{t ? r->csc_ptr[m] : r->csr_ptr[m], t ? r->csc_idx[m] : r->csr_idx[m], t ? r->csc_val[m] : r->csr_val[m],
+                    r->d_heavy_lines[s], r->n_heavy[s], r->slot0[s]};
+}
+// Sums the heavy lines of the line sets in `mask` against x and returns where the gather kernels find them (slot-indexed).  The
+// partials and the sums live in the context's workspace: they are consumed by the very next launch on the same stream.
+int heavy_prepare(pk_ctx* ctx, const pk_r1cs* r, unsigned mask, const fe* x, const fe** heavy_vals) {
+    *heavy_vals = nullptr;
+    bool any = false;
+    for (int s = 0; s < 6; s++) any |= ((mask >> s) & 1u) && r->n_heavy[s];
+    if (!any) return PK_OK;
+    int rc = ensure_ws(ctx, 32 * (r->n_slots + r->n_chunks_total));
+    if (rc) return rc;
+    fe* vals = (fe*)ctx->d_ws;
+    fe* partials = vals + r->n_slots;
+    for (int s = 0; s < 6; s++) {
+        if (!((mask >> s) & 1u) || !r->n_heavy[s]) continue;
+        const line_set L = set_of(r, s);
+        heavy_dot_kernel<<<r->n_chunks[s], RED_THREADS, 0, ctx->stream>>>(L.idx, L.val, r->d_chunks + r->chunk0[s], r->d_interner, x, partials + r->chunk0[s]);
+        heavy_sum_kernel<<<r->n_heavy[s], RED_THREADS, 0, ctx->stream>>>(r->d_slot_chunk0, r->d_slot_nchunks, r->slot0[s], 0, partials, vals);
+    }
+    PK_LAUNCH_CHECK(ctx);
+    *heavy_vals = vals;
     return PK_OK;
 }
 
@@ -114,6 +209,10 @@ int pk_r1cs_destroy(pk_ctx* ctx, pk_r1cs* r) {
         (void)hipFree(r->csr_ptr[m]); (void)hipFree(r->csr_idx[m]); (void)hipFree(r->csr_val[m]);
         (void)hipFree(r->csc_ptr[m]); (void)hipFree(r->csc_idx[m]); (void)hipFree(r->csc_val[m]);
     }
+    for (int s = 0; s < 6; s++) (void)hipFree(r->d_heavy_lines[s]);
+    (void)hipFree(r->d_chunks);
+    (void)hipFree(r->d_slot_chunk0);
+    (void)hipFree(r->d_slot_nchunks);
     delete r;
     return PK_OK;
 }
@@ -139,6 +238,7 @@ int pk_r1cs_create(pk_ctx* ctx, size_t num_constraints, size_t num_witnesses, co
     if (n_interned && hipMemcpy(r->d_interner, interner, n_interned * 32, hipMemcpyHostToDevice) != hipSuccess)
         return fail(set_err(ctx, PK_ERR_HIP, "interner upload"));
     try {  // the host-side index arrays are sized by caller-supplied dimensions: no exception may cross the C ABI
+    std::vector<uint32_t> heavy_lines[6], host_ptr[6];
     for (int m = 0; m < 3; m++) {
         const pk_sparse_matrix& M = mats[m];
         const size_t nnz = M.nnz;
@@ -168,9 +268,39 @@ int pk_r1cs_create(pk_ctx* ctx, size_t num_constraints, size_t num_witnesses, co
                 ri[pos] = (uint32_t)i;
                 cv[pos] = vv[k];
             }
+        for (size_t i = 0; i < num_constraints; i++)
+            if (rp[i + 1] - rp[i] > HEAVY_DEGREE) heavy_lines[m].push_back((uint32_t)i);
+        for (size_t j = 0; j < num_witnesses; j++)
+            if (cp[j + 1] - cp[j] > HEAVY_DEGREE) heavy_lines[3 + m].push_back((uint32_t)j);
+        host_ptr[m] = rp;
+        host_ptr[3 + m] = cp;
         if ((rc = upload_u32(ctx, rp, &r->csr_ptr[m])) || (rc = upload_u32(ctx, ci, &r->csr_idx[m])) || (rc = upload_u32(ctx, vv, &r->csr_val[m])) ||
             (rc = upload_u32(ctx, cp, &r->csc_ptr[m])) || (rc = upload_u32(ctx, ri, &r->csc_idx[m])) || (rc = upload_u32(ctx, cv, &r->csc_val[m])))
             return fail(rc);
+    }
+    // heavy lines -> chunks (sets in order, lines ascending within a set, a line's chunks consecutive)
+    std::vector<heavy_chunk> chunks;
+    std::vector<uint32_t> slot_chunk0, slot_nchunks;
+    for (int s = 0; s < 6; s++) {
+        r->n_heavy[s] = (uint32_t)heavy_lines[s].size();
+        r->slot0[s] = (uint32_t)slot_chunk0.size();
+        r->chunk0[s] = (uint32_t)chunks.size();
+        for (uint32_t line : heavy_lines[s]) {
+            const uint32_t b = host_ptr[s][line], e = host_ptr[s][line + 1], slot = (uint32_t)slot_chunk0.size();
+            slot_chunk0.push_back((uint32_t)chunks.size());
+            for (uint32_t k = b; k < e; k += HEAVY_CHUNK) chunks.push_back(heavy_chunk{slot, k, std::min(e, k + HEAVY_CHUNK)});
+            slot_nchunks.push_back((uint32_t)chunks.size() - slot_chunk0.back());
+        }
+        r->n_chunks[s] = (uint32_t)chunks.size() - r->chunk0[s];
+        if (r->n_heavy[s] && (rc = upload_u32(ctx, heavy_lines[s], &r->d_heavy_lines[s]))) return fail(rc);
+    }
+    r->n_slots = slot_chunk0.size();
+    r->n_chunks_total = chunks.size();
+    if (r->n_slots) {
+        if ((rc = upload_u32(ctx, slot_chunk0, &r->d_slot_chunk0)) || (rc = upload_u32(ctx, slot_nchunks, &r->d_slot_nchunks))) return fail(rc);
+        if (hipMalloc((void**)&r->d_chunks, chunks.size() * sizeof(heavy_chunk)) != hipSuccess) return fail(set_err(ctx, PK_ERR_OOM, "hipMalloc heavy chunks"));
+        if (hipMemcpy(r->d_chunks, chunks.data(), chunks.size() * sizeof(heavy_chunk), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(set_err(ctx, PK_ERR_HIP, "heavy chunk upload"));
     }
     } catch (const std::bad_alloc&) {
         return fail(set_err(ctx, PK_ERR_OOM, "host memory exhausted while indexing the R1CS (%zu x %zu)", num_constraints, num_witnesses));
@@ -286,13 +416,7 @@ int pk_r1cs_witness_bounds(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, u
     PK_ENTER(ctx);
     PK_REQUIRE(ctx, r && d_z && d_a && d_b && d_c, "null pointer");
     PK_REQUIRE(ctx, m0 <= 30 && r->num_constraints <= ((size_t)1 << m0), "R1CS constraints exceed scheme capacity");  // whir_r1cs.rs:52-54
-    size_t padded = (size_t)1 << m0;
-    ProfScope prof(ctx, "witness_bounds");
-    witness_bounds_kernel<<<(unsigned)((padded + 255) / 256), 256, 0, ctx->stream>>>(
-        r->csr_ptr[0], r->csr_idx[0], r->csr_val[0], r->csr_ptr[1], r->csr_idx[1], r->csr_val[1], r->d_interner, (const fe*)d_z,
-        r->num_constraints, padded, (fe*)d_a, (fe*)d_b, (fe*)d_c, 1, 0);
-    PK_LAUNCH_CHECK(ctx);
-    return PK_OK;
+    return witness_bounds_strided(ctx, r, d_z, m0, 1, 0, d_a, d_b, d_c);
 }
 
 int pk_r1cs_matvec(pk_ctx* ctx, const pk_r1cs* r, int matrix, int transpose, const uint64_t* d_x, uint64_t* d_y) {
@@ -301,11 +425,12 @@ int pk_r1cs_matvec(pk_ctx* ctx, const pk_r1cs* r, int matrix, int transpose, con
     PK_REQUIRE(ctx, matrix >= 0 && matrix < 3, "matrix must be 0 (A), 1 (B) or 2 (C)");
     size_t n_out = transpose ? r->num_witnesses : r->num_constraints;
     if (!n_out) return PK_OK;
-    const uint32_t* ptr = transpose ? r->csc_ptr[matrix] : r->csr_ptr[matrix];
-    const uint32_t* idx = transpose ? r->csc_idx[matrix] : r->csr_idx[matrix];
-    const uint32_t* val = transpose ? r->csc_val[matrix] : r->csr_val[matrix];
+    const int s = (transpose ? 3 : 0) + matrix;
     ProfScope prof(ctx, "sparse_matvec");
-    sparse_gather_kernel<<<(unsigned)((n_out + 255) / 256), 256, 0, ctx->stream>>>(ptr, idx, val, r->d_interner, (const fe*)d_x, n_out, (fe*)d_y);
+    const fe* hv = nullptr;
+    int rc = heavy_prepare(ctx, r, 1u << s, (const fe*)d_x, &hv);
+    if (rc) return rc;
+    sparse_gather_kernel<<<(unsigned)((n_out + 255) / 256), 256, 0, ctx->stream>>>(set_of(r, s), r->d_interner, hv, (const fe*)d_x, n_out, (fe*)d_y);
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
 }
@@ -323,9 +448,10 @@ int pk_r1cs_test_witness_satisfaction(pk_ctx* ctx, const pk_r1cs* r, const uint6
     PK_HIP(ctx, hipMemsetAsync(d_bad, 0xff, 8, ctx->stream));
     {
         ProfScope prof(ctx, "r1cs_satisfaction");
-        satisfaction_kernel<<<(unsigned)((r->num_constraints + 255) / 256), 256, 0, ctx->stream>>>(
-            r->csr_ptr[0], r->csr_idx[0], r->csr_val[0], r->csr_ptr[1], r->csr_idx[1], r->csr_val[1], r->csr_ptr[2], r->csr_idx[2], r->csr_val[2],
-            r->d_interner, (const fe*)d_witness, r->num_constraints, d_bad);
+        const fe* hv = nullptr;
+        if ((rc = heavy_prepare(ctx, r, 7u, (const fe*)d_witness, &hv))) return rc;
+        satisfaction_kernel<<<(unsigned)((r->num_constraints + 255) / 256), 256, 0, ctx->stream>>>(set_of(r, 0), set_of(r, 1), set_of(r, 2), r->d_interner, hv,
+                                                                                                 (const fe*)d_witness, r->num_constraints, d_bad);
         PK_LAUNCH_CHECK(ctx);
     }
     unsigned long long bad = 0;
@@ -342,18 +468,7 @@ int pk_r1cs_test_witness_satisfaction(pk_ctx* ctx, const pk_r1cs* r, const uint6
 int pk_r1cs_external_row(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_eq_alpha, uint64_t* d_out) {
     PK_ENTER(ctx);
     PK_REQUIRE(ctx, r && d_eq_alpha && d_out, "null pointer");
-    if (!r->num_witnesses) return PK_OK;
-    csc3 m;
-    for (int k = 0; k < 3; k++) {
-        m.ptr[k] = r->csc_ptr[k];
-        m.idx[k] = r->csc_idx[k];
-        m.val[k] = r->csc_val[k];
-    }
-    ProfScope prof(ctx, "sparse_matvec");
-    sparse_gather3_kernel<<<(unsigned)((r->num_witnesses + 255) / 256), 256, 0, ctx->stream>>>(m, r->d_interner, (const fe*)d_eq_alpha, r->num_witnesses,
-                                                                                             (fe*)d_out, 0, r->num_witnesses);
-    PK_LAUNCH_CHECK(ctx);
-    return PK_OK;
+    return external_row_range(ctx, r, d_eq_alpha, 0, r->num_witnesses, d_out);
 }
 
 }  // extern "C"
@@ -366,9 +481,11 @@ int witness_bounds_strided(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, u
     PK_REQUIRE(ctx, m0 <= 30 && r->num_constraints <= ((size_t)1 << m0) && stride && offset < stride, "bad shard of the witness bounds");
     const size_t padded = ((size_t)1 << m0) / stride;
     ProfScope prof(ctx, "witness_bounds");
-    witness_bounds_kernel<<<(unsigned)((padded + 255) / 256), 256, 0, ctx->stream>>>(
-        r->csr_ptr[0], r->csr_idx[0], r->csr_val[0], r->csr_ptr[1], r->csr_idx[1], r->csr_val[1], r->d_interner, (const fe*)d_z,
-        r->num_constraints, padded, (fe*)d_a, (fe*)d_b, (fe*)d_c, stride, offset);
+    const fe* hv = nullptr;  // heavy rows are summed whole on every rank of a sharded sumcheck (they are few)
+    int rc = heavy_prepare(ctx, r, 3u, (const fe*)d_z, &hv);
+    if (rc) return rc;
+    witness_bounds_kernel<<<(unsigned)((padded + 255) / 256), 256, 0, ctx->stream>>>(set_of(r, 0), set_of(r, 1), r->d_interner, hv, (const fe*)d_z,
+                                                                                     r->num_constraints, padded, (fe*)d_a, (fe*)d_b, (fe*)d_c, stride, offset);
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
 }
@@ -378,13 +495,12 @@ int external_row_range(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_eq_alpha
     if (last > r->num_witnesses) last = r->num_witnesses;
     if (first >= last) return PK_OK;
     csc3 m;
-    for (int k = 0; k < 3; k++) {
-        m.ptr[k] = r->csc_ptr[k];
-        m.idx[k] = r->csc_idx[k];
-        m.val[k] = r->csc_val[k];
-    }
+    for (int k = 0; k < 3; k++) m.m[k] = set_of(r, 3 + k);
     ProfScope prof(ctx, "sparse_matvec");
-    sparse_gather3_kernel<<<(unsigned)((last - first + 255) / 256), 256, 0, ctx->stream>>>(m, r->d_interner, (const fe*)d_eq_alpha, r->num_witnesses,
+    const fe* hv = nullptr;
+    int rc = heavy_prepare(ctx, r, 7u << 3, (const fe*)d_eq_alpha, &hv);
+    if (rc) return rc;
+    sparse_gather3_kernel<<<(unsigned)((last - first + 255) / 256), 256, 0, ctx->stream>>>(m, r->d_interner, hv, (const fe*)d_eq_alpha, r->num_witnesses,
                                                                                          (fe*)d_out, first, last);
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;

@@ -55,6 +55,81 @@ def test_r1cs_products(ctx, oracle, nc, nw):
     r.close()
 
 
+def heavy_r1cs(nc, nw, seed):
+    """matrices with the long lines real constraint systems have: a column nearly every row touches (the constant-one witness),
+    rows and columns whose lengths sit on the heavy threshold (64 / 65) and on the chunk size (2048 / 2049 / 4097), a row with a
+    term per witness (a grand sum), besides ordinary short rows"""
+    from provekit_amd.sparse_matrix import SparseMatrix
+
+    rng = np.random.default_rng(seed)
+    mats = []
+    for which in range(3):
+        rows = []
+        special = {0: 64, 1: 65, 2: 2048, 3: 2049, 4: 4097, 5: nw, 6: 0}
+        for i in range(nc):
+            k = special.get(i, int(rng.integers(1, 5)))
+            cols = set(int(c) for c in rng.choice(nw, size=min(k, nw), replace=False))
+            if i > 6 and rng.random() < 0.9:
+                cols.add(0)  # the heavy column
+            if i > 6 and i % 3 == which:
+                cols.add(1 + which)  # three more columns of ~nc/3 entries each
+            if 100 <= i < 164:
+                cols.add(7)  # exactly 64 entries: not heavy
+            if 200 <= i < 265:
+                cols.add(8)  # 65: heavy
+            rows.append(sorted(cols))
+        nri, ci = [], []
+        for r_ in rows:
+            nri.append(len(ci))
+            ci += r_
+        vv = rng.integers(0, 17, size=len(ci))
+        mats.append(SparseMatrix(nc, nw, np.array(nri, np.uint32), np.array(ci, np.uint32), vv.astype(np.uint32)))
+    return mats
+
+
+@pytest.mark.parametrize("nc,nw", [(3000, 5000), (9000, 4100)])
+def test_r1cs_products_with_heavy_rows_and_columns(ctx, oracle, nc, nw):
+    """lines longer than 64 entries are summed by workgroups before the gather (csrc/r1cs.hip "heavy lines"): every product, the
+    satisfaction check and the single-matrix products still equal the oracle's row-by-row sums bit for bit"""
+    import ctypes as C
+
+    from provekit_amd import ProveKitHipError
+    from provekit_amd._lib import lib
+    from provekit_amd.field import random_field
+    from provekit_amd.sparse_matrix import R1CS
+
+    a, b, c = heavy_r1cs(nc, nw, nc)
+    interner = random_field(17, 5)
+    r = R1CS(ctx, a, b, c, interner)
+    z = random_field(nw, 9)
+    d_z = ctx.upload(z)
+    m0 = (nc - 1).bit_length()
+    da, db, dc = r.calculate_witness_bounds(d_z, m0)
+    ea, eb, ec = (oracle.spmv(nc, nw, m.new_row_indices, m.col_indices, m.values, interner, z) for m in (a, b, c))
+    zpad = np.zeros(((1 << m0) - nc, 4), np.uint64)
+    assert np.array_equal(ctx.download_fe(da, 1 << m0), np.concatenate([ea, zpad]))
+    assert np.array_equal(ctx.download_fe(db, 1 << m0), np.concatenate([eb, zpad]))
+    assert np.array_equal(ctx.download_fe(dc, 1 << m0), np.concatenate([oracle.hadamard(ea, eb), zpad]))
+    eq = random_field(1 << m0, 10)
+    d_eq = ctx.upload(eq)
+    out = ctx.download_fe(r.calculate_external_row_of_r1cs_matrices(d_eq), 3 * nw).reshape(3, nw, 4)
+    for k, m in enumerate((a, b, c)):
+        exp = oracle.spmv(nc, nw, m.new_row_indices, m.col_indices, m.values, interner, eq[:nc], transpose=True)
+        assert np.array_equal(out[k], exp), k
+        # the single-matrix entry points (pk_r1cs_matvec), both directions
+        d_y = ctx.alloc_fe(max(nc, nw))
+        ctx._check(lib.pk_r1cs_matvec(ctx.handle, r.handle, k, 0, d_z.ptr, d_y.ptr))
+        assert np.array_equal(ctx.download_fe(d_y, nc), (ea, eb, ec)[k])
+        ctx._check(lib.pk_r1cs_matvec(ctx.handle, r.handle, k, 1, d_eq.ptr, d_y.ptr))
+        assert np.array_equal(ctx.download_fe(d_y, nw), exp)
+    # satisfaction: random z does not satisfy; the first failing row is the oracle's
+    want_bad = next(i for i in range(nc) if not np.array_equal(oracle.hadamard(ea[i : i + 1], eb[i : i + 1])[0], ec[i]))
+    with pytest.raises(ProveKitHipError) as e:
+        r.test_witness_satisfaction(d_z)
+    assert e.value.row == want_bad
+    r.close()
+
+
 def test_r1cs_rejects_bad_input(ctx):
     from provekit_amd import ProveKitHipError
     from provekit_amd.field import random_field
