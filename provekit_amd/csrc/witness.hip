@@ -30,6 +30,7 @@
 #include "ctx.hpp"
 #include "fe29.hpp"
 #include "feinv.hpp"
+#include "reduce.hpp"
 
 using namespace pk;
 
@@ -239,6 +240,49 @@ __global__ __launch_bounds__(256) void spice_resolve_kernel(const SpiceOp* __res
     }
 }
 
+// ---- long sums (witness_builder.rs:45-60 with thousands of terms: a LogUp grand sum has one per lookup) --------------------------
+// A lane that walks 10^5 terms holds its level for 10^5 dependent products.  Sums longer than SUM_HEAVY terms leave the item list:
+// a workgroup per SUM_CHUNK terms forms a partial sum, a workgroup per sum adds the partials.  Exact field additions: the order
+// does not show in the result.
+constexpr u32 SUM_HEAVY = 128, SUM_CHUNK = 1024;
+struct SumChunk {
+    u32 begin, end;  // term numbers (pairs of P.extra)
+};
+struct HeavySum {
+    u32 builder, level, out, chunk0, n_chunks;
+};
+__global__ __launch_bounds__(RED_THREADS) void heavy_sum_part_kernel(const SumChunk* __restrict__ chunks, const u32* __restrict__ extra, const fe* __restrict__ W,
+                                                                     const fe* __restrict__ K, fe* __restrict__ partials) {
+    PK_LATENCY_PRIO();
+    __shared__ uint4 smem[16];
+    const SumChunk c = chunks[blockIdx.x];
+    fe acc = fe_zero();
+    for (u32 t = c.begin + threadIdx.x; t < c.end; t += RED_THREADS) {
+        fe x = fe_load(W + extra[2 * t + 1]);
+        if (extra[2 * t] != NONE) x = fe_mulx(fe_load(K + extra[2 * t]), x);
+        acc = fe_add(acc, x);
+    }
+    wide w[1] = {wide_zero()};
+    wide_add_fe(w[0], acc);
+    const fe sum = block_reduce_wide<1>(w, smem);
+    if (threadIdx.x == 0) fe_store(partials + blockIdx.x, sum);
+}
+__global__ __launch_bounds__(RED_THREADS) void heavy_sum_final_kernel(const HeavySum* __restrict__ sums, const fe* __restrict__ partials, u32 chunk_base,
+                                                                      fe* __restrict__ W, unsigned char* __restrict__ is_set) {
+    PK_LATENCY_PRIO();
+    __shared__ uint4 smem[16];
+    const HeavySum hs = sums[blockIdx.x];
+    fe acc = fe_zero();
+    for (u32 j = threadIdx.x; j < hs.n_chunks; j += RED_THREADS) acc = fe_add(acc, fe_load(partials + (hs.chunk0 - chunk_base) + j));
+    wide w[1] = {wide_zero()};
+    wide_add_fe(w[0], acc);
+    const fe sum = block_reduce_wide<1>(w, smem);
+    if (threadIdx.x == 0) {
+        fe_store(W + hs.out, sum);
+        is_set[hs.out] = 1;
+    }
+}
+
 // ---- postcard(Vec<WitnessBuilder>) ---------------------------------------------------------------------------------------------
 constexpr uint64_t PK_MAX_WITNESS_INDEX = 1ull << 27;
 struct Reader {
@@ -285,6 +329,9 @@ struct Program {
     std::vector<fe> consts;         // Montgomery
     std::vector<u32> extra;
     std::vector<SpiceBlock> spice;  // sorted by level
+    std::vector<HeavySum> heavy_sums;  // sorted by level; their chunks in the same order
+    std::vector<SumChunk> sum_chunks;
+    std::vector<std::pair<u32, u32>> heavy_terms;  // per heavy sum before sorting: (first term, number of terms)
     size_t n_counts = 0;
     std::string error;
 };
@@ -293,7 +340,7 @@ struct Parsed {  // a builder before levelling
     std::vector<u32> reads, writes;
     std::vector<u32> copies;  // witnesses copied as Options, not unwrapped (Spice values): None is legal and stays None
     std::vector<WbItem> main, second;  // second = the phase after main (COUNT_OUT)
-    int spice = -1;
+    int spice = -1, heavy_sum = -1;
 };
 
 u32 add_const(Program& P, const fe& canon) {
@@ -370,7 +417,13 @@ bool parse_builder(Reader& rd, Program& P, u32 bi, Parsed& b) {
                 P.extra.push_back(coef);
                 P.extra.push_back(w);
             }
-            b.main.push_back(it);
+            if (n > SUM_HEAVY) {  // summed by workgroups between the two phases of its level, not by one lane
+                b.heavy_sum = (int)P.heavy_sums.size();
+                P.heavy_sums.push_back(HeavySum{bi, 0, it.out, 0, 0});
+                P.heavy_terms.push_back({it.w[0] / 2, (u32)n});
+            } else {
+                b.main.push_back(it);
+            }
             break;
         }
         case 3: {  // Product(idx, a, b)
@@ -613,6 +666,7 @@ bool build_program(const uint8_t* bytes, size_t len, Program& P, size_t* consume
         level[i] = lv;
         max_level = std::max(max_level, lv);
         if (B[i].spice >= 0) P.spice[(size_t)B[i].spice].level = lv;
+        if (B[i].heavy_sum >= 0) P.heavy_sums[(size_t)B[i].heavy_sum].level = lv;
     }
     // a None copied by a Spice block must still be None when the block runs here, whatever the level order: refuse the (contrived)
     // list in which a LATER builder solves it
@@ -643,6 +697,21 @@ bool build_program(const uint8_t* bytes, size_t len, Program& P, size_t* consume
         std::stable_sort(P.items.begin() + P.phase_begin[ph], P.items.begin() + P.phase_begin[ph + 1],
                          [](const WbItem& a, const WbItem& b) { return a.op < b.op; });
     std::stable_sort(P.spice.begin(), P.spice.end(), [](const SpiceBlock& a, const SpiceBlock& b) { return a.level < b.level; });
+    {  // heavy sums by level, each with its chunks (consecutive, in the sums' order)
+        std::vector<size_t> order(P.heavy_sums.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return P.heavy_sums[a].level < P.heavy_sums[b].level; });
+        std::vector<HeavySum> sorted;
+        for (size_t i : order) {
+            HeavySum hs = P.heavy_sums[i];
+            const u32 t0 = P.heavy_terms[i].first, n = P.heavy_terms[i].second;
+            hs.chunk0 = (u32)P.sum_chunks.size();
+            for (u32 t = 0; t < n; t += SUM_CHUNK) P.sum_chunks.push_back(SumChunk{t0 + t, t0 + std::min(n, t + SUM_CHUNK)});
+            hs.n_chunks = (u32)P.sum_chunks.size() - hs.chunk0;
+            sorted.push_back(hs);
+        }
+        P.heavy_sums.swap(sorted);
+    }
     return true;
 }
 
@@ -657,6 +726,9 @@ struct pk_witness_program {
     u32* d_counts = nullptr;
     unsigned long long* d_err = nullptr;
     std::vector<SpiceOp*> d_spice_ops;
+    HeavySum* d_heavy_sums = nullptr;
+    SumChunk* d_sum_chunks = nullptr;
+    fe* d_sum_partials = nullptr;
     unsigned long long *d_keys = nullptr, *d_sorted = nullptr;  // sized for the longest Spice block
     void* d_sort_tmp = nullptr;
     size_t sort_tmp_bytes = 0;
@@ -683,6 +755,9 @@ int pk_witness_program_destroy(pk_ctx* ctx, pk_witness_program* p) {
     (void)hipFree(p->d_counts);
     (void)hipFree(p->d_err);
     for (auto q : p->d_spice_ops) (void)hipFree(q);
+    (void)hipFree(p->d_heavy_sums);
+    (void)hipFree(p->d_sum_chunks);
+    (void)hipFree(p->d_sum_partials);
     (void)hipFree(p->d_keys);
     (void)hipFree(p->d_sorted);
     (void)hipFree(p->d_sort_tmp);
@@ -741,6 +816,10 @@ int pk_witness_builders_from_postcard(pk_ctx* ctx, const uint8_t* bytes, size_t 
               up((void**)&p->d_phase_begin, P.phase_begin.data(), P.phase_begin.size() * 4) && up((void**)&p->d_consts, P.consts.data(), P.consts.size() * 32) &&
               up((void**)&p->d_extra, P.extra.data(), P.extra.size() * 4) && hipMalloc((void**)&p->d_counts, (P.n_counts ? P.n_counts : 1) * 4) == hipSuccess &&
               hipMalloc((void**)&p->d_err, 8) == hipSuccess;
+    if (!P.heavy_sums.empty())
+        ok = ok && up((void**)&p->d_heavy_sums, P.heavy_sums.data(), P.heavy_sums.size() * sizeof(HeavySum)) &&
+             up((void**)&p->d_sum_chunks, P.sum_chunks.data(), P.sum_chunks.size() * sizeof(SumChunk)) &&
+             hipMalloc((void**)&p->d_sum_partials, P.sum_chunks.size() * 32) == hipSuccess;
     size_t longest = 0;
     for (auto& sb : P.spice) {
         SpiceOp* d = nullptr;
@@ -783,7 +862,10 @@ int pk_witness_solve(pk_ctx* ctx, pk_witness_program* p, const uint64_t* d_acir,
     PK_HIP(ctx, hipMemsetAsync(p->d_err, 0xff, 8, ctx->stream));
     fe* W = (fe*)d_witness;
     const size_t n_phases = P.phase_begin.size() - 1;
-    size_t sp = 0;  // next Spice block
+    size_t sp = 0, hs = 0;  // next Spice block, next heavy sum
+    auto block_at = [&](size_t phase) {  // does a Spice block or a heavy sum run right before this (odd) phase?
+        return (phase & 1) == 1 && ((sp < P.spice.size() && P.spice[sp].level == phase / 2) || (hs < P.heavy_sums.size() && P.heavy_sums[hs].level == phase / 2));
+    };
     {
         ProfScope prof(ctx, "witness_builders");
         for (size_t ph = 0; ph < n_phases;) {
@@ -804,15 +886,21 @@ int pk_witness_solve(pk_ctx* ctx, pk_witness_program* p, const uint64_t* d_acir,
                     }
                 }
             }
+            if ((ph & 1) == 1 && hs < P.heavy_sums.size() && P.heavy_sums[hs].level == ph / 2) {  // the long sums of this level
+                size_t he = hs;
+                while (he < P.heavy_sums.size() && P.heavy_sums[he].level == ph / 2) he++;
+                const u32 c0 = P.heavy_sums[hs].chunk0, c1 = P.heavy_sums[he - 1].chunk0 + P.heavy_sums[he - 1].n_chunks;
+                heavy_sum_part_kernel<<<c1 - c0, RED_THREADS, 0, ctx->stream>>>(p->d_sum_chunks + c0, p->d_extra, W, p->d_consts, p->d_sum_partials + c0);
+                heavy_sum_final_kernel<<<(unsigned)(he - hs), RED_THREADS, 0, ctx->stream>>>(p->d_heavy_sums + hs, p->d_sum_partials + c0, c0, W, d_is_set);
+                hs = he;
+            }
             if (n == 0) {
                 ph++;
                 continue;
             }
             if (n <= NARROW) {  // a run of narrow phases in one launch (no Spice block may fall inside the run)
                 size_t run = 1;
-                while (ph + run < n_phases && P.phase_begin[ph + run + 1] - P.phase_begin[ph + run] <= NARROW &&
-                       !(((ph + run) & 1) == 1 && sp < P.spice.size() && P.spice[sp].level == (ph + run) / 2))
-                    run++;
+                while (ph + run < n_phases && P.phase_begin[ph + run + 1] - P.phase_begin[ph + run] <= NARROW && !block_at(ph + run)) run++;
                 wb_narrow_run_kernel<<<1, NARROW, 0, ctx->stream>>>(p->d_items, p->d_phase_begin, (u32)ph, (u32)run, W, d_is_set, p->d_consts, (const fe*)d_acir, m_chal,
                                                                   p->d_extra, p->d_counts, p->d_err);
                 ph += run;

@@ -220,3 +220,42 @@ def test_fill_witness_draws_one_u128_per_unset_entry(ctx, oracle):
         else:
             assert lib.pk_selftest_chacha((C.c_uint8 * 32).from_buffer_copy(seed), i >> 2, 6, 0, 12, blk) == 0
             assert got[i] == int.from_bytes(bytes(blk)[16 * (i & 3): 16 * (i & 3) + 16], "little"), i
+
+
+def test_long_sums_are_summed_by_workgroups(ctx, oracle):
+    """Sum builders with 128 / 129 / 1024 / 1025 / 5000 / 70000 terms (a LogUp grand sum has a term per lookup): above 128 terms
+    the sum leaves the per-lane item list (csrc/witness.hip "long sums"); values, levels (a long sum of long sums, consumers one
+    level up) and the None pattern still equal the sequential solver's"""
+    import random
+
+    import witness_ref as R
+
+    from provekit_amd.witness import WitnessBuilder as WB, inspect_witness_builders, encode_witness_builders
+
+    rnd = random.Random(21)
+    n_in = 3000
+    acir = [rnd.randrange(R.P) for _ in range(n_in)]
+    b = [WB.Acir(i, i) for i in range(n_in)]
+    nxt = n_in
+    sums = []
+    for n_terms in (128, 129, 1024, 1025, 5000, 70000):
+        terms = [(None if rnd.random() < 0.3 else rnd.randrange(R.P), rnd.randrange(n_in)) for _ in range(n_terms)]
+        b.append(WB.Sum(nxt, terms))
+        sums.append(nxt)
+        nxt += 1
+    # products of the sums (consumers one level up), then a long sum over those products and the first sums again
+    prods = []
+    for s_ in sums:
+        b.append(WB.Product(nxt, s_, rnd.randrange(n_in)))
+        prods.append(nxt)
+        nxt += 1
+    terms = [(rnd.randrange(R.P), rnd.choice(sums + prods + list(range(n_in)))) for _ in range(300)] + [(3, prods[-1]), (None, sums[1])]
+    b.append(WB.Sum(nxt, terms))
+    top = nxt
+    nxt += 1
+    b.append(WB.Inverse(nxt, top))
+    nxt += 2  # one witness nobody writes
+    info = inspect_witness_builders(encode_witness_builders(b))
+    assert info["n_levels"] == 5 and info["n_items"] == len(b) - 6  # the six sums above 128 terms are not items
+    want = _check(ctx, oracle, b, acir, [], nxt)
+    assert want[-1] is None and want[top] == sum((1 if c is None else c) * want[i] for c, i in terms) % R.P

@@ -34,6 +34,7 @@ kinds = {
     "logup": lambda i: WB.LogUpDenominator(i, pick(), fe(), pick()),
     "const": lambda i: WB.Constant(i, fe()),
 }
+LONG = 1 << 17  # one Sum of 2^17 terms (a LogUp grand sum): a single builder, not N of them
 mixes = {}
 for k in (1, 8, 64, 512, 4096):
     def mk(i, k=k, chosen={}):
@@ -42,9 +43,13 @@ for k in (1, 8, 64, 512, 4096):
         return WB.Inverse(i, pick()) if i in chosen[k] else rnd.choice([kinds["product"], kinds["sum5"], kinds["logup"], kinds["prod_linear"]])(i)
     mixes[f"mixed, {k} inverses"] = mk
 kinds.update(mixes)
+kinds["one sum of 2^17 terms"] = None
 for name, mk in kinds.items():
     b = [WB.Acir(i, i) for i in range(n_in)]
-    if name != "none":
+    if mk is None:
+        b.append(WB.Sum(n_in, [(fe(), pick()) for _ in range(LONG)]))
+        b += [WB.Constant(n_in + 1 + i, 1) for i in range(N - 1)]
+    elif name != "none":
         b += [mk(n_in + i) for i in range(N)]
     nw = n_in + N
     prog = WitnessProgram(ctx, b)
