@@ -29,8 +29,9 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 
 def synth_r1cs(ctx, m_0, n_wit, seed):
     """R1CS-shaped synthetic instance, SATISFIABLE by construction: 3/4 * 2^m_0 constraints
-    (sum a z)(sum b z) = z[out_i] with ~3 entries per row in A and B over the inputs, C selecting a fresh output per row, small
-    interned coefficients; built vectorised.  -> (R1CS, mats, interner, num_constraints, n_in)"""
+    (sum a z)(sum b z) = z[out_i] with 3 entries per row in A and B over the inputs -- one of them the constant-one witness in
+    half of the rows, so its column has ~2^18.6 entries like a real system's -- C selecting a fresh output per row, small interned
+    coefficients; built vectorised.  -> (R1CS, mats, interner, num_constraints, n_in)"""
     from provekit_amd.field import ints_to_limbs
     from provekit_amd.sparse_matrix import R1CS, SparseMatrix
 
@@ -41,6 +42,7 @@ def synth_r1cs(ctx, m_0, n_wit, seed):
     mats = []
     for _ in range(2):
         base = np.sort(rng.integers(0, 1 + n_in - 2, size=(nc, 3), dtype=np.int64), axis=1) + np.arange(3)
+        base[rng.random(nc) < 0.5, 0] = 0  # a constant term in half of the rows: the constant-one witness' column is as heavy as in a real system
         nri = (np.arange(nc, dtype=np.uint32) * 3).astype(np.uint32)
         mats.append(SparseMatrix(nc, n_wit, nri, base.reshape(-1).astype(np.uint32), rng.integers(0, 16, size=3 * nc).astype(np.uint32)))
     mats.append(SparseMatrix(nc, n_wit, np.arange(nc, dtype=np.uint32), (1 + n_in + np.arange(nc)).astype(np.uint32), np.zeros(nc, dtype=np.uint32)))
@@ -565,7 +567,7 @@ def main():
             "dtype": "u32x8 (BN254-Fr, 256-bit Montgomery integers)",
             "data": "synthetic",
             "config": {
-                "workload": f"poseidon-rounds size class: m={m}, m_0={m_0}, satisfiable synthetic R1CS ({nc} constraints, {n_wit} witnesses), batch-2 WHIR commit + zk-sumcheck + {cfg_w.n_rounds}-round WHIR opening, "
+                "workload": f"poseidon-rounds size class: m={m}, m_0={m_0}, satisfiable synthetic R1CS ({nc} constraints, {n_wit} witnesses, a constant term in half of the rows of A and B), batch-2 WHIR commit + zk-sumcheck + {cfg_w.n_rounds}-round WHIR opening, "
                             f"queries {cfg_w.num_queries}/{cfg_w.final_queries}, pow_bits {cfg_w.pow_bits}/{cfg_w.final_pow_bits} (WhirConfig::new derivation, security 128, "
                             f"ConjectureList), blinding WHIR n={cfg_b.n_vars} queries {cfg_b.num_queries}/{cfg_b.final_queries}, Skyscraper-sponge transcript, ChaCha12 masks",
                 "proofs_per_step": conc * (1 if args.sharded else world),
