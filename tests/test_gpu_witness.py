@@ -259,3 +259,29 @@ def test_long_sums_are_summed_by_workgroups(ctx, oracle):
     assert info["n_levels"] == 5 and info["n_items"] == len(b) - 6  # the six sums above 128 terms are not items
     want = _check(ctx, oracle, b, acir, [], nxt)
     assert want[-1] is None and want[top] == sum((1 if c is None else c) * want[i] for c, i in terms) % R.P
+
+
+def test_a_large_spice_block(ctx, oracle):
+    """60 k loads / stores over 4096 cells (the radix sort spans many workgroups; cells hit dozens of times, some never): read
+    timestamps, old values, final values and final timestamps equal the sequential replay's"""
+    import random
+
+    from provekit_amd.witness import WitnessBuilder as WB
+
+    rnd = random.Random(8)
+    M, K = 4096, 60000
+    acir = [rnd.randrange(M) if rnd.random() < 0.97 else rnd.randrange(16) for _ in range(K)] + [rnd.randrange(1 << 200) for _ in range(K + M)]
+    b = [WB.Acir(i, i) for i in range(2 * K + M)]  # 0..K-1 addresses, K..2K-1 values to store / loaded values, 2K..2K+M-1 initial memory
+    nxt = 2 * K + M
+    ops = []
+    for k in range(K):
+        if rnd.random() < 0.5:
+            ops.append(("load", k, K + k, nxt))
+            nxt += 1
+        else:
+            ops.append(("store", k, nxt, K + k, nxt + 1))
+            nxt += 2
+    rv, rt = nxt, nxt + M
+    b.append(WB.SpiceWitnesses(M, 2 * K, ops, rv, rt))
+    want = _check(ctx, oracle, b, acir, [], rt + M)
+    assert want[rt + M - 1] is not None and max(want[rt : rt + M]) > 50000
