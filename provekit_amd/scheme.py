@@ -123,7 +123,7 @@ class WhirR1CSScheme:
     def prove(self, d_witness, seed=None) -> bytes:
         """-> WhirR1CSProof.transcript.  seed=None: fresh OS randomness per proof (as the reference's thread_rng)."""
         n = self.prove_nocopy(d_witness, seed)
-        return bytes(self._buf[:n])
+        return C.string_at(self._buf, n)
 
     def prove_nocopy(self, d_witness, seed=None) -> int:
         """prove and return only the transcript length (bench loop: no Python-side copy)"""
@@ -137,6 +137,10 @@ class WhirR1CSScheme:
         """NoirProofSchemeProver::prove after ACVM execution (noir_proof_scheme.rs:63-92): witness transcript -> witness builders ->
         fill_witness -> prove, all on the device.  builders: provekit_amd.witness.WitnessProgram; d_acir: the ACIR witness map
         as a dense device array (Montgomery) indexed by ACIR witness index; public_acir_idx: Circuit::public_inputs().indices()."""
+        return C.string_at(self._buf, self.noir_prove_nocopy(builders, d_acir, n_acir, public_acir_idx, seed))
+
+    def noir_prove_nocopy(self, builders, d_acir, n_acir: int, public_acir_idx=(), seed=None) -> int:
+        """noir_prove, returning only the transcript length (timing loops: no Python-side copy)"""
         import numpy as np
 
         idx = np.ascontiguousarray(public_acir_idx, dtype=np.uint32)
@@ -144,4 +148,4 @@ class WhirR1CSScheme:
         ptr = d_acir.ptr if isinstance(d_acir, DeviceBuffer) else d_acir
         self.ctx._check(lib.pk_noir_prove(self.ctx.handle, self.handle, builders.handle, ptr, n_acir, idx.ctypes.data if len(idx) else None, len(idx),
                                           self._seed_arg(seed), self._buf, len(self._buf), C.byref(n)))
-        return bytes(self._buf[: n.value])
+        return n.value

@@ -72,7 +72,7 @@ def run(kind):
         c, r1cs, s, prog, d_acir = workers[w]
         for i in range(per):
             if kind == "noir":
-                s.noir_prove(prog, d_acir, len(acir), pub_idx, seed=100 + i)
+                s.noir_prove_nocopy(prog, d_acir, len(acir), pub_idx, seed=100 + i)
             else:
                 s.prove_nocopy(d_ws[w], seed=100 + i)
 
@@ -91,7 +91,7 @@ def single(kind, reps=5):
     for i in range(reps):
         t0 = time.perf_counter()
         if kind == "noir":
-            s.noir_prove(prog, d_acir, len(acir), pub_idx, seed=200 + i)
+            s.noir_prove_nocopy(prog, d_acir, len(acir), pub_idx, seed=200 + i)
         else:
             s.prove_nocopy(d_ws[0], seed=200 + i)
         best = min(best, time.perf_counter() - t0)
