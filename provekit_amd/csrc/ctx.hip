@@ -36,6 +36,7 @@ int pk_ctx_create(int device, pk_ctx** out) {
         return PK_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    pk::ntt_retain_ctx(ctx);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
         ctx->num_cus = prop.multiProcessorCount;

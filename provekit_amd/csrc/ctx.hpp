@@ -175,6 +175,7 @@ void comm_release(pk_ctx* ctx);
 int eval_univariate_multi(pk_ctx* ctx, const uint64_t* const* d_polys, unsigned np, size_t n, const uint64_t z[4], uint64_t* out);  // mle.hip
 int dot_rows(pk_ctx* ctx, const uint64_t* d_w, size_t row_stride, unsigned nrows, const uint64_t* d_f, const uint64_t* d_g, size_t n, uint64_t* out);
 int pow_solve_x(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t* nonce, bool striped);  // pow.hip
-void ntt_release_ctx(pk_ctx* ctx);  // ntt.hip: frees the per-context twiddle tables
+void ntt_retain_ctx(pk_ctx* ctx);   // ntt.hip: one more context on this device shares its twiddle tables
+void ntt_release_ctx(pk_ctx* ctx);  // ntt.hip: the context lets go of the device's twiddle tables (freed with the last context)
 
 }  // namespace pk

@@ -22,6 +22,7 @@
 //   n = n1*R2*R3 + n2*R3 + n3,   k = k1 + R1*k2 + R1*R2*k3.
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include <atomic>
@@ -472,25 +473,66 @@ __global__ __launch_bounds__(256) void ntt_shard_prestep_kernel(const fe* __rest
     }
 }
 
+// ---- twiddle tables shared by the contexts of a device --------------------------------------------------------------------------
+// Sixteen provers on one GPU used to hold sixteen copies of every table (71 MB each at the poseidon size): 1.1 GB of identical
+// twiddles competing for the 256 MiB Infinity Cache.  The tables are pure functions of their key, so one copy per device serves
+// every context: built once under the store's mutex (the building context drains its stream before the table is published),
+// kept until the last context of the device is destroyed.  A context remembers the pointers it has looked up (its own maps), so
+// the hot path takes no lock.
+struct TableStore {
+    std::mutex mu;
+    std::map<unsigned long long, void*> tables;
+    unsigned contexts = 0;
+};
+TableStore& store_of(int device) {
+    static TableStore stores[64];
+    return stores[device & 63];
+}
+enum TableKind : unsigned long long { TK_W = 1, TK_WS = 2, TK_W29 = 3, TK_WS29 = 4, TK_PASS = 5 };
+// looks `key` up in the device's store; on a miss `build` allocates and fills the table on ctx->stream
+template <class Build>
+int shared_table(pk_ctx* ctx, unsigned long long key, void** out, Build build) {
+    TableStore& S = store_of(ctx->device);
+    std::lock_guard<std::mutex> lock(S.mu);
+    auto it = S.tables.find(key);
+    if (it != S.tables.end()) {
+        *out = it->second;
+        return PK_OK;
+    }
+    void* T = nullptr;
+    int rc = build(&T);
+    if (rc) return rc;
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // complete before another context's stream may read it
+    S.tables[key] = T;
+    *out = T;
+    return PK_OK;
+}
+
 int get_twiddles(pk_ctx* ctx, unsigned log_n, const fe** out) {
-    // per-context cache (a pk_ctx is single-caller, so no locking; distinct contexts never share tables)
+    // the context's own map of pointers already looked up (a pk_ctx is single-caller: no locking on this path)
     auto it = ctx->twiddles.find(log_n);
     if (it != ctx->twiddles.end()) {
         *out = (const fe*)it->second;
         return PK_OK;
     }
-    size_t n = (size_t)1 << log_n;
-    fe* W = nullptr;
-    PK_HIP(ctx, hipMalloc((void**)&W, 32 * (n < 2 ? 2 : n)));
-    twiddle_init_kernel<<<1, 64, 0, ctx->stream>>>(W, log_n);
-    for (size_t h = 2; h < n; h <<= 1) {
-        twiddle_seed_kernel<<<1, 64, 0, ctx->stream>>>(W, h);
-        unsigned grid = (unsigned)((h + 255) / 256);
-        twiddle_double_kernel<<<grid, 256, 0, ctx->stream>>>(W, h);
-    }
-    PK_LAUNCH_CHECK(ctx);
-    ctx->twiddles[log_n] = W;
-    *out = W;
+    void* T = nullptr;
+    int rc = shared_table(ctx, (TK_W << 56) | log_n, &T, [&](void** made) {
+        size_t n = (size_t)1 << log_n;
+        fe* W = nullptr;
+        PK_HIP(ctx, hipMalloc((void**)&W, 32 * (n < 2 ? 2 : n)));
+        twiddle_init_kernel<<<1, 64, 0, ctx->stream>>>(W, log_n);
+        for (size_t h = 2; h < n; h <<= 1) {
+            twiddle_seed_kernel<<<1, 64, 0, ctx->stream>>>(W, h);
+            unsigned grid = (unsigned)((h + 255) / 256);
+            twiddle_double_kernel<<<grid, 256, 0, ctx->stream>>>(W, h);
+        }
+        PK_LAUNCH_CHECK(ctx);
+        *made = W;
+        return (int)PK_OK;
+    });
+    if (rc) return rc;
+    ctx->twiddles[log_n] = T;
+    *out = (const fe*)T;
     return PK_OK;
 }
 
@@ -500,13 +542,19 @@ int get_twiddles_scaled(pk_ctx* ctx, unsigned log_n, const fe* W, const fe** out
         *out = (const fe*)it->second;
         return PK_OK;
     }
-    const size_t n = (size_t)1 << log_n;
-    fe* Ws = nullptr;
-    PK_HIP(ctx, hipMalloc((void**)&Ws, 32 * (n < 2 ? 2 : n)));
-    twiddle_scale_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(W, Ws, n);
-    PK_LAUNCH_CHECK(ctx);
-    ctx->twiddles_scaled[log_n] = Ws;
-    *out = Ws;
+    void* T = nullptr;
+    int rc = shared_table(ctx, (TK_WS << 56) | log_n, &T, [&](void** made) {
+        const size_t n = (size_t)1 << log_n;
+        fe* Ws = nullptr;
+        PK_HIP(ctx, hipMalloc((void**)&Ws, 32 * (n < 2 ? 2 : n)));
+        twiddle_scale_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(W, Ws, n);
+        PK_LAUNCH_CHECK(ctx);
+        *made = Ws;
+        return (int)PK_OK;
+    });
+    if (rc) return rc;
+    ctx->twiddles_scaled[log_n] = T;
+    *out = (const fe*)T;
     return PK_OK;
 }
 
@@ -517,13 +565,19 @@ int get_twiddles29(pk_ctx* ctx, unsigned log_n, int which, const fe* W, const u3
         *out = (const u32*)it->second;
         return PK_OK;
     }
-    const size_t n = (size_t)1 << log_n;
-    u32* T = nullptr;
-    PK_HIP(ctx, hipMalloc((void**)&T, 36 * (n < 2 ? 2 : n)));
-    twiddle_unpack_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(W, T, n);
-    PK_LAUNCH_CHECK(ctx);
+    void* T = nullptr;
+    int rc = shared_table(ctx, ((which ? TK_WS29 : TK_W29) << 56) | log_n, &T, [&](void** made) {
+        const size_t n = (size_t)1 << log_n;
+        u32* U = nullptr;
+        PK_HIP(ctx, hipMalloc((void**)&U, 36 * (n < 2 ? 2 : n)));
+        twiddle_unpack_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(W, U, n);
+        PK_LAUNCH_CHECK(ctx);
+        *made = U;
+        return (int)PK_OK;
+    });
+    if (rc) return rc;
     cache[log_n] = T;
-    *out = T;
+    *out = (const u32*)T;
     return PK_OK;
 }
 
@@ -539,13 +593,19 @@ int get_pass_table(pk_ctx* ctx, unsigned log_n, unsigned pass, bool scaled, cons
         *out = (const u32*)it->second;
         return PK_OK;
     }
-    u32* T = nullptr;
-    const size_t n = rows_k * row;
-    PK_HIP(ctx, hipMalloc((void**)&T, 36 * n));
-    twiddle_pass_table_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(src29, T, rows_k, row, mul, ((size_t)1 << log_n) - 1);
-    PK_LAUNCH_CHECK(ctx);
+    void* T = nullptr;
+    int rc = shared_table(ctx, (TK_PASS << 56) | key, &T, [&](void** made) {
+        u32* U = nullptr;
+        const size_t n = rows_k * row;
+        PK_HIP(ctx, hipMalloc((void**)&U, 36 * n));
+        twiddle_pass_table_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(src29, U, rows_k, row, mul, ((size_t)1 << log_n) - 1);
+        PK_LAUNCH_CHECK(ctx);
+        *made = U;
+        return (int)PK_OK;
+    });
+    if (rc) return rc;
     ctx->twiddles_pass[key] = T;
-    *out = T;
+    *out = (const u32*)T;
     return PK_OK;
 }
 
@@ -619,17 +679,23 @@ int launch_pass(pk_ctx* ctx, unsigned log_r, const PassParams& p, bool in_r_cont
 
 namespace pk {
 
+void ntt_retain_ctx(pk_ctx* ctx) {
+    TableStore& S = store_of(ctx->device);
+    std::lock_guard<std::mutex> lock(S.mu);
+    S.contexts++;
+}
+// the context forgets its pointers; the device's tables go with its last context
 void ntt_release_ctx(pk_ctx* ctx) {
-    for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
     ctx->twiddles.clear();
-    for (auto& kv : ctx->twiddles_scaled) (void)hipFree(kv.second);
     ctx->twiddles_scaled.clear();
-    for (auto& c : ctx->twiddles29) {
-        for (auto& kv : c) (void)hipFree(kv.second);
-        c.clear();
-    }
-    for (auto& kv : ctx->twiddles_pass) (void)hipFree(kv.second);
+    for (auto& c : ctx->twiddles29) c.clear();
     ctx->twiddles_pass.clear();
+    TableStore& S = store_of(ctx->device);
+    std::lock_guard<std::mutex> lock(S.mu);
+    if (S.contexts && --S.contexts == 0) {
+        for (auto& kv : S.tables) (void)hipFree(kv.second);
+        S.tables.clear();
+    }
 }
 
 // Can a transform of this size deliver the hash-ready output (every output = 32 * value as a plain integer < p instead of
