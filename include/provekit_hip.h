@@ -250,7 +250,10 @@ int pk_fe_axpy(pk_ctx *ctx, uint64_t *d_y, const uint64_t *beta, const uint64_t 
 /* ------------------------------------------------------------------ S1 / S4: R1CS sparse products
  * pk_sparse_matrix mirrors provekit_common::SparseMatrix (provekit/common/src/sparse_matrix.rs:12-27):
  * new_row_indices[num_rows] = offset of each row's first entry, col_indices[nnz], values[nnz] =
- * indices into the Interner's table of distinct field elements (interner.rs).  mats = {A, B, C}. */
+ * indices into the Interner's table of distinct field elements (interner.rs).  mats = {A, B, C}.
+ * A pk_r1cs is immutable once created: every context of its device may use it (one upload serves all the prover threads of a
+ * GPU); destroy it after the schemes that were bound to it.  Rows and columns longer than 64 entries -- the constant-one
+ * witness' column, a grand sum's row -- are summed by workgroups instead of one lane; nothing for the caller to do. */
 typedef struct pk_sparse_matrix {
     const uint32_t *new_row_indices;
     const uint32_t *col_indices;

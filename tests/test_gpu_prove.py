@@ -297,6 +297,52 @@ def test_concurrent_provers_are_deterministic(oracle):
         c.close()
 
 
+def test_one_r1cs_upload_serves_every_context_of_the_device(oracle):
+    """a pk_r1cs is immutable after creation (the heavy-line sums live in the calling context's workspace): four contexts prove
+    concurrently over ONE uploaded R1CS -- with rows and a column above the heavy threshold -- and agree with the lone prover"""
+    import threading
+
+    import provekit_amd
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS
+    from test_gpu_witness import _mont, _noir_instance
+    from provekit_amd.witness import WitnessProgram
+
+    builders, acir, pub_idx, nw, coeffs, trips = _noir_instance(oracle, 3, n_in=6, n_prod=3000)  # constant column in half the rows
+    nc = trips[0][0][-1] + 1
+    m, m_0 = 13, 12
+    interner = oracle.to_mont(oracle.ints_to_limbs(coeffs))
+    c0 = provekit_amd.Context(0)
+    shared = R1CS(c0, *(to_sparse(nc, nw, t) for t in trips), interner)
+    cfgs = (WhirConfig.for_size(m, 6.0), blinding_config_for(m_0, 6.0))
+
+    def make(c):
+        return c, WhirR1CSScheme(c, shared, m, m_0, *cfgs), WitnessProgram(c, builders), c.upload(_mont(oracle, acir))
+
+    lone = make(c0)
+    seeds = [21, 22, 23]
+    want = [lone[1].noir_prove(lone[2], lone[3], len(acir), pub_idx, seed=sd) for sd in seeds]
+    workers = [make(provekit_amd.Context(0)) for _ in range(4)]
+    got = [None] * 4
+
+    def run(i):
+        _, s, prog, d_acir = workers[i]
+        got[i] = [s.noir_prove(prog, d_acir, len(acir), pub_idx, seed=sd) for sd in seeds]
+
+    ths = [threading.Thread(target=run, args=(i,)) for i in range(4)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert all(g == want for g in got)
+    for c, s, prog, _ in workers + [lone]:
+        prog.close()
+        s.close()
+    shared.close()
+    for c, *_ in workers + [lone]:
+        c.close()
+
+
 @pytest.mark.parametrize("m,m_0,nc,nw", [(10, 12, 4000, 500), (14, 6, 60, 8000), (12, 12, 4096, 2048), (9, 9, 300, 256)])
 def test_scheme_shapes_fit_their_arena(ctx, oracle, m, m_0, nc, nw):
     """pk_scheme_create sizes the proof arena from (m, m_0, rate, batch, fold, num_witnesses): shapes far from m_0 = m - 1
