@@ -485,8 +485,10 @@ struct TableStore {
     unsigned contexts = 0;
 };
 TableStore& store_of(int device) {
-    static TableStore stores[64];
-    return stores[device & 63];
+    static std::mutex mu;
+    static std::map<int, TableStore> stores;  // nodes of a std::map stay where they are
+    std::lock_guard<std::mutex> lock(mu);
+    return stores[device];
 }
 enum TableKind : unsigned long long { TK_W = 1, TK_WS = 2, TK_W29 = 3, TK_WS29 = 4, TK_PASS = 5 };
 // looks `key` up in the device's store; on a miss `build` allocates and fills the table on ctx->stream
