@@ -443,7 +443,7 @@ def main():
     conc = 1 if args.sharded else max(1, args.concurrency)
     # every prover owns an arena of 26 x 32 B x 2^m (+ workspace, R1CS copy): keep the provers within half of the HBM
     per_prover = 40 * 32 * (1 << m)
-    conc = max(1, min(conc, int(0.5 * torch.cuda.get_device_properties(local_rank).total_memory / per_prover)))
+    conc = max(1, min(conc, int(float(os.environ.get("PK_BENCH_HBM_FRACTION", "0.5")) * torch.cuda.get_device_properties(local_rank).total_memory / per_prover)))
     from provekit_amd.device_set import join_device_set, max_over_ranks
 
     workers = []  # (ctx, prover, witness): one independent prover per worker, all on this rank's GPU
