@@ -285,3 +285,59 @@ def test_a_large_spice_block(ctx, oracle):
     b.append(WB.SpiceWitnesses(M, 2 * K, ops, rv, rt))
     want = _check(ctx, oracle, b, acir, [], rt + M)
     assert want[rt + M - 1] is not None and max(want[rt : rt + M]) > 50000
+
+
+def test_noir_prove_at_scale(ctx, oracle):
+    """100 k builders / constraints (m = 18), the constant-one column in half of the rows (heavy lines), a LogUp-style closing: one
+    Sum over 20 k inverses with its one-row constraint (a heavy row and a long sum): the device witness equals the sequential
+    solver's everywhere, satisfies the R1CS, and the one-call proof is accepted by the verifier with the matrices"""
+    import verifier as V
+    import witness_ref as R
+    from test_gpu_prove import to_sparse
+
+    from provekit_amd._lib import lib
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS
+    from provekit_amd.witness import WitnessBuilder as WB, WitnessProgram, fill_witness, witness_challenges
+
+    builders, acir, pub_idx, nw, coeffs, trips = _noir_instance(oracle, 41, n_in=50, n_prod=100000)
+    A, B, Cm = trips
+    # the closing sum: every inverse the list produced, one Sum builder, one constraint  (sum a_i z_i) * 1 = z_out
+    inv = [b[1] for b in builders if b[0] == 7][:20000]
+    out = nw - 3  # the first of the three witnesses nobody wrote
+    builders.append(WB.Sum(out, [(None, i) for i in inv]))
+    row = A[0][-1] + 1
+    for col in sorted(inv):
+        A[0].append(row); A[1].append(col); A[2].append(0)
+    B[0].append(row); B[1].append(0); B[2].append(0)
+    Cm[0].append(row); Cm[1].append(out); Cm[2].append(0)
+    nc = row + 1
+    m, m_0 = 18, 17
+    assert nw <= 1 << (m - 1) and nc <= 1 << m_0
+    r1cs = R1CS(ctx, *(to_sparse(nc, nw, t) for t in trips), oracle.to_mont(oracle.ints_to_limbs(coeffs)))
+    cfg_w, cfg_b = WhirConfig.for_size(m, 8.0), blinding_config_for(m_0, 8.0)
+    scheme = WhirR1CSScheme(ctx, r1cs, m, m_0, cfg_w, cfg_b)
+    prog = WitnessProgram(ctx, builders)
+    d_acir = ctx.upload(_mont(oracle, acir))
+    proof = scheme.noir_prove(prog, d_acir, len(acir), pub_idx, seed=3)
+    # the witness, step by step, against the oracle
+    ch = R.witness_challenges(nc, nw, [acir[i] for i in pub_idx], 2)
+    want = R.solve_witness_vec(builders, acir, ch, nw)
+    d_w, d_set = ctx.alloc_fe(nw), ctx.alloc(nw)
+    chm = _mont(oracle, ch)
+    ctx._check(lib.pk_witness_solve(ctx.handle, prog.handle, d_acir.ptr, len(acir), chm.ctypes.data, 2, d_w.ptr, nw, d_set.ptr))
+    assert fill_witness(ctx, d_w, d_set, nw, seed=3) == 2
+    z = oracle.limbs_to_ints(oracle.from_mont(ctx.download_fe(d_w, nw)))
+    assert [zi for zi, x in zip(z, want) if x is not None] == [x for x in want if x is not None]
+    assert r1cs.test_witness_satisfaction(d_w) is None
+    assert scheme.prove(d_w, seed=3) == proof
+
+    def vcfg(c):
+        return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
+
+    mats = [(t[0], t[1], [coeffs[v] for v in t[2]]) for t in trips]
+    assert V.verify(proof, scheme.domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b), r1cs=(nc, nw, mats))
+    prog.close()
+    scheme.close()
+    r1cs.close()
