@@ -1,10 +1,12 @@
 // feinv.hpp -- modular inverse in BN254-Fr for one lane: Bernstein-Yang "safegcd" division steps (eprint 2019/266) in the
 // half-delta form, 30 steps per batch on 32-bit words, the transition matrix applied to (f, g) and, modulo p, to (d, e) on nine
-// signed 30-bit limbs.  20 batches = 600 steps (590 suffice for any 256-bit input).  Every lane runs the same instruction
-// sequence whatever its operand, so a wavefront never diverges; ~17 k instructions against ~114 k for x^(p-2) (253 squarings +
-// 125 products of ~300 instructions each), which is what bounds the latency of a witness-builder level that holds one Inverse
-// (witness_builder.rs:66-69: `operand.inverse().unwrap()`).  The inverse of a field element is unique, so any correct algorithm
-// is bit-identical to ark-ff's.
+// signed 30-bit limbs.  Two forms.  fe_inverse_plain: 20 batches = 600 steps (590 suffice for any 256-bit input), every lane the
+// same instruction sequence whatever its operand -- ~17 k instructions against ~114 k for x^(p-2) (253 squarings + 125 products
+// of ~300 instructions each).  fe_inverse_plain_var: the steps of a batch in variable time (zero runs shifted at once, up to six
+// bits cancelled per odd step: ~8 iterations instead of 30) until g = 0, ~8 k instructions; the lanes of a wavefront differ by a
+// few iterations.  ark-ff's own inverse is variable-time too.  The latency of an inversion is what a witness-builder level that
+// holds one Inverse costs (witness_builder.rs:66-69: `operand.inverse().unwrap()`).  The inverse of a field element is unique, so
+// any correct algorithm is bit-identical to ark-ff's.
 #pragma once
 #include "fe29.hpp"
 
@@ -62,6 +64,48 @@ PK_HD i32 divsteps30(i32 zeta, u32 f0, u32 g0, trans& t) {
     t.q = (i32)q;
     t.r = (i32)r;
     return zeta;
+}
+
+// The same 30 steps in variable time (classic form, eta = -delta): a run of zero bits of g is one shift, and an odd g loses up to six
+// bits at once to a multiple w f of f, w = -g f^-1 mod 2^k with f^-1 = f (2 - f^2) mod 64 (one Newton step from f f = 1 mod 8),
+// k <= eta + 1 so that no swap falls inside the run.  ~8 iterations instead of 30; lanes of a wavefront differ by a few.
+PK_HD i32 divsteps30_var(i32 eta, u32 f0, u32 g0, trans& t) {
+    u32 u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
+    u32 finv = f * (2u - f * f);  // f^-1 mod 64; f changes only in a swap
+    int i = 30;
+    for (;;) {
+        const int zeros = __builtin_ctz(g | (0xffffffffu << i));  // at most i
+        g >>= zeros;
+        u <<= zeros;
+        v <<= zeros;
+        eta -= zeros;
+        i -= zeros;
+        if (i == 0) break;
+        if (eta < 0) {  // g is odd: swap when delta > 0
+            eta = -eta;
+            u32 x = f;
+            f = g;
+            g = 0u - x;
+            x = u;
+            u = q;
+            q = 0u - x;
+            x = v;
+            v = r;
+            r = 0u - x;
+            finv = f * (2u - f * f);
+        }
+        int limit = eta + 1 > i ? i : eta + 1;
+        if (limit > 6) limit = 6;
+        const u32 w = (0u - g * finv) & ((1u << limit) - 1u);
+        g += f * w;
+        q += u * w;
+        r += v * w;
+    }
+    t.u = (i32)u;
+    t.v = (i32)v;
+    t.q = (i32)q;
+    t.r = (i32)r;
+    return eta;
 }
 
 // (d, e) <- t (d, e) / 2^30 mod p; d, e stay in (-2p, p)
@@ -187,12 +231,38 @@ PK_HD fe fe_inverse_plain(const fe& a) {
     return from_s30(d);
 }
 
+// the same inverse with the variable-time steps: batches until g = 0 (18-19 for this p; 25 bound the classic form at 256 bits)
+PK_HD fe fe_inverse_plain_var(const fe& a) {
+    using namespace inv30;
+    s30 d, e, f, g = to_s30(a);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        d.v[i] = 0;
+        e.v[i] = i == 0;
+        f.v[i] = p_limb(i);
+    }
+    i32 eta = -1;
+#pragma unroll 1
+    for (int it = 0; it < 30; it++) {
+        i32 nz = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) nz |= g.v[i];
+        if (nz == 0) break;
+        trans t;
+        eta = divsteps30_var(eta, (u32)f.v[0], (u32)g.v[0], t);
+        update_de(d, e, t);
+        update_fg(f, g, t);
+    }
+    normalize(d, f.v[8]);
+    return from_s30(d);
+}
+
 // Montgomery in, Montgomery out: (x R)^-1 = x^-1 R^-1, times R^3 through one Montgomery product (a b R^-1) = x^-1 R
 PK_HD fe fe_inverse_mont(const fe& xr) {
     fe r3;  // R^3 mod p
     r3.v[0] = 0xb4bf0040u; r3.v[1] = 0x5e94d8e1u; r3.v[2] = 0x1cfbb6b8u; r3.v[3] = 0x2a489cbeu;
     r3.v[4] = 0xa19fcfedu; r3.v[5] = 0x893cc664u; r3.v[6] = 0x7fcc657cu; r3.v[7] = 0x0cf8594bu;
-    return fe_mulx(fe_inverse_plain(xr), r3);
+    return fe_mulx(fe_inverse_plain_var(xr), r3);
 }
 
 }  // namespace pk

@@ -68,7 +68,8 @@ PK_HD fe selftest_op(int op, const fe& x, const fe& y) {
             break;
         }
         case 21: r = fe_inverse_mont(x); break;   // feinv.hpp: Montgomery in, Montgomery out (0 -> 0)
-        case 22: r = fe_inverse_plain(x); break;  // plain integers mod p
+        case 22: r = fe_inverse_plain(x); break;  // plain integers mod p, constant sequence
+        case 23: r = fe_inverse_plain_var(x); break;  // the same, variable-time steps
         default: break;
     }
     return r;
@@ -368,7 +369,7 @@ int pk_selftest_arith(int op, const uint64_t* a, const uint64_t* b, uint64_t* ou
     if (!a || !out || (!b && (op == 0 || op == 1 || op == 2 || op == 4 || op == 15 || op == 16 || op == 19 || op == 20))) return PK_ERR_BAD_ARG;
     for (size_t i = 0; i < n; i++) {
         fe x = load_host(a + 4 * i), y = b ? load_host(b + 4 * i) : x;
-        if (op < 0 || op > 22) return PK_ERR_BAD_ARG;
+        if (op < 0 || op > 23) return PK_ERR_BAD_ARG;
         fe r = selftest_op(op, x, y);
         store_host(out + 4 * i, r);
     }

@@ -194,7 +194,7 @@ def test_grouped_dot_product(oracle):
 
 def test_safegcd_inverse_is_the_field_inverse(oracle):
     """feinv.hpp (the witness builders' Inverse, witness_builder.rs:66-69) against pow(x, -1, p): plain integers (op 22) and
-    Montgomery in / Montgomery out (op 21); edge values, every bit length, 20 k random elements; 0 -> 0"""
+    Montgomery in / Montgomery out (op 21); both step forms (ops 22, 23); edge values, every bit length, 20 k random elements; 0 -> 0"""
     import random
 
     rnd = random.Random(1)
@@ -203,4 +203,5 @@ def test_safegcd_inverse_is_the_field_inverse(oracle):
     want = [pow(v, -1, P) if v else 0 for v in vals]
     a = oracle.ints_to_limbs(vals)
     assert oracle.limbs_to_ints(run(22, a)) == want
+    assert oracle.limbs_to_ints(run(23, a)) == want  # the variable-time steps (what the witness builders run)
     assert oracle.limbs_to_ints(oracle.from_mont(run(21, oracle.to_mont(a)))) == want

@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("op", list(range(15)) + [21, 22])  # 21 / 22: the safegcd inverse (feinv.hpp)
+@pytest.mark.parametrize("op", list(range(15)) + [21, 22, 23])  # 21-23: the safegcd inverse (feinv.hpp), both step forms
 def test_device_equals_host(ctx, oracle, op):
     from provekit_amd._lib import lib
     from provekit_amd.field import random_field
