@@ -4,7 +4,7 @@ pk_prove on a witness that is already there, at the bench size (m = 21) under th
 built together with its builder list (tests/test_gpu_witness._noir_instance at scale: every constraint is one builder's defining
 equation -- products, inverses, sums -- over inputs, two transcript challenges and earlier outputs), so the proof is of a
 satisfiable instance and the verifier accepts it.  One JSON object.
-usage: python tools/noir_bench.py [n_builders=780000] [concurrency=16] [proofs_per_prover=6]"""
+usage: python tools/noir_bench.py [n_builders=780000] [concurrency=16] [proofs_per_prover=6] [m=21]"""
 import json
 import os
 import sys
@@ -27,7 +27,8 @@ from test_gpu_witness import _mont, _noir_instance  # noqa: E402
 n_builders = int(sys.argv[1]) if len(sys.argv) > 1 else 780000
 conc = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 6
-m, m_0 = 21, 20
+m = int(sys.argv[4]) if len(sys.argv) > 4 else 21
+m_0 = m - 1
 t0 = time.perf_counter()
 builders, acir, pub_idx, nw, coeffs, trips = _noir_instance(oracle, 5, n_in=1000, n_prod=n_builders)
 nc = trips[0][0][-1] + 1
