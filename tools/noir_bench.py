@@ -104,6 +104,21 @@ res = {"m": m, "builders": len(builders), "witnesses": nw, "constraints": nc, "l
        "host_build_s": round(t_build, 1), "provers": conc,
        "prove_proofs_per_s": round(run("prove"), 1), "noir_prove_proofs_per_s": round(run("noir"), 1),
        "prove_single_ms": round(single("prove"), 2), "noir_prove_single_ms": round(single("noir"), 2)}
+# every prover thread must produce the same bytes for the same seed (shared R1CS-independent state: twiddle tables, nothing else)
+agree = [None] * conc
+
+
+def check(w):
+    c, r1cs, s, prog, d_acir = workers[w]
+    agree[w] = [s.noir_prove(prog, d_acir, len(acir), pub_idx, seed=300 + i) for i in range(3)]
+
+
+ths = [threading.Thread(target=check, args=(w,)) for w in range(conc)]
+for t in ths:
+    t.start()
+for t in ths:
+    t.join()
+res["threads_agree"] = all(a == agree[0] for a in agree)
 import verifier as V  # noqa: E402
 
 

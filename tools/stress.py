@@ -36,7 +36,7 @@ az, bz = (oracle.spmv(nc, nw, nri, ci, v, interner, z) for nri, ci, v in mats)
 z[1 + n_in :] = oracle.hadamard(az, bz)
 mats.append((np.arange(nc, dtype=np.uint32), (1 + n_in + np.arange(nc)).astype(np.uint32), np.zeros(nc, dtype=np.uint32)))
 cfg_w, cfg_b = WhirConfig.poseidon_witness(), blinding_config_for(m_0)
-T, SEEDS = 16, list(range(100, 112))
+T, SEEDS = 16, list(range(100, 100 + int(os.environ.get("PK_STRESS_SEEDS", "12"))))
 workers = []
 for _ in range(T):
     c = provekit_amd.Context(0)
