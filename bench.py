@@ -240,13 +240,17 @@ def cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg):
     return dt, o.L.pko_num_threads()
 
 
-def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3):
-    """BASELINE configs[4] on this GPU, as a secondary figure of the default line: one batch-2 WHIR commit of 2^26 seeded
-    coefficients (RS-encode of 2 x 16 NTTs of 2^23 + 2^23 leaf hashes of width 32 + the tree), buffers allocated once,
-    timed with hipEvents on the context's stream.  Algorithmic bytes as BASELINE.md 4."""
+def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3, world=1, dist=None, one_gpu=False):
+    """BASELINE configs[4] as a secondary figure of the default line: one batch-2 WHIR commit of 2^26 seeded coefficients
+    (RS-encode of 2 x 16 NTTs of 2^23 + 2^23 leaf hashes of width 32 + the tree), buffers allocated once.  At world 1 it is
+    timed with hipEvents on the context's stream; at world > 1 `ctx` has joined the run's device set, the commit is SHARDED
+    by leaf index behind the C ABI (rank g encodes and hashes the rows i = g mod G, one all-gather of leaf digests) and the
+    clock is the launcher contract's: barrier, wall time, max over ranks -- so one `--gpus N` run yields both the weak-scaling
+    proofs/s and north_star's strong-scaling commit curve.  Algorithmic bytes as BASELINE.md 4."""
     import ctypes as C
 
     from provekit_amd._lib import lib
+    from provekit_amd.device_set import max_over_ranks
 
     n, rows, width = 1 << n_vars, 1 << (n_vars + 1 - 4), 32
     polys = []
@@ -260,19 +264,93 @@ def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3):
     ctx._check(lib.pk_commit_sizes(ctx.handle, 2, n_vars, 1, 4, *[C.byref(x) for x in szs]))
     leaves, nodes, scratch = (ctx.alloc_fe(x.value) for x in szs)
     root_buf = (C.c_uint8 * 32)()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     ms = []
     for i in range(reps + 1):
-        ctx.timer_start()
-        ctx._check(lib.pk_commit_into(ctx.handle, ptrs, 2, n_vars, 1, 4, leaves.ptr, nodes.ptr, scratch.ptr, root_buf, None))
-        t = ctx.timer_stop()
+        if world > 1:
+            barrier()
+            t0 = time.perf_counter()
+            ctx._check(lib.pk_commit_into(ctx.handle, ptrs, 2, n_vars, 1, 4, leaves.ptr, nodes.ptr, scratch.ptr, root_buf, None))
+            barrier()
+            t = 1e3 * max_over_ranks(time.perf_counter() - t0, dist, None if one_gpu else f"cuda:{local_rank}")
+        else:
+            ctx.timer_start()
+            ctx._check(lib.pk_commit_into(ctx.handle, ptrs, 2, n_vars, 1, 4, leaves.ptr, nodes.ptr, scratch.ptr, root_buf, None))
+            t = ctx.timer_stop()
         if i:
             ms.append(t)
     root = bytes(root_buf).hex()
     alg = 32 * 2 * n + 32 * 2 * 2 * n + 64 * rows
     best = min(ms)
-    return {"workload": f"batch-2 WHIR commit of 2^{n_vars} coefficients (rate 1/2, fold 16): {rows * 31 + rows - 1} compressions, 32 NTTs of 2^{n_vars - 3}",
-            "ms_per_commit": best, "algorithmic_GB": alg / 1e9, "achieved_GBps": alg / (best * 1e-3) / 1e9,
-            "frac_of_hbm_peak": alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, "root": root}
+    how = "one GPU" if world == 1 else (f"sharded by leaf index over {world} ranks, " + ("host-transport (gloo) all-gather, single-GPU development mode" if one_gpu
+                                                                                      else "RCCL all-gather of leaf digests over xGMI") + "; wall clock, max over ranks")
+    return {"workload": f"batch-2 WHIR commit of 2^{n_vars} coefficients (rate 1/2, fold 16): {rows * 31 + rows - 1} compressions, 32 NTTs of 2^{n_vars - 3}; {how}",
+            "n_gpus": world, "scaling": "strong", "ms_per_commit": best, "commits_per_s": 1e3 / best, "algorithmic_GB": alg / 1e9,
+            "achieved_GBps": alg / (best * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (best * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), "root": root}
+
+
+def size_class_probe(provekit_amd, torch, local_rank, m, proofs_per_prover=3):
+    """Secondary figure of the default line: another BASELINE size class (configs[2]: m = 23, configs[3]: m = 25) on this GPU --
+    the reference's own derived WHIR schedule for that size, a satisfiable synthetic R1CS of the same construction as the bench's
+    (ONE statement and witness shared by the provers of the class; masks differ per proof), provers capped at half the HBM.
+    A handful of proofs each: throughput with all provers in flight, then one proof at a time."""
+    import threading
+
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+
+    m_0 = m - 1
+    n_wit = (1 << (m - 1)) - 5
+    cfg_w, cfg_b = WhirConfig.derive(m), blinding_config_for(m_0)
+    torch.cuda.empty_cache()  # the commit probe's coefficient tensors
+    free, total = torch.cuda.mem_get_info(local_rank)
+    conc = max(1, min(16, int(min(0.5 * total, 0.8 * free) / (40 * 32 * (1 << m)))))
+    c0 = provekit_amd.Context(local_rank)
+    r1cs, _, _, nc, n_in = synth_r1cs(c0, m_0, n_wit, seed=4321 + m)
+    d_z, z_host = satisfying_witness(c0, r1cs, n_wit, nc, n_in, 7 + m)
+    ctxs = [c0] + [provekit_amd.Context(local_rank) for _ in range(conc - 1)]
+    provers = [WhirR1CSScheme(c, r1cs, m, m_0, cfg_w, cfg_b) for c in ctxs]  # a pk_r1cs is immutable: one upload serves every context
+    wit = [d_z] + [c.upload(z_host) for c in ctxs[1:]]
+
+    def wave(first_seed, per):
+        def work(w):
+            for i in range(per):
+                provers[w].prove_nocopy(wit[w], seed=first_seed + w * per + i)
+
+        ths = [threading.Thread(target=work, args=(w,)) for w in range(conc)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+
+    wave(900000, 1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    wave(1, proofs_per_prover)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    singles = []
+    for i in range(3):
+        t1 = time.perf_counter()
+        provers[0].prove_nocopy(wit[0], seed=77 + i)
+        singles.append(time.perf_counter() - t1)
+    out = {"m": m, "m_0": m_0, "constraints": nc, "witnesses": n_wit, "queries": list(cfg_w.num_queries) + [cfg_w.final_queries],
+           "pow_bits": list(cfg_w.pow_bits) + [cfg_w.final_pow_bits], "provers": conc, "proofs_timed": conc * proofs_per_prover,
+           "proofs_per_s": conc * proofs_per_prover / dt, "single_proof_ms": 1e3 * sorted(singles)[1]}
+    for p in provers:
+        p.close()
+    for w in wit[1:]:
+        w.free()
+    r1cs.close()
+    for c in ctxs:
+        c.close()
+    torch.cuda.empty_cache()
+    return out
 
 
 def commit_workload(args, rank, local_rank, world, dist, torch):
@@ -378,6 +456,10 @@ def main():
                          "--log2-size: the launcher's own parser rejects --m as an ambiguous abbreviation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-commit-probe", action="store_true", help="skip the secondary 2^26 commit figure (configs[4]) of the default line")
+    ap.add_argument("--commit-log2-size", type=int, default=26, help="log2 coefficients of the secondary commit figure (26 = BASELINE configs[4])")
+    ap.add_argument("--size-classes", default="23,25",
+                    help="other BASELINE size classes reported as secondary keys of the default line (configs[2]: 23, configs[3]: 25); '' = none")
+    ap.add_argument("--no-h2d-probe", action="store_true", help="skip the secondary PCIe-inclusive rate (witness uploaded before every proof)")
     ap.add_argument("--workload", choices=["prove", "commit"], default="prove",
                     help="prove = BASELINE configs[1] (default, the judged line); commit = one batch-2 WHIR commit of 2^m coefficients "
                          "(configs[4] with --m 26), SHARDED over the ranks with an all-gather of leaf digests (strong scaling)")
@@ -524,6 +606,48 @@ def main():
             ctx._check(lib.pk_selftest_modmul_rate(ctx.handle, waves, ilp, 2000, C.byref(r)))
             peak_modmul = max(peak_modmul, r.value)
 
+    # ---- secondary figures of the default line (each guarded: none may break the line) -----------------------------------
+    # (a) PCIe-inclusive rate: the same waves with the witness uploaded before every proof
+    h2d_rate = None
+    if not args.h2d and not args.sharded and not args.no_h2d_probe:
+        try:
+            args.h2d = True
+            run_proofs(200000, conc)
+            barrier()
+            t1 = time.perf_counter()
+            run_proofs(300000, 4 * conc)
+            barrier()
+            h2d_rate = world * 4 * conc / max_over_ranks(time.perf_counter() - t1, dist, None if one_gpu else f"cuda:{local_rank}")
+        except Exception as e:  # noqa: BLE001
+            h2d_rate = None
+            print(f"[bench] h2d probe failed: {e}", file=sys.stderr)
+        finally:
+            args.h2d = False
+    # (b) BASELINE configs[4]: the 2^26 commit -- on one GPU, or SHARDED over the ranks of the run (every rank takes part)
+    commit_fig = None
+    if m == 21 and not args.sharded and not args.no_commit_probe:
+        try:
+            cctx, keep = ctx, None
+            if world > 1:
+                cctx = provekit_amd.Context(local_rank)
+                keep = join_device_set(cctx, rank, world, dist, "host" if one_gpu else "rccl")  # noqa: F841 (kept alive)
+            commit_fig = commit_probe(cctx, torch, local_rank, n_vars=args.commit_log2_size, world=world, dist=dist, one_gpu=one_gpu)
+            if world > 1:
+                cctx.comm_destroy()
+                cctx.close()
+        except Exception as e:  # e.g. a GPU with less memory
+            commit_fig = {"error": str(e)[:200]}
+    # (c) the other BASELINE size classes (configs[2] m = 23, configs[3] m = 25), rank 0's GPU only
+    size_figs = {}
+    if rank == 0 and m == 21 and not args.sharded and args.size_classes:
+        for mm in [int(x) for x in args.size_classes.split(",") if x.strip()]:
+            try:
+                size_figs[str(mm)] = size_class_probe(provekit_amd, torch, local_rank, mm)
+            except Exception as e:  # noqa: BLE001
+                size_figs[str(mm)] = {"error": str(e)[:200]}
+    if dist is not None:
+        dist.barrier()
+
     if rank == 0:
         # roofline of the dominant kernel (leaf_hash): algorithmic bytes per launch / measured avg duration
         bytes_step, launches_step, compresses_step = leaf_hash_bytes([(m, 2, cfg_w.n_rounds), (cfg_b.n_vars, 2, cfg_b.n_rounds)])
@@ -621,11 +745,14 @@ def main():
             "single_stream": {"ms_per_proof": 1e3 * iso_dt, "proofs_per_s": 1.0 / iso_dt},
             "stage_ms_per_proof_isolated": stage_ms,
         }
-        if world == 1 and m == 21 and not args.no_commit_probe:
-            try:  # secondary figure; never allowed to break the line
-                line["commit_2p26"] = commit_probe(ctx, torch, local_rank)
-            except Exception as e:  # e.g. a GPU with less memory
-                line["commit_2p26"] = {"error": str(e)[:200]}
+        if h2d_rate is not None:
+            line["h2d_inclusive_proofs_per_s"] = h2d_rate
+            line["h2d_note"] = (f"same workload, {conc} provers, the 32 x {n_wit} B witness uploaded from pageable host memory before every proof; "
+                                "never `value` (inputs are resident when the clock starts)")
+        if commit_fig is not None:
+            line["commit_2p26" if args.commit_log2_size == 26 else f"commit_2p{args.commit_log2_size}"] = commit_fig
+        if size_figs:
+            line["size_classes"] = size_figs
         if not args.no_cpu_baseline and world == 1:
             cdt, threads = cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg_w)
             line["cpu_baseline"] = {
@@ -634,7 +761,8 @@ def main():
                 "cores": threads,
                 "kind": "port",
                 "sample": f"1 proof (a step is {conc} of them) of the same workload (m={m}) through oracle/pk_oracle.c, OpenMP on {threads} threads wherever the reference "
-                          "uses rayon (commit, sumcheck, eq, sums); SpMV serial as in the reference; 2^8 blinding WHIR omitted",
+                          "uses rayon (commit, sumcheck, eq, sums); SpMV serial as in the reference; NOT the whole step: the 2^8 blinding WHIR, the STIR "
+                          "openings (Merkle paths + leaf gathers) and the transcript are omitted, so the real CPU figure is lower still",
             }
         emit(line)
     if dist is not None:

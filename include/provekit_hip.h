@@ -49,6 +49,7 @@ extern "C" {
 #define PK_ERR_RCCL (-4)
 #define PK_ERR_NO_DEVICE (-5)
 #define PK_ERR_UNSATISFIED (-6) /* pk_r1cs_test_witness_satisfaction: a constraint failed */
+#define PK_ERR_IO_PATTERN (-7) /* an IO pattern does not declare the operations the prover performs (spongefish: InvalidIOPattern) */
 
 /* leaf-matrix layouts: element (leaf i, column j) lives at */
 #define PK_LEAF_MAJOR 0 /* i*width + j : ark / whir order (a leaf is contiguous)        */
@@ -402,7 +403,30 @@ int pk_scheme_create(pk_ctx *ctx, const pk_r1cs *r1cs, size_t num_constraints, s
 int pk_scheme_destroy(pk_ctx *ctx, pk_scheme *scheme);
 int pk_prove(pk_ctx *ctx, pk_scheme *scheme, const uint64_t *d_witness, size_t n_witness, const uint8_t *rng_seed32,
              uint8_t *transcript_out, size_t cap, size_t *len);
-/* the spongefish-style domain separator the transcript IV is derived from (labels are this library's) */
+/* The IO pattern (spongefish DomainSeparator) of a proof: WhirR1CSScheme::create_io_pattern(), provekit/common/src/whir_r1cs.rs:28-39.
+ * Its bytes fix the sponge IV (Keccak tag, spongefish HashStateWithInstructions::new) and declare every absorb / squeeze / hint
+ * of the proof, which spongefish checks operation by operation on both sides (prover/src/whir_r1cs.rs:57-58,
+ * verifier/src/whir_r1cs.rs:40-41).
+ *   pk_scheme_set_io_pattern    the drop-in caller hands over `scheme.create_io_pattern().as_bytes()`: the library parses it the way
+ *                               DomainSeparator::finalize does ("\0"-separated <A|S><count><label> / H<label> / R, neighbours merged),
+ *                               REFUSES it (PK_ERR_IO_PATTERN, the first differing operation in pk_last_error) unless it declares
+ *                               exactly the operation sequence pk_prove performs for this scheme, and from then on derives the IV
+ *                               from those bytes -- so the proof is the one the reference's verifier state expects.  NULL / 0
+ *                               restores the library's own restatement.
+ *   pk_whir_r1cs_io_pattern     that restatement (host only, no context): provekit's labels are in the tree, the labels inside
+ *                               whir's commit_statement / add_whir_proof are whir's as published and UNPINNED here except the four
+ *                               hint labels and "pow-nonce", which the in-tree Go verifier's pattern walker names
+ *                               (recursive-verifier/app/circuit/common.go:41-100).  Size query with buf = NULL.
+ *   pk_io_pattern_check         host only: does `pattern` declare pk_prove's operations for (m_0, configs)?  PK_OK, or
+ *                               PK_ERR_IO_PATTERN with the reason in `why`.
+ *   pk_scheme_domain_separator  the bytes currently in force.
+ * pk_prove itself enforces the pattern in force while it writes the proof (PK_ERR_IO_PATTERN if an operation strays: a library
+ * bug, never a caller error). */
+int pk_scheme_set_io_pattern(pk_ctx *ctx, pk_scheme *scheme, const uint8_t *pattern, size_t n);
+int pk_whir_r1cs_io_pattern(unsigned m_0, const pk_whir_config *whir_witness, const pk_whir_config *whir_for_hiding_spartan,
+                            uint8_t *buf, size_t cap, size_t *len);
+int pk_io_pattern_check(const uint8_t *pattern, size_t n, unsigned m_0, const pk_whir_config *whir_witness,
+                        const pk_whir_config *whir_for_hiding_spartan, char *why, size_t why_cap);
 int pk_scheme_domain_separator(const pk_scheme *scheme, char *buf, size_t cap, size_t *len);
 
 /* ------------------------------------------------------------------ X4: the R1CS witness builders

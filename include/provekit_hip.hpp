@@ -240,6 +240,11 @@ class WhirR1CSScheme {
     }
     pk_scheme* get() const { return h_; }
     const Context& context() const { return *c_; }
+    // WhirR1CSScheme::create_io_pattern (provekit/common/src/whir_r1cs.rs:28-39): the bytes of the IO pattern in force; a caller
+    // that holds the reference's own (`create_io_pattern().as_bytes()`) installs them -- refused unless they declare the
+    // operations the prover performs ("... IO pattern ..." is thrown, pk_scheme_set_io_pattern)
+    std::string create_io_pattern() const { return domain_separator(); }
+    void set_io_pattern(const std::string& bytes) { c_->check(pk_scheme_set_io_pattern(c_->get(), h_, (const uint8_t*)bytes.data(), bytes.size())); }
     std::string domain_separator() const {
         size_t n = 0;
         pk_scheme_domain_separator(h_, nullptr, 0, &n);

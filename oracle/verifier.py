@@ -83,11 +83,52 @@ def keccak_tag(data: bytes) -> bytes:
 
 
 # ------------------------------------------------------------------ transcript (verifier side)
+def parse_io_pattern(pattern: bytes):
+    """spongefish DomainSeparator::finalize: "\\0"-separated ops after the protocol id; A/S carry a decimal count, H/R do
+    not; neighbouring absorbs / squeezes merge.  -> [[kind, count], ...]"""
+    ops = []
+    for part in pattern.split(b"\0")[1:]:
+        if not part:
+            raise VerifyError("IO pattern: empty operation")
+        kind = chr(part[0])
+        if kind in "HR":
+            ops.append([kind, 1])
+            continue
+        if kind not in "AS":
+            raise VerifyError("IO pattern: unknown operation kind")
+        digits = b""
+        for ch in part[1:]:
+            if not 48 <= ch <= 57:
+                break
+            digits += bytes([ch])
+        if not digits or int(digits) == 0:
+            raise VerifyError("IO pattern: zero or missing count")
+        if ops and ops[-1][0] == kind:
+            ops[-1][1] += int(digits)
+        else:
+            ops.append([kind, int(digits)])
+    return ops
+
+
 class Arthur:
+    """VerifierState: the sponge starts from the Keccak tag of the IO pattern's bytes and -- like spongefish's
+    HashStateWithInstructions -- every absorb / squeeze / hint is checked against the operations the pattern declares
+    (skipped for an empty pattern: the structure-only walk of the reference's own proof, whose pattern is unknown)."""
+
     def __init__(self, domain_separator: bytes, transcript: bytes):
         self.st = [0, int.from_bytes(keccak_tag(domain_separator), "little") % P]
         self.absorb_pos, self.squeeze_pos = 0, 1
         self.t, self.i = transcript, 0
+        self.ops = parse_io_pattern(domain_separator) if domain_separator else None
+
+    def _expect(self, kind, n):
+        if self.ops is None or n == 0:
+            return
+        if not self.ops or self.ops[0][0] != kind or self.ops[0][1] < n:
+            raise VerifyError(f"operation {kind}{n} does not follow the IO pattern (next declared: {self.ops[0] if self.ops else 'end'})")
+        self.ops[0][1] -= n
+        if self.ops[0][1] == 0:
+            self.ops.pop(0)
 
     def _absorb(self, x):
         if self.absorb_pos == 1:
@@ -110,6 +151,7 @@ class Arthur:
         return b
 
     def next_scalars(self, n):
+        self._expect("A", n)
         out = []
         for _ in range(n):
             v = int.from_bytes(self._read(32), "little")
@@ -119,26 +161,30 @@ class Arthur:
         return out
 
     def challenge_scalars(self, n):
+        self._expect("S", n)
         return [self._squeeze() for _ in range(n)]
 
     def challenge_bytes(self, n):
+        self._expect("S", -(-n // 15))
         out = b""
         while len(out) < n:
             out += self._squeeze().to_bytes(32, "little")[: min(15, n - len(out))]
         return out
 
     def next_bytes(self, n):
+        self._expect("A", n)
         b = self._read(n)
         for x in b:
             self._absorb(x)
         return b
 
     def hint(self):
+        self._expect("H", 1)
         (ln,) = struct.unpack("<I", self._read(4))
         return self._read(ln)
 
     def done(self):
-        return self.i == len(self.t)
+        return self.i == len(self.t) and not self.ops
 
 
 # ------------------------------------------------------------------ helpers
@@ -261,7 +307,7 @@ def parse_commitment(A: Arthur, cfg: WhirConfig):  # mtUtilities.go:51-76
     (root,) = A.next_scalars(1)
     ood_pts = A.challenge_scalars(cfg.commitment_ood_samples)
     ood_ans = [A.next_scalars(cfg.commitment_ood_samples) for _ in range(cfg.batch_size)]
-    (beta,) = A.challenge_scalars(1)
+    (beta,) = A.challenge_scalars(1) if cfg.batch_size > 1 else (1,)
     return dict(root=root, ood_pts=ood_pts, ood_ans=ood_ans, beta=beta)
 
 
@@ -367,7 +413,9 @@ def mle_eval_table(table, point):
 def verify(transcript: bytes, domain_separator: bytes, m: int, m_0: int, cfg_w: WhirConfig, cfg_b: WhirConfig, r1cs=None,
            structure_only: bool = False, hash_version: int = 2):
     """WhirR1CSVerifier::verify.  r1cs = (num_constraints, num_witnesses, [(rows, cols, vals)]*3 canonical) enables the
-    matrix-evaluation check of the deferred weights.  structure_only / hash_version: see _MODE."""
+    matrix-evaluation check of the deferred weights; for statements too big for Python sums r1cs may be a callable
+    (alpha, point) -> [eq(alpha)^T M_k eq(point) for k in A, B, C] over canonical ints (tests/oracle_lib.matrix_evaluator).
+    structure_only / hash_version: see _MODE."""
     old = dict(_MODE)
     _MODE.update(structure_only=structure_only, hash_version=hash_version)
     try:
@@ -409,15 +457,14 @@ def _verify(transcript, domain_separator, m, m_0, cfg_w, cfg_b, r1cs):
     # the Spartan relation (whir_r1cs.rs:78-86)
     ensure(f_at_alpha == (f_sums[0] * f_sums[1] - f_sums[2]) * eq_poly(r, alpha) % P, "last sumcheck value does not match")
     if r1cs is not None:  # matrix_evaluation.go: deferred_k == MLE(eq(alpha)^T M_k zero-extended)(wrev)
-        nc, nw, mats = r1cs
-        eq_a = pr.eq_table(alpha)
-        half = 1 << (m - 1)
-        eq_lo = pr.eq_table(wrev[1:])
+        if callable(r1cs):  # big statements: the caller evaluates eq(alpha)^T M_k eq(wrev[1:]) (e.g. with the C oracle's SpMV)
+            evals = r1cs(alpha, wrev[1:])
+        else:
+            nc, nw, mats = r1cs
+            ensure(1 << (m - 1) >= nw, "witness does not fit")
+            eq_a = pr.eq_table(alpha)
+            eq_lo = pr.eq_table(wrev[1:])
+            evals = [sum(v * eq_a[i] * eq_lo[j] for i, j, v in zip(*mats[k])) % P for k in range(3)]
         for k in range(3):
-            rows, cols, vals = mats[k]
-            acc = 0
-            for i, j, v in zip(rows, cols, vals):
-                acc += v * eq_a[i] * eq_lo[j]
-            ensure(wdef[k] == acc * (1 - wrev[0]) % P, f"deferred evaluation of weight {k} does not match the R1CS matrix")
-        ensure(half >= nw, "witness does not fit")
+            ensure(wdef[k] == evals[k] * (1 - wrev[0]) % P, f"deferred evaluation of weight {k} does not match the R1CS matrix")
     return True

@@ -371,7 +371,7 @@ int whir_commit(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, fe* const* pol
         }
     }
     for (unsigned b = 0; b < batch; b++) T.add_scalars(&C.ood_answers[b * C.ood_points.size()], C.ood_points.size());
-    C.beta = T.challenge_scalar();
+    C.beta = batch > 1 ? T.challenge_scalar() : fe_one();  // whir draws the batching randomness only for a real batch
     return PK_OK;
 }
 
@@ -782,23 +782,107 @@ std::string witness_io_pattern(size_t n_public, size_t n_challenges) {
     return d;
 }
 
-std::string domain_separator_for(const pk_scheme& s) {
-    // spongefish-style op list ("\0"-separated <A|S|H><count><label>); labels are ours (unpinned)
-    auto whir_commit_ops = [](const pk_whir_config& c) {
-        return std::string("A1merkle_digest\0S", 17) + std::to_string(c.commitment_ood_samples) + std::string("ood_query\0A", 11) +
-               std::to_string(c.commitment_ood_samples * c.batch_size) + std::string("ood_ans\0S1batching_randomness\0", 30);
+// WhirR1CSScheme::create_io_pattern (provekit/common/src/whir_r1cs.rs:28-39) restated:
+//   IOPattern::new("🌪️").commit_statement(w).add_rand(m_0).commit_statement(b).add_zk_sumcheck_polynomials(m_0)
+//            .add_whir_proof(b).hint("claimed_evaluations").add_whir_proof(w)
+// provekit's own labels (utils/sumcheck.rs:119-142) are in the tree.  commit_statement / add_whir_proof live in whir @3e7f8c2
+// (absent): their OPERATIONS are pinned by the in-tree Go verifier's read order (mtUtilities.go:51-76, whir.go:51-220) and the
+// labels "stir_answers", "merkle_proof", "deferred_weight_evaluations", "pow-nonce" by its pattern walker (common.go:41-100);
+// the remaining labels are whir's / spongefish-pow's as published (merkle_digest, ood_query, ood_ans, sumcheck_poly,
+// folding_randomness, combination_randomness, pow_queries, stir_queries, final_coeffs, final_queries) -- UNPINNED here, which is
+// why a caller that holds the reference's bytes overrides this string (pk_scheme_set_io_pattern).  Zero-count operations are
+// omitted exactly where whir guards them (no OOD samples, no grinding).
+std::string whir_r1cs_io_pattern(unsigned m_0, const pk_whir_config& w, const pk_whir_config& h) {
+    std::string d = "\xF0\x9F\x8C\xAA\xEF\xB8\x8F";  // "🌪️"
+    auto op = [&](char kind, size_t count, const char* label) {
+        d.push_back('\0');
+        d.push_back(kind);
+        if (kind == 'A' || kind == 'S') d += std::to_string(count);
+        d += label;
     };
-    std::string d = "\xF0\x9F\x8C\xAA\xEF\xB8\x8F";  // "🌪️" (provekit/common/src/whir_r1cs.rs:30)
-    d.push_back('\0');
-    d += whir_commit_ops(s.whir_witness);
-    d += "S" + std::to_string(s.m_0) + std::string("rand\0", 5);
-    d += whir_commit_ops(s.whir_hiding);
-    d += std::string("A1Sum of G over boolean hypercube\0S1Rho\0", 40);
-    for (unsigned i = 0; i < s.m_0; i++) d += std::string("A4Sumcheck Polynomials\0S1Sumcheck Random\0", 41);
-    d += std::string("A2Polynomial sums\0", 18);
-    d += "whir:n=" + std::to_string(s.whir_hiding.n_vars) + std::string("\0Hclaimed_evaluations\0", 22);
-    d += "whir:n=" + std::to_string(s.whir_witness.n_vars);
+    auto A = [&](size_t n, const char* l) { if (n) op('A', n, l); };
+    auto S = [&](size_t n, const char* l) { if (n) op('S', n, l); };
+    auto challenge_bytes = [&](size_t n, const char* l) { S((n + 14) / 15, l); };  // 15 uniform bytes per squeezed element
+    auto pow = [&](double bits) {  // spongefish-pow challenge_pow: 32 challenge bytes, 8-byte nonce
+        if (bits > 0.0) {
+            challenge_bytes(32, "pow_queries");
+            A(8, "pow-nonce");
+        }
+    };
+    auto add_ood = [&](size_t samples, size_t batch) {
+        S(samples, "ood_query");
+        A(samples * batch, "ood_ans");
+    };
+    auto add_sumcheck = [&](unsigned rounds) {
+        for (unsigned i = 0; i < rounds; i++) {
+            A(3, "sumcheck_poly");
+            S(1, "folding_randomness");
+        }
+    };
+    auto commit_statement = [&](const pk_whir_config& c) {
+        A(1, "merkle_digest");
+        add_ood(c.commitment_ood_samples, c.batch_size);
+        if (c.batch_size > 1) S(1, "batching_randomness");  // drawn right after the commitment (mtUtilities.go:71-75)
+    };
+    auto query_bytes = [](size_t domain, unsigned fold) {
+        const size_t folded = domain >> fold;
+        return (size_t)((ilog2(folded) + 7) / 8);
+    };
+    auto add_whir_proof = [&](const pk_whir_config& c) {
+        const unsigned k = c.folding_factor;
+        S(1, "initial_combination_randomness");
+        add_sumcheck(k);
+        size_t domain = (size_t)1 << (c.n_vars + c.starting_log_inv_rate);
+        for (unsigned r = 0; r < c.n_rounds; r++) {
+            A(1, "merkle_digest");
+            add_ood(c.ood_samples[r], 1);
+            pow(c.pow_bits[r]);
+            challenge_bytes((size_t)c.num_queries[r] * query_bytes(domain, k), "stir_queries");
+            op('H', 0, "stir_answers");
+            op('H', 0, "merkle_proof");
+            S(1, "combination_randomness");
+            add_sumcheck(k);
+            domain >>= 1;
+        }
+        const unsigned final_vars = c.n_vars - k * (c.n_rounds + 1);
+        A((size_t)1 << final_vars, "final_coeffs");
+        pow(c.final_pow_bits);
+        challenge_bytes((size_t)c.final_queries * query_bytes(domain, k), "final_queries");
+        op('H', 0, "stir_answers");
+        op('H', 0, "merkle_proof");
+        add_sumcheck(final_vars);
+        pow(c.final_folding_pow_bits);  // once, after the last round (whir.go:196-201)
+        op('H', 0, "deferred_weight_evaluations");
+    };
+    commit_statement(w);
+    S(m_0, "rand");
+    commit_statement(h);
+    A(1, "Sum of G over boolean hypercube");
+    S(1, "Rho");
+    for (unsigned i = 0; i < m_0; i++) {
+        A(4, "Sumcheck Polynomials");
+        S(1, "Sumcheck Random");
+    }
+    A(2, "Polynomial sums");
+    add_whir_proof(h);
+    op('H', 0, "claimed_evaluations");
+    add_whir_proof(w);
     return d;
+}
+
+// do the caller's IO-pattern bytes declare the operations pk_prove performs for (m_0, w, h)?  "" = yes, else the first difference
+std::string io_pattern_mismatch(const std::string& theirs, unsigned m_0, const pk_whir_config& w, const pk_whir_config& h) {
+    std::vector<IoOp> a, b;
+    std::string err;
+    if (!io_pattern_parse(theirs, a, err)) return err;
+    if (!io_pattern_parse(whir_r1cs_io_pattern(m_0, w, h), b, err)) return "internal: " + err;
+    auto name = [](const IoOp& o) { return std::string(1, o.kind) + (o.kind == 'A' || o.kind == 'S' ? std::to_string(o.count) : std::string()); };
+    for (size_t i = 0; i < a.size() && i < b.size(); i++)
+        if (a[i].kind != b[i].kind || a[i].count != b[i].count)
+            return "IO pattern operation #" + std::to_string(i + 1) + " (after merging) is " + name(a[i]) + " but this scheme's prover performs " + name(b[i]);
+    if (a.size() != b.size())
+        return "IO pattern declares " + std::to_string(a.size()) + " operations (after merging), this scheme's prover performs " + std::to_string(b.size());
+    return "";
 }
 
 }  // namespace
@@ -848,7 +932,7 @@ int pk_scheme_create(pk_ctx* ctx, const pk_r1cs* r1cs, size_t num_constraints, s
     s->m_0 = m_0;
     s->whir_witness = *whir_witness;
     s->whir_hiding = *whir_for_hiding_spartan;
-    s->domain_separator = domain_separator_for(*s);
+    s->domain_separator = whir_r1cs_io_pattern(s->m_0, s->whir_witness, s->whir_hiding);
     // arena = the sum of pk_prove's allocations (nothing is freed inside a proof).  With N = 2^m, R = 2^starting_log_inv_rate,
     // F = 2^folding_factor: f, g in both forms 4N; initial codeword batch*R*N and its tree 2R/F N; working polynomial and the
     // sumcheck ping-pong 4N; round codewords (domain halves each round) < R N, their trees < 2R/F N, folded polynomials
@@ -1065,6 +1149,9 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     CK(whir_prove(ctx, A, s->whir_witness, W.com, wts, wlen, 3, T));
     CK(pk_ctx_sync(ctx));
     lap("witness WHIR proof");
+    // the proof performed exactly the operations its IO pattern declares (what spongefish enforces on the reference's side)
+    if (!T.finished())
+        return set_err(ctx, PK_ERR_IO_PATTERN, "%s", T.violation().empty() ? "the proof ended before its IO pattern did" : T.violation().c_str());
 
     *len = T.narg.size();
     if (!transcript_out) return PK_OK;  // size query
@@ -1226,6 +1313,44 @@ int pk_scheme_domain_separator(const pk_scheme* s, char* buf, size_t cap, size_t
     if (!s || !len) return PK_ERR_BAD_ARG;
     *len = s->domain_separator.size();
     if (buf && cap >= *len) memcpy(buf, s->domain_separator.data(), *len);
+    return PK_OK;
+}
+
+static bool whir_config_sane(const pk_whir_config* c) {
+    return c && c->folding_factor >= 1 && c->folding_factor <= 8 && c->n_rounds <= PK_MAX_WHIR_ROUNDS && c->batch_size >= 1 && c->batch_size <= 4 &&
+           c->n_vars >= c->folding_factor * (c->n_rounds + 1) && c->n_vars + c->starting_log_inv_rate <= 28 && c->commitment_ood_samples <= 4;
+}
+
+int pk_whir_r1cs_io_pattern(unsigned m_0, const pk_whir_config* whir_witness, const pk_whir_config* whir_for_hiding_spartan, uint8_t* buf,
+                            size_t cap, size_t* len) {
+    if (!len || m_0 < 1 || m_0 > 27 || !whir_config_sane(whir_witness) || !whir_config_sane(whir_for_hiding_spartan)) return PK_ERR_BAD_ARG;
+    const std::string p = whir_r1cs_io_pattern(m_0, *whir_witness, *whir_for_hiding_spartan);
+    *len = p.size();
+    if (buf && cap >= p.size()) memcpy(buf, p.data(), p.size());
+    return PK_OK;
+}
+
+int pk_io_pattern_check(const uint8_t* pattern, size_t n, unsigned m_0, const pk_whir_config* whir_witness,
+                        const pk_whir_config* whir_for_hiding_spartan, char* why, size_t why_cap) {
+    if (why && why_cap) why[0] = 0;
+    if (!pattern || m_0 < 1 || m_0 > 27 || !whir_config_sane(whir_witness) || !whir_config_sane(whir_for_hiding_spartan)) return PK_ERR_BAD_ARG;
+    const std::string bad = io_pattern_mismatch(std::string((const char*)pattern, n), m_0, *whir_witness, *whir_for_hiding_spartan);
+    if (bad.empty()) return PK_OK;
+    if (why && why_cap) snprintf(why, why_cap, "%s", bad.c_str());
+    return PK_ERR_IO_PATTERN;
+}
+
+int pk_scheme_set_io_pattern(pk_ctx* ctx, pk_scheme* s, const uint8_t* pattern, size_t n) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, s, "null pointer");
+    if (!pattern || !n) {  // back to the library's restatement
+        s->domain_separator = whir_r1cs_io_pattern(s->m_0, s->whir_witness, s->whir_hiding);
+        return PK_OK;
+    }
+    const std::string theirs((const char*)pattern, n);
+    const std::string bad = io_pattern_mismatch(theirs, s->m_0, s->whir_witness, s->whir_hiding);
+    if (!bad.empty()) return set_err(ctx, PK_ERR_IO_PATTERN, "%s", bad.c_str());
+    s->domain_separator = theirs;
     return PK_OK;
 }
 

@@ -9,8 +9,12 @@
 // utilities/utilities.go:84-101): scalars = 32-byte canonical little-endian, absorbed as field elements; hints =
 // u32-LE length + payload, not absorbed; PoW nonce = 8 bytes big-endian, absorbed byte-wise; challenge bytes are
 // taken 15 at a time from squeezed elements (spongefish's bytes_uniform_modp for a 254-bit modulus).
-// Parity with the reference transcript is UNPINNED: the domain-separator labels live in the absent
-// `whir`/`spongefish` crates.
+// The sponge IV is the Keccak tag of the IO pattern's bytes (DomainSeparator::as_bytes()); a caller that holds the
+// reference's `create_io_pattern()` hands those bytes over (pk_scheme_set_io_pattern) and the transcript then both starts
+// from the reference's IV and ENFORCES the pattern op by op the way spongefish's HashStateWithInstructions does
+// (absorb / squeeze / hint against the declared stack), so a proof that would trip the reference verifier's pattern check
+// fails here first.  Without one the library's own restatement of the pattern is used (prover.hip `whir_r1cs_io_pattern`:
+// provekit's labels from the tree, whir's recalled -- DESIGN.md 6 lists which are pinned by the Go verifier's parser).
 #pragma once
 #include <chrono>
 #include <cstdint>
@@ -212,20 +216,68 @@ inline void sky_permute_host(fe& l_c, fe& r_c) {
     memcpy(r_c.v, r, 32);
 }
 
+// ---- spongefish IO pattern: "<protocol id>" then "\0<A|S><count><label>", "\0H<label>", "\0R" ------------------------
+// DomainSeparator::finalize: parse, reject zero counts, merge neighbouring absorbs / squeezes.
+struct IoOp {
+    char kind;     // 'A' absorb, 'S' squeeze, 'H' hint, 'R' ratchet
+    size_t count;  // units (field elements); 1 for H / R
+};
+inline bool io_pattern_parse(const std::string& bytes, std::vector<IoOp>& ops, std::string& err) {
+    ops.clear();
+    size_t pos = bytes.find('\0');
+    if (pos == std::string::npos) return true;  // a bare protocol id: no operations
+    size_t index = 0;
+    while (pos != std::string::npos) {
+        const size_t next = bytes.find('\0', pos + 1);
+        const std::string part = bytes.substr(pos + 1, next == std::string::npos ? std::string::npos : next - pos - 1);
+        pos = next;
+        index++;
+        if (part.empty()) {
+            err = "IO pattern: empty operation #" + std::to_string(index);
+            return false;
+        }
+        const char kind = part[0];
+        if (kind == 'H' || kind == 'R') {
+            ops.push_back({kind, 1});
+            continue;
+        }
+        if (kind != 'A' && kind != 'S') {
+            err = "IO pattern: operation #" + std::to_string(index) + " has unknown kind";
+            return false;
+        }
+        size_t i = 1, count = 0;
+        while (i < part.size() && part[i] >= '0' && part[i] <= '9' && count < ((size_t)1 << 40)) count = count * 10 + (size_t)(part[i++] - '0');
+        if (count == 0) {
+            err = "IO pattern: operation #" + std::to_string(index) + " has a zero or missing count";
+            return false;
+        }
+        if (!ops.empty() && ops.back().kind == kind)
+            ops.back().count += count;
+        else
+            ops.push_back({kind, count});
+    }
+    return true;
+}
+
 class Transcript {
   public:
     std::vector<uint8_t> narg;  // the proof string (WhirR1CSProof::transcript)
     double permute_seconds = 0.0;  // host time spent in the sponge permutation (PK_PROVE_TIMING)
     unsigned permutes = 0;
 
-    explicit Transcript(const std::string& domain_separator) {
+    explicit Transcript(const std::string& io_pattern) {
         uint8_t iv[32];
-        keccak_tag(domain_separator, iv);
+        keccak_tag(io_pattern, iv);  // HashStateWithInstructions::generate_tag
         st_[0] = fe_zero();
         fe c;
         memcpy(c.v, iv, 32);
         st_[1] = fe_reduce_any(c);  // FieldElement::new(bigint_from_bytes_le(iv)), sponge.rs:46-49
+        if (!io_pattern_parse(io_pattern, ops_, violation_)) ops_.clear();
     }
+    // "" while every operation so far matched the declared pattern; otherwise the first mismatch (spongefish: InvalidIOPattern)
+    const std::string& violation() const { return violation_; }
+    // ... and nothing declared was left undone (spongefish checks this when the state is dropped)
+    bool finished() const { return violation_.empty() && op_ == ops_.size(); }
     // prover -> verifier: field elements (Montgomery in memory), written canonical LE and absorbed
     void add_scalars(const fe* mont, size_t n) {
         for (size_t i = 0; i < n; i++) add_canon(h_to_canon(mont[i]));
@@ -233,15 +285,20 @@ class Transcript {
     void add_scalar(const fe& mont) { add_scalars(&mont, 1); }
     // a digest is already a canonical value (provekit/common/src/skyscraper/whir.rs:96-102)
     void add_canon(const fe& canon) {
+        expect('A', 1);
         append(canon.v, 32);
         absorb(canon);
     }
     // verifier -> prover
-    fe challenge_scalar() { return h_from_canon(squeeze()); }
+    fe challenge_scalar() {
+        expect('S', 1);
+        return h_from_canon(squeeze());
+    }
     void challenge_scalars(fe* out, size_t n) {
         for (size_t i = 0; i < n; i++) out[i] = challenge_scalar();
     }
     void challenge_bytes(uint8_t* out, size_t n) {
+        expect('S', (n + 14) / 15);
         while (n) {
             fe c = squeeze();
             size_t take = n < 15 ? n : 15;
@@ -251,6 +308,7 @@ class Transcript {
         }
     }
     void add_bytes(const uint8_t* b, size_t n) {
+        expect('A', n);
         append(b, n);
         for (size_t i = 0; i < n; i++) {
             fe c = fe_zero();
@@ -259,6 +317,7 @@ class Transcript {
         }
     }
     void hint(const void* payload, size_t len) {
+        expect('H', 1);
         uint32_t l = (uint32_t)len;
         append(&l, 4);
         append(payload, len);
@@ -273,6 +332,23 @@ class Transcript {
     }
     fe st_[2];
     int absorb_pos_ = 0, squeeze_pos_ = 1;  // R = 1
+    std::vector<IoOp> ops_;
+    size_t op_ = 0, used_ = 0;  // position in ops_, units of ops_[op_] already consumed
+    std::string violation_;
+    void expect(char kind, size_t n) {
+        if (!n || !violation_.empty()) return;
+        if (op_ >= ops_.size() || ops_[op_].kind != kind || ops_[op_].count - used_ < n) {
+            violation_ = std::string("transcript operation ") + kind + std::to_string(n) + " does not follow the IO pattern: operation #" +
+                         std::to_string(op_ + 1) + " is " +
+                         (op_ < ops_.size() ? std::string(1, ops_[op_].kind) + std::to_string(ops_[op_].count - used_) + " (remaining)" : std::string("past the end"));
+            return;
+        }
+        used_ += n;
+        if (used_ == ops_[op_].count) {
+            op_++;
+            used_ = 0;
+        }
+    }
     void append(const void* p, size_t n) {
         const uint8_t* b = static_cast<const uint8_t*>(p);
         narg.insert(narg.end(), b, b + n);

@@ -300,6 +300,9 @@ __global__ __launch_bounds__(RED_THREADS) void heavy_sum_final_kernel(const Heav
 
 // ---- postcard(Vec<WitnessBuilder>) ---------------------------------------------------------------------------------------------
 constexpr uint64_t PK_MAX_WITNESS_INDEX = 1ull << 27;
+// work items one program may expand to (a builder that writes many witnesses becomes one item per witness): a scheme holds at
+// most 2^26 witnesses, so a list from untrusted bytes that asks for more than this is refused before anything is allocated for it
+constexpr uint64_t PK_MAX_PROGRAM_ITEMS = 1ull << 27;
 struct Reader {
     const uint8_t* p;
     size_t n, off = 0;
@@ -348,6 +351,7 @@ struct Program {
     std::vector<SumChunk> sum_chunks;
     std::vector<std::pair<u32, u32>> heavy_terms;  // per heavy sum before sorting: (first term, number of terms)
     size_t n_counts = 0;
+    uint64_t expanded = 0;  // work items + Spice cells asked for so far (PK_MAX_PROGRAM_ITEMS)
     std::string error;
 };
 
@@ -380,6 +384,12 @@ bool read_cow(Reader& rd, Program& P, Parsed& b, u32& packed) {  // ConstantOrR1
 
 // one builder (witness_builder.rs:33-117, variants in declaration order)
 bool parse_builder(Reader& rd, Program& P, u32 bi, Parsed& b) {
+    // `count` more work items: refused once the program's total passes PK_MAX_PROGRAM_ITEMS (checked BEFORE the caller expands)
+    auto budget = [&](uint64_t count) {
+        if (count > PK_MAX_PROGRAM_ITEMS || P.expanded + count > PK_MAX_PROGRAM_ITEMS) return rd.ok = false;
+        P.expanded += count;
+        return true;
+    };
     auto item = [&](u32 op, u32 out) {
         WbItem it{};
         it.op = op;
@@ -454,6 +464,7 @@ bool parse_builder(Reader& rd, Program& P, u32 bi, Parsed& b) {
             if (!rd.ok || n > rd.n - rd.off) return rd.ok = false;
             // the table is expanded to one work item per entry: an absurd size from untrusted bytes must not drive host allocations
             if (range > (1u << 26) || P.n_counts + range > (1ull << 28)) return rd.ok = false;
+            if ((uint64_t)start + range > PK_MAX_WITNESS_INDEX || !budget(n + range)) return rd.ok = false;
             const u32 base = (u32)P.n_counts;
             P.n_counts += range;
             for (uint64_t i = 0; i < n; i++) {
@@ -526,6 +537,12 @@ bool parse_builder(Reader& rd, Program& P, u32 bi, Parsed& b) {
             const u32 first = rd.index();
             (void)rd.index();  // num_witnesses
             if (!rd.ok || declared != values.size()) return rd.ok = false;
+            // one item per (digit, value): zero-width digits are legal, so only the COUNT of bases bounds the product -- cap it
+            // (256 one-bit digits is the finest decomposition that reads any bit), keep every written index a witness index
+            // (64-bit arithmetic: first + bases * values must not wrap) and charge the expansion to the program's budget
+            if (log_bases.size() > 256) return rd.ok = false;
+            const uint64_t dd_items = (uint64_t)log_bases.size() * values.size();
+            if ((uint64_t)first + dd_items > PK_MAX_WITNESS_INDEX || !budget(dd_items + values.size())) return rd.ok = false;
             u32 total = 0;
             for (u32 lb : log_bases) {
                 if (lb > 256 || total + lb > 256) return rd.ok = false;  // field_to_le_bits yields 256 bits: a longer slice panics
@@ -568,9 +585,10 @@ bool parse_builder(Reader& rd, Program& P, u32 bi, Parsed& b) {
             sb.builder = bi;
             sb.memory_length = rd.index();
             sb.initial_start = rd.index();
-            if (sb.memory_length > (1u << 28)) return rd.ok = false;  // three reads / writes per cell are recorded below
+            // three reads / writes per cell are recorded below: charged to the budget before anything is pushed
+            if ((uint64_t)sb.initial_start + sb.memory_length > PK_MAX_WITNESS_INDEX || !budget(3ull * sb.memory_length)) return rd.ok = false;
             const uint64_t n = rd.varint();
-            if (!rd.ok || n > rd.n - rd.off) return rd.ok = false;
+            if (!rd.ok || n > rd.n - rd.off || !budget(n)) return rd.ok = false;
             for (uint64_t i = 0; i < n; i++) {
                 const uint64_t kind = rd.varint();
                 SpiceOp op{};
@@ -598,6 +616,8 @@ bool parse_builder(Reader& rd, Program& P, u32 bi, Parsed& b) {
             (void)rd.index();  // first_witness_idx
             (void)rd.index();  // num_witnesses
             if (!rd.ok) return false;
+            if ((uint64_t)sb.rv_start + sb.memory_length > PK_MAX_WITNESS_INDEX || (uint64_t)sb.rt_start + sb.memory_length > PK_MAX_WITNESS_INDEX)
+                return rd.ok = false;
             for (u32 a = 0; a < sb.memory_length; a++) {
                 b.copies.push_back(sb.initial_start + a);
                 b.writes.push_back(sb.rv_start + a);
@@ -621,6 +641,7 @@ bool parse_builder(Reader& rd, Program& P, u32 bi, Parsed& b) {
             const uint64_t n = rd.varint();
             if (!rd.ok || n > rd.n - rd.off) return rd.ok = false;
             if (P.n_counts + 65536 > (1ull << 28)) return rd.ok = false;
+            if ((uint64_t)start + 65536 > PK_MAX_WITNESS_INDEX || !budget(n + 65536)) return rd.ok = false;
             const u32 base = (u32)P.n_counts;
             P.n_counts += 65536;  // 2^(2 * BINOP_ATOMIC_BITS)
             for (uint64_t i = 0; i < n; i++) {

@@ -75,6 +75,25 @@ def _cfg_struct(cfg: WhirConfig) -> WhirConfigStruct:
     return s
 
 
+def create_io_pattern(m_0: int, whir_witness: WhirConfig, whir_for_hiding_spartan: WhirConfig) -> bytes:
+    """WhirR1CSScheme::create_io_pattern as the library restates it (pk_whir_r1cs_io_pattern; host only)."""
+    cw, cb = _cfg_struct(whir_witness), _cfg_struct(whir_for_hiding_spartan)
+    n = C.c_size_t()
+    if lib.pk_whir_r1cs_io_pattern(m_0, C.byref(cw), C.byref(cb), None, 0, C.byref(n)):
+        raise ValueError("pk_whir_r1cs_io_pattern: bad scheme shape")
+    buf = (C.c_uint8 * n.value)()
+    lib.pk_whir_r1cs_io_pattern(m_0, C.byref(cw), C.byref(cb), buf, n.value, C.byref(n))
+    return bytes(buf)
+
+
+def io_pattern_check(pattern: bytes, m_0: int, whir_witness: WhirConfig, whir_for_hiding_spartan: WhirConfig) -> str:
+    """"" if `pattern` declares the operations pk_prove performs for this scheme shape, else the reason (pk_io_pattern_check)."""
+    cw, cb = _cfg_struct(whir_witness), _cfg_struct(whir_for_hiding_spartan)
+    why = C.create_string_buffer(512)
+    rc = lib.pk_io_pattern_check(pattern, len(pattern), m_0, C.byref(cw), C.byref(cb), why, len(why))
+    return "" if rc == 0 else (why.value.decode() or f"error {rc}")
+
+
 def blinding_config_for(m_0: int, test_pow_bits: float | None = None) -> WhirConfig:
     """new_whir_config_for_size(next_power_of_two(4*m_0) + 1, 2) (provekit/r1cs-compiler/src/whir_r1cs.rs:31-34)"""
     nb = max((4 * m_0 - 1).bit_length(), 0)
@@ -91,11 +110,22 @@ class WhirR1CSScheme:
                                         C.byref(h)))
         self.handle = h.value
         self._buf = (C.c_uint8 * (8 << 20))()
+        self._read_domain_separator()
+
+    def _read_domain_separator(self):
         n = C.c_size_t()
         lib.pk_scheme_domain_separator(self.handle, None, 0, C.byref(n))
         ds = C.create_string_buffer(n.value)
         lib.pk_scheme_domain_separator(self.handle, ds, n.value, C.byref(n))
         self.domain_separator = ds.raw[: n.value]
+
+    def set_io_pattern(self, pattern: bytes | None):
+        """Hand over `WhirR1CSScheme::create_io_pattern().as_bytes()` (provekit/common/src/whir_r1cs.rs:28-39): the sponge IV is
+        derived from these bytes from now on; refused unless they declare the operations pk_prove performs.  None restores the
+        library's restatement."""
+        pattern = pattern or b""
+        self.ctx._check(lib.pk_scheme_set_io_pattern(self.ctx.handle, self.handle, pattern if pattern else None, len(pattern)))
+        self._read_domain_separator()
 
     def close(self):
         if self.handle is not None and self.ctx.handle is not None:

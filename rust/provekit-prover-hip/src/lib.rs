@@ -11,8 +11,10 @@
 //! (`&[FieldElement]` is `[u64; 4]` Montgomery limbs, the ABI's element layout), and the proof string back.
 //!
 //! Two grains.  [`HipProver`] hands the whole of `prove` to `pk_prove`, duplex-sponge transcript included: fastest (one FFI call
-//! per proof), but the bytes follow that library's own domain-separator labels -- the reference's come from `spongefish`/`whir`,
-//! which are not in its tree (Cargo.toml:130-132), so a stock verifier does not accept them (DESIGN.md "Oracle and pinning").
+//! per proof).  The sponge IV and the operation schedule come from THIS side: `HipProver::new` passes
+//! `scheme.create_io_pattern().as_bytes()` (provekit/common/src/whir_r1cs.rs:28-39) through `pk_scheme_set_io_pattern`, which
+//! refuses a pattern that does not declare exactly the operations `pk_prove` performs -- so a version skew between whir's
+//! `add_whir_proof` and the library surfaces at construction, not as a proof the verifier rejects.
 //! [`stepwise::StepProver`] keeps the transcript in `spongefish::ProverState`, created from the scheme's own `IOPattern`, and
 //! calls one entry point per data-parallel block: byte-compatible by construction for the in-tree half of
 //! `prove`; [`stepwise::HipNoirProofScheme`] puts `NoirProofSchemeProver` (the trait the CLI calls) on top of it.
@@ -159,7 +161,13 @@ impl<'a> HipProver<'a> {
         ctx.check(unsafe {
             sys::pk_scheme_create(ctx.raw, dev.raw, dev.num_constraints, dev.num_witnesses, scheme.m as _, scheme.m_0 as _, &w, &b, &mut raw)
         })?;
-        Ok(Self { ctx, scheme, r1cs: dev, raw })
+        let this = Self { ctx, scheme, r1cs: dev, raw }; // from here on Drop releases the scheme
+        // the reference's own IO pattern: its bytes fix the sponge IV, its operations are checked against pk_prove's
+        let io = scheme.create_io_pattern();
+        let bytes = io.as_bytes();
+        ctx.check(unsafe { sys::pk_scheme_set_io_pattern(ctx.raw, raw, bytes.as_ptr(), bytes.len()) })
+            .context("the scheme's IO pattern does not match the HIP prover's operation schedule")?;
+        Ok(this)
     }
 
     pub fn scheme(&self) -> &WhirR1CSScheme {

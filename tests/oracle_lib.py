@@ -197,6 +197,25 @@ def spmv(num_rows, num_cols, nri, ci, vals, interner, x, transpose=False):
     return y
 
 
+def matrix_evaluator(num_rows, num_cols, mats, interner):
+    """-> the callable oracle/verifier.verify takes as `r1cs` for statements too big for Python sums:
+    (alpha, point) |-> [eq(alpha)^T M_k eq(point, zero-extended columns)] for the three CSR matrices
+    mats[k] = (new_row_indices, col_indices, value_indices into `interner` (Montgomery)), computed with the C oracle
+    (pko_eq_table, pko_spmv, pko_dot): the bilinear form the Go verifier evaluates in matrix_evaluation.go."""
+
+    def evaluate(alpha, point):
+        eq_a = eq_table(to_mont(ints_to_limbs(alpha)))[:num_rows]
+        assert (1 << len(point)) >= num_cols
+        eq_p = eq_table(to_mont(ints_to_limbs(point)))[:num_cols]
+        out = []
+        for nri, ci, vals in mats:
+            y = spmv(num_rows, num_cols, nri, ci, vals, interner, eq_p)
+            out.append(limbs_to_ints(from_mont(dot(eq_a, y).reshape(1, 4)))[0])
+        return out
+
+    return evaluate
+
+
 def hadamard(a, b):
     a, b = fe_arr(a), fe_arr(b)
     out = np.empty_like(a)

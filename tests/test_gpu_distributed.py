@@ -83,6 +83,23 @@ def _check_multirank_bench(ctx, one_gpu):
     # whole-job aggregate: one step = one wave of `concurrency` proofs per GPU -> ranks x concurrency x steps proofs / time
     assert p["config"]["proofs_per_step"] == 2 * 2
     assert abs(p["value"] - 2 * 2 * 2 / (p["ms_per_step"] * 2 * 1e-3)) / p["value"] < 1e-6
+    # the DEFAULT line's secondary figures under world > 1 (what the driver's `--gpus N` run yields besides the weak-scaling
+    # proofs/s): the commit probe runs SHARDED over the ranks (north_star's strong-scaling curve; here 2^17 instead of 2^26 to
+    # keep the test short) and gives the unsharded root; the PCIe-inclusive rate is a second timed pass
+    m2 = 17
+    q = launch(["--workload", "prove", "--concurrency", "2", "--no-cpu-baseline", "--commit-log2-size", str(m2), "--size-classes", ""])
+    assert q["n_gpus"] == 2 and q["scaling"] == "weak" and q["h2d_inclusive_proofs_per_s"] > 0
+    cp = q[f"commit_2p{m2}"]
+    assert cp["n_gpus"] == 2 and cp["scaling"] == "strong" and cp["ms_per_commit"] > 0 and "sharded by leaf index over 2 ranks" in cp["workload"]
+    polys = []
+    for b in range(2):
+        t = torch.randint(0, 2**62, (1 << m2, 4), dtype=torch.int64, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(17 + b))
+        t[:, 3] &= (1 << 60) - 1
+        polys.append(t)
+    torch.cuda.synchronize()
+    ref = commit_batch(ctx, [int(t.data_ptr()) for t in polys], m2)
+    assert cp["root"] == ref.root.hex()
+    ref.close()
     # latency mode: one proof at a time sharded over the two ranks (commits of >= 64 rows per rank split by leaf index)
     sh = launch(["--workload", "prove", "--sharded", "--log2-size", "15", "--no-cpu-baseline"])
     assert sh["n_gpus"] == 2 and sh["scaling"] == "strong" and sh["config"]["proofs_per_step"] == 1 and sh["value"] > 0

@@ -186,8 +186,9 @@ def size_class_instance(oracle, m):
 def prove_verify_size_class(ctx, oracle, m, check_layout=False):
     """A SATISFIABLE instance of the size class (m, m_0 = m - 1) under the reference's own WHIR schedule
     (WhirConfig.derive: queries, OOD samples and grinding difficulties of new_whir_config_for_size): the proof must pass every
-    check of the independent verifier (transcript, Merkle openings of the 2^(m-3)-leaf tree, both sumchecks, folds, PoW); the
-    O(nnz) matrix evaluation of the deferred weights is left to the smaller cases above."""
+    check of the independent verifier (transcript, Merkle openings of the 2^(m-3)-leaf tree, both sumchecks, folds, PoW) and
+    the matrix evaluation of the deferred weights -- eq(alpha)^T {A, B, C} eq(point), recursive-verifier's matrix_evaluation.go,
+    the relation provekit/verifier/src/whir_r1cs.rs:78-86 leaves to it -- evaluated with the C oracle's SpMV."""
     import verifier as V
     from provekit_amd.field import random_field
     from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
@@ -208,9 +209,15 @@ def prove_verify_size_class(ctx, oracle, m, check_layout=False):
                             c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
 
     args = (scheme.domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
-    assert V.verify(proof, *args)
+    matrices = oracle.matrix_evaluator(nc, nw, mats, interner)
+    assert V.verify(proof, *args, r1cs=matrices)
     fresh = scheme.prove(d_z)  # production randomness (OS CSPRNG): another transcript, equally valid
-    assert fresh != proof and V.verify(fresh, *args)
+    assert fresh != proof and V.verify(fresh, *args, r1cs=matrices)
+    # the matrix check bites: the same proof against a statement with one coefficient changed is refused
+    other = [tuple(np.copy(a) for a in t) for t in mats]
+    other[1][2][len(other[1][2]) // 2] ^= 1
+    with pytest.raises(V.VerifyError, match="does not match the R1CS matrix"):
+        V.verify(proof, *args, r1cs=oracle.matrix_evaluator(nc, nw, other, interner))
     bad = bytearray(proof)
     bad[len(bad) // 2] ^= 1
     with pytest.raises((V.VerifyError, Exception)):
@@ -388,6 +395,53 @@ def test_the_bench_statement_verifies(ctx, oracle):
         return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
                             c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
 
-    assert V.verify(proof, scheme.domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b))
+    # ... including the R1CS relation itself: the deferred weight evaluations against bench's own matrices (C oracle SpMV)
+    csr = [(M.new_row_indices, M.col_indices, M.values) for M in mats]
+    assert V.verify(proof, scheme.domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b), r1cs=oracle.matrix_evaluator(nc, n_wit, csr, interner))
+    scheme.close()
+    r1cs.close()
+
+
+def test_prove_under_a_caller_supplied_io_pattern(ctx, oracle):
+    """pk_scheme_set_io_pattern: the drop-in caller's `create_io_pattern().as_bytes()` (provekit/common/src/whir_r1cs.rs:28-39)
+    replaces the library's restatement -- other labels, same operations.  The proof then starts from THAT pattern's IV (the
+    verifier built on the same bytes accepts it, the one built on the library's pattern does not), and a pattern that does not
+    declare pk_prove's operations is refused up front."""
+    import verifier as V
+    from provekit_amd import ProveKitHipError
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for, create_io_pattern
+    from provekit_amd.sparse_matrix import R1CS
+
+    m, m_0, nc, n_in = 10, 8, 200, 150
+    nw, z, coeffs, trips = satisfiable_r1cs(nc, n_in, 21)
+    r1cs = R1CS(ctx, *(to_sparse(nc, nw, t) for t in trips), oracle.to_mont(oracle.ints_to_limbs(coeffs)))
+    cfg_w, cfg_b = WhirConfig.for_size(m, 5.0), blinding_config_for(m_0, 5.0)
+    scheme = WhirR1CSScheme(ctx, r1cs, m, m_0, cfg_w, cfg_b)
+    ours = scheme.domain_separator
+    assert ours == create_io_pattern(m_0, cfg_w, cfg_b)
+    d_z = ctx.upload(oracle.to_mont(oracle.ints_to_limbs(z)))
+    p_ours = scheme.prove(d_z, seed=4)
+
+    def vcfg(c):
+        return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
+
+    mats = [(t[0], t[1], [coeffs[v] for v in t[2]]) for t in trips]
+    shape = (m, m_0, vcfg(cfg_w), vcfg(cfg_b))
+    theirs = ours.replace(b"merkle_digest", b"root").replace(b"\0A2ood_ans", b"\0A1ood_ans\0A1ood_ans").replace(b"stir_queries", b"stir_challenge_indexes")
+    scheme.set_io_pattern(theirs)
+    assert scheme.domain_separator == theirs
+    p_theirs = scheme.prove(d_z, seed=4)
+    assert p_theirs != p_ours and p_theirs[:32] == p_ours[:32]  # same commitment, different challenges from the first squeeze on
+    assert V.verify(p_theirs, theirs, *shape, r1cs=(nc, nw, mats))
+    with pytest.raises(V.VerifyError):
+        V.verify(p_theirs, ours, *shape)
+    with pytest.raises(ProveKitHipError, match="IO pattern"):
+        scheme.set_io_pattern(ours.replace(b"\0Hclaimed_evaluations", b"", 1))
+    with pytest.raises(ProveKitHipError, match="IO pattern"):
+        scheme.set_io_pattern(create_io_pattern(m_0, WhirConfig.for_size(m, 0.0), cfg_b))  # declares no grinding
+    assert scheme.domain_separator == theirs  # a refused pattern changes nothing
+    scheme.set_io_pattern(None)
+    assert scheme.domain_separator == ours and scheme.prove(d_z, seed=4) == p_ours
     scheme.close()
     r1cs.close()

@@ -33,6 +33,14 @@ def test_reference_proof_walks_in_our_read_order():
     cfg_w, cfg_b = vcfg(WhirConfig.for_size(m)), vcfg(blinding_config_for(m_0))
     assert cfg_b.n_vars == 8 and len(cfg_b.num_queries) == 1  # next_power_of_two(4 * 20) + 1 variables, one round + final
     assert V.verify(t, b"", m, m_0, cfg_w, cfg_b, structure_only=True, hash_version=1)
+    # ... and it performs exactly the operations this library's IO pattern declares for the scheme (absorb / squeeze / hint counts
+    # in order, spongefish's own check; the labels -- hence the IV and the challenges -- are what stays unpinned)
+    from provekit_amd.scheme import create_io_pattern
+
+    pattern = create_io_pattern(m_0, WhirConfig.for_size(m), blinding_config_for(m_0))
+    assert V.verify(t, pattern, m, m_0, cfg_w, cfg_b, structure_only=True, hash_version=1)
+    with pytest.raises(V.VerifyError, match="IO pattern"):
+        V.verify(t, pattern.replace(b"\0Hclaimed_evaluations", b"", 1), m, m_0, cfg_w, cfg_b, structure_only=True, hash_version=1)
     # the walk is sensitive to the shape: a different round count, m_0 or OOD count must not parse
     import copy
 
