@@ -515,6 +515,14 @@ int pk_selftest_coop_round(pk_ctx *ctx, const uint32_t l[9], const uint32_t r[9]
                            uint64_t cycles[4]);
 int pk_selftest_fp52_sqr_device(pk_ctx *ctx, const uint64_t *d_a, uint64_t *d_out5, size_t n);
 int pk_selftest_modmul_rate_fp52(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double *modmul_per_s);
+/* modular reduction as a constant-matrix product on the matrix core (v_mfma_i32_16x16x64_i8 over the
+ * 8/8/8/5-bit digits a 29-bit limb already holds; csrc/selftest.hip "Reduction on the matrix core") -- measured and
+ * NOT adopted.  pk_selftest_mfma_reduce: the product itself, exact (d_t_limbs: n x 18 limbs of 29 bits, d_out: n x 36 column sums
+ * with sum_i out[i] 2^(29 (i/4) + 8 (i%4)) == t 2^-256 mod p, non-negative, < 2^270).  The two rate probes return squarings per
+ * second: the matrix pipe fed for free, and the vector work that remains with the matrix products and lane movement free. */
+int pk_selftest_mfma_reduce(pk_ctx *ctx, const uint32_t *d_t_limbs, int32_t *d_out, size_t n);
+int pk_selftest_mfma_reduce_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned iters, double *squarings_per_s);
+int pk_selftest_mfma_valu_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double *squarings_per_s);
 
 #ifdef __cplusplus
 }

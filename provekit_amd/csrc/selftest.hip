@@ -377,3 +377,350 @@ int pk_selftest_arith(int op, const uint64_t* a, const uint64_t* b, uint64_t* ou
 }
 
 }  // extern "C"
+
+// ============================================================================================================================
+// VERDICT r03 item 5 -- the one execution unit never tried: modular REDUCTION as a constant-matrix product on the matrix core.
+//
+// Formulation (the best one found; DESIGN.md 4 "Reduction on the matrix core").  The 522-bit square t = a^2 sits in 18 limbs of
+// 29 bits.  A normalised limb is already four digits of 8, 8, 8 and 5 bits in the byte lanes of its register, so t is 72 digits
+// d_k at bit positions e_k = 29 (k / 4) + 8 (k % 4) with NO conversion.  Reduction is linear in the digits:
+//     t * 2^-256  ==  sum_k d_k * c_k  (mod p),       c_k = 2^(e_k - 256) mod p   (constants, < p)
+// -- the Montgomery factor costs nothing, it is inside the constants -- and writing each c_k in the same mixed-radix digits makes
+// the sum a (36 x 72) by (72 x batch) integer matrix product: v_mfma_i32_16x16x64_i8, rows = output digits, columns = values.
+// i8 is signed, so digits are recoded to [-128, 127] (per limb: add 0x00808080, xor 0x00808080) and an offset multiple of p keeps
+// the total positive.  The 36 column sums (|.| < 2^21) are assembled into 9 limbs by shifts and two 64-bit multiply-adds per limb,
+// and one 9-multiply-add fold of the bits above 2^253 brings the result under 2^254 + small.
+//
+// Three probes (tools/mfma_reduce.py -> profiles/r04_modmul_rates.json):
+//   pk_selftest_mfma_reduce        the matrix product itself on real inputs, operands loaded straight in fragment layout: EXACT
+//                                  (tests/test_gpu_selftest.py checks sum C_i 2^(f_i) == t 2^-256 mod p and the bound)
+//   pk_selftest_mfma_reduce_rate   the matrix pipe alone: the 24 MFMAs one wavefront (64 values) needs per squaring, register resident
+//   pk_selftest_mfma_valu_rate     the vector work that REMAINS per squaring (the 45-product square, the carry sweep to digits, the
+//                                  signed recoding, the limb assembly, the top fold) with the matrix products and all cross-lane
+//                                  movement (about 40 v_permlane swaps each way) taken as free
+// The achievable rate is below min(pipe, remainder) -- both are reported next to the 29-bit integer squaring they would replace.
+// ============================================================================================================================
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// host: signed mixed-radix digits (positions 29 q + 8 b, b < 4; byte 3 of a limb carries 5 bits + what is left) of 0 <= x < 2^261
+static void mixed_digits_signed(const unsigned __int128 lohi[3], int out[36]) {
+    // x as 9 limbs of 29 bits
+    u32 limb[9];
+    unsigned __int128 w0 = lohi[0], w1 = lohi[1], w2 = lohi[2];  // 128 + 128 + 5 bits
+    auto bit = [&](int i) -> u32 { return i < 128 ? (u32)(w0 >> i) & 1u : i < 256 ? (u32)(w1 >> (i - 128)) & 1u : (u32)(w2 >> (i - 256)) & 1u; };
+    for (int q = 0; q < 9; q++) {
+        u32 v = 0;
+        for (int b = 0; b < 29; b++) v |= bit(29 * q + b) << b;
+        limb[q] = v;
+    }
+    for (int q = 0; q < 9; q++) {
+        u32 y = (limb[q] + 0x00808080u) ^ 0x00808080u;
+        out[4 * q + 0] = (int8_t)(y & 255);
+        out[4 * q + 1] = (int8_t)((y >> 8) & 255);
+        out[4 * q + 2] = (int8_t)((y >> 16) & 255);
+        out[4 * q + 3] = (int)(y >> 24);  // 0 .. 32
+    }
+}
+
+// fragment tables: A[T][kb][lane] = 16 signed bytes, row i = 16 T + lane % 16, k = 64 kb + 16 (lane / 16) + [0, 16)
+struct MfmaReduceTables {
+    v4i A[3][2][64];
+    v4i C0[3][64];  // accumulator start: the digits of the offset OFFS * p, rows 16 T + 4 (lane / 16) + v
+};
+
+// c = 2^e * 2^-256 mod p by repeated doubling / halving on host 64-bit limbs
+static void pow2_mod_p(int e, uint64_t out[4]) {
+    using namespace pk::host64;
+    uint64_t x[4] = {1, 0, 0, 0};
+    if (e >= 0) {
+        for (int i = 0; i < e; i++) {
+            uint64_t y[4] = {x[0], x[1], x[2], x[3]};
+            add_mod(x, y);
+        }
+    } else {
+        for (int i = 0; i < -e; i++) {  // halve: (x + (x odd ? p : 0)) / 2
+            unsigned __int128 c = 0;
+            uint64_t t[5];
+            const bool odd = x[0] & 1;
+            for (int k = 0; k < 4; k++) {
+                c += (unsigned __int128)x[k] + (odd ? P64[k] : 0);
+                t[k] = (uint64_t)c;
+                c >>= 64;
+            }
+            t[4] = (uint64_t)c;
+            for (int k = 0; k < 4; k++) x[k] = (t[k] >> 1) | (t[k + 1] << 63);
+        }
+    }
+    memcpy(out, x, 32);
+}
+
+constexpr int MFMA_OFFS_LOG2 = 15;  // offset 2^15 * p: above 72 * 128 * p, the most negative the signed digits can make the sum
+
+static void build_mfma_tables(MfmaReduceTables& T) {
+    static int A[48][128];
+    memset(A, 0, sizeof A);
+    for (int k = 0; k < 72; k++) {
+        uint64_t c[4];
+        pow2_mod_p(29 * (k / 4) + 8 * (k % 4) - 256, c);
+        unsigned __int128 w[3] = {((unsigned __int128)c[1] << 64) | c[0], ((unsigned __int128)c[3] << 64) | c[2], 0};
+        int dg[36];
+        mixed_digits_signed(w, dg);
+        for (int i = 0; i < 36; i++) A[i][k] = dg[i];
+    }
+    for (int t = 0; t < 3; t++)
+        for (int kb = 0; kb < 2; kb++)
+            for (int lane = 0; lane < 64; lane++) {
+                int8_t b[16];
+                for (int j = 0; j < 16; j++) b[j] = (int8_t)A[16 * t + lane % 16][64 * kb + 16 * (lane / 16) + j];
+                memcpy(&T.A[t][kb][lane], b, 16);
+            }
+    // offset 2^15 p (< 2^269): plain (unsigned, unrecoded) mixed-radix digits; the top digit takes everything above bit 253
+    {
+        using namespace pk::host64;
+        unsigned __int128 w[3] = {0, 0, 0};
+        // 2^15 * p as a 269-bit integer in three 128-bit words (the third holds bits 256..)
+        unsigned __int128 carry = 0;
+        uint64_t o[5];
+        for (int k = 0; k < 4; k++) {
+            unsigned __int128 v = ((unsigned __int128)P64[k] << MFMA_OFFS_LOG2) + carry;
+            o[k] = (uint64_t)v;
+            carry = v >> 64;
+        }
+        o[4] = (uint64_t)carry;
+        w[0] = ((unsigned __int128)o[1] << 64) | o[0];
+        w[1] = ((unsigned __int128)o[3] << 64) | o[2];
+        w[2] = o[4];
+        int dg[48] = {};
+        auto bit = [&](int i) -> u32 { return i < 128 ? (u32)(w[0] >> i) & 1u : i < 256 ? (u32)(w[1] >> (i - 128)) & 1u : (u32)(w[2] >> (i - 256)) & 1u; };
+        for (int q = 0; q < 9; q++)
+            for (int b = 0; b < 4; b++) {
+                const int pos = 29 * q + 8 * b, width = (q == 8 && b == 3) ? 40 : (b == 3 ? 5 : 8);
+                int v = 0;
+                for (int x = 0; x < width && x < 30; x++) v |= (int)bit(pos + x) << x;
+                dg[4 * q + b] = v;
+            }
+        for (int t = 0; t < 3; t++)
+            for (int lane = 0; lane < 64; lane++) {
+                int c4[4];
+                for (int v = 0; v < 4; v++) c4[v] = dg[16 * t + 4 * (lane / 16) + v];
+                memcpy(&T.C0[t][lane], c4, 16);
+            }
+    }
+}
+
+// one group of 16 values: lane l supplies value 16 g + l % 16, limbs 16 kb + 4 (l / 16) + [0, 4)
+__device__ __forceinline__ v4i mfma_b_fragment(const u32* __restrict__ t_limbs, size_t value, int kb, int lane) {
+    v4i b;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int q = 16 * kb + 4 * (lane / 16) + j;
+        const u32 limb = q < 18 ? t_limbs[value * 18 + q] : 0u;
+        b[j] = q < 18 ? (int)((limb + 0x00808080u) ^ 0x00808080u) : 0;
+    }
+    return b;
+}
+
+// out[value][36] = the column sums.  One wavefront per 16 values.
+__global__ __launch_bounds__(64) void mfma_reduce_kernel(const u32* __restrict__ t_limbs, const MfmaReduceTables* __restrict__ tab, int* __restrict__ out,
+                                                         size_t n_values) {
+    const int lane = threadIdx.x;
+    const size_t g = blockIdx.x;
+    const size_t value = 16 * g + lane % 16;
+    const bool live = value < n_values;
+    const v4i b0 = live ? mfma_b_fragment(t_limbs, value, 0, lane) : v4i{0, 0, 0, 0};
+    const v4i b1 = live ? mfma_b_fragment(t_limbs, value, 1, lane) : v4i{0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        v4i c = tab->C0[t][lane];
+        c = __builtin_amdgcn_mfma_i32_16x16x64_i8(tab->A[t][0][lane], b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_i32_16x16x64_i8(tab->A[t][1][lane], b1, c, 0, 0, 0);
+        if (live)
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int i = 16 * t + 4 * (lane / 16) + v;
+                if (i < 36) out[value * 36 + i] = c[v];
+            }
+    }
+}
+
+// the matrix pipe alone: per iteration the 24 MFMAs of one wavefront-squaring (4 groups x 3 row tiles x 2 K blocks)
+__global__ __launch_bounds__(256) void mfma_reduce_rate_kernel(const MfmaReduceTables* __restrict__ tab, int* __restrict__ out, unsigned iters) {
+    const int lane = threadIdx.x & 63;
+    v4i a[3][2];
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) a[t][kb] = tab->A[t][kb][lane];
+    v4i b[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++) b[g][kb] = v4i{(int)threadIdx.x + g, (int)blockIdx.x + kb, 0x01020304 * (g + 1), 0x11 * (kb + 1)};
+    v4i acc = {0, 0, 0, 0};
+    for (unsigned it = 0; it < iters; it++) {
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                v4i c = acc;
+                c = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][0], b[g][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[t][1], b[g][1], c, 0, 0, 0);
+                b[g][0][t & 3] ^= c[0] & 0x0f0f0f0f;  // the next squaring's digits depend on this one's sums
+                acc[t & 3] = c[1] & 1;
+            }
+    }
+    if (acc[0] == 0x7fffffff) out[blockIdx.x * 256 + threadIdx.x] = acc[1] + acc[2] + acc[3] + b[0][0][0];
+}
+
+// the vector work that remains per squaring, one lane per value
+template <int ILP>
+__global__ __launch_bounds__(256) void mfma_valu_rate_kernel(const fe* __restrict__ in, u32* __restrict__ out, unsigned iters) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    fe29 x[ILP];
+#pragma unroll
+    for (int k = 0; k < ILP; k++) {
+        x[k] = unpack_reduce29(fe_load(in + (i % 64)));
+        x[k].v[0] += (u32)k;
+    }
+    for (unsigned it = 0; it < iters; it++) {
+#pragma unroll
+        for (int s = 0; s < ILP; s++) {
+            const fe29 l = x[s];
+            // (1) the square: 45 multiply-adds
+            u64 acc[18];
+#pragma unroll
+            for (int k = 0; k < 18; k++) acc[k] = 0;
+            u32 a2[9];
+#pragma unroll
+            for (int j = 0; j < 9; j++) a2[j] = l.v[j] << 1;
+#pragma unroll
+            for (int a = 0; a < 9; a++) {
+                acc[2 * a] += (u64)l.v[a] * l.v[a];
+#pragma unroll
+                for (int j = a + 1; j < 9; j++) acc[a + j] += (u64)l.v[a] * a2[j];
+            }
+            // (2) carry sweep to 18 normalised limbs = 72 digits, and the signed recoding of each limb
+            u32 rec[18];
+#pragma unroll
+            for (int k = 0; k < 17; k++) {
+                acc[k + 1] += acc[k] >> 29;
+                rec[k] = (((u32)acc[k] & M29) + 0x00808080u) ^ 0x00808080u;
+            }
+            rec[17] = ((u32)acc[17] + 0x00808080u) ^ 0x00808080u;
+            // (3) [matrix core: 36 column sums per value.  FREE here: stand-ins of the right width taken from live registers]
+            int cs[36];
+#pragma unroll
+            for (int c = 0; c < 36; c++) cs[c] = (int)(rec[(c * 7) % 18] ^ rec[(c * 5 + 3) % 18]) >> 10;
+            // (4) limb assembly: digits 4q .. 4q+3 at bit offsets 0, 8, 16, 24 of limb q -- one shift-add and two 64-bit multiply-adds
+            long long L[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                long long v = (long long)(cs[4 * q] + (cs[4 * q + 1] << 8));
+                v += (long long)cs[4 * q + 2] * (1 << 16);
+                v += (long long)cs[4 * q + 3] * (1 << 24);
+                L[q] = v;
+            }
+            // (5) signed carry sweep, then the fold of the bits above 2^253 (limb 8 above bit 21): + hi * (2^253 mod p)
+            fe29 r;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                L[q + 1] += L[q] >> 29;
+                r.v[q] = (u32)L[q] & M29;
+            }
+            const u32 hi = (u32)(L[8] >> 21);
+            r.v[8] = (u32)L[8] & ((1u << 21) - 1);
+            u64 c = 0;
+#pragma unroll
+            for (int q = 0; q < 9; q++) {
+                c += (u64)hi * kp29(5, q) + r.v[q];  // stand-in constant of the right shape (a 254-bit multiple of p's limbs)
+                r.v[q] = q < 8 ? ((u32)c & M29) : (u32)c;
+                c >>= 29;
+            }
+#pragma unroll
+            for (int q = 0; q < 9; q++) r.v[q] &= M29;
+            x[s] = r;
+        }
+    }
+    u32 sum = 0;
+#pragma unroll
+    for (int k = 0; k < ILP; k++)
+#pragma unroll
+        for (int q = 0; q < 9; q++) sum += x[k].v[q];
+    if (sum == 0xfffffff1u) out[i] = sum;  // keeps the chain live
+}
+
+static int mfma_tables_device(pk_ctx* ctx, MfmaReduceTables** d_tab) {
+    static MfmaReduceTables host;
+    static bool built = false;
+    if (!built) {
+        build_mfma_tables(host);
+        built = true;
+    }
+    int rc = ensure_scratch(ctx, sizeof(MfmaReduceTables) + (1 << 20));
+    if (rc) return rc;
+    *d_tab = (MfmaReduceTables*)ctx->d_scratch;
+    PK_HIP(ctx, hipMemcpyAsync(*d_tab, &host, sizeof host, hipMemcpyHostToDevice, ctx->stream));
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PK_OK;
+}
+
+extern "C" {
+
+// d_t_limbs: n x 18 u32 (29-bit limbs of the 522-bit squares), d_out: n x 36 i32 column sums
+int pk_selftest_mfma_reduce(pk_ctx* ctx, const uint32_t* d_t_limbs, int32_t* d_out, size_t n) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, d_t_limbs && d_out, "null pointer");
+    if (!n) return PK_OK;
+    MfmaReduceTables* tab = nullptr;
+    int rc = mfma_tables_device(ctx, &tab);
+    if (rc) return rc;
+    mfma_reduce_kernel<<<(unsigned)((n + 15) / 16), 64, 0, ctx->stream>>>(d_t_limbs, tab, d_out, n);
+    PK_LAUNCH_CHECK(ctx);
+    return sync_stream(ctx);
+}
+
+// squarings/s the matrix pipe sustains when fed for free: every wavefront-iteration is 64 squarings' worth of MFMAs
+int pk_selftest_mfma_reduce_rate(pk_ctx* ctx, unsigned waves_per_simd, unsigned iters, double* squarings_per_s) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, squarings_per_s && waves_per_simd >= 1 && waves_per_simd <= 8 && iters >= 1, "bad argument");
+    MfmaReduceTables* tab = nullptr;
+    int rc = mfma_tables_device(ctx, &tab);
+    if (rc) return rc;
+    const unsigned blocks = (unsigned)ctx->num_cus * waves_per_simd;  // 256 threads = 4 wavefronts = one per SIMD
+    int* out = (int*)((char*)ctx->d_scratch + sizeof(MfmaReduceTables));
+    mfma_reduce_rate_kernel<<<blocks, 256, 0, ctx->stream>>>(tab, out, 8);
+    PK_LAUNCH_CHECK(ctx);
+    float ms = 0;
+    if ((rc = pk_timer_start(ctx))) return rc;
+    mfma_reduce_rate_kernel<<<blocks, 256, 0, ctx->stream>>>(tab, out, iters);
+    PK_LAUNCH_CHECK(ctx);
+    if ((rc = pk_timer_stop(ctx, &ms))) return rc;
+    *squarings_per_s = (double)blocks * 256.0 * iters / (ms * 1e-3);
+    return PK_OK;
+}
+
+int pk_selftest_mfma_valu_rate(pk_ctx* ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double* squarings_per_s) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, squarings_per_s && waves_per_simd >= 1 && waves_per_simd <= 8 && (ilp == 1 || ilp == 2) && iters >= 1, "bad argument");
+    int rc = ensure_scratch(ctx, 1 << 20);
+    if (rc) return rc;
+    const unsigned blocks = (unsigned)ctx->num_cus * waves_per_simd;
+    fe* in = (fe*)ctx->d_scratch;
+    u32* out = (u32*)((char*)ctx->d_scratch + 4096);
+    PK_HIP(ctx, hipMemsetAsync(in, 0x5a, 64 * 32, ctx->stream));
+    auto launch = [&](unsigned n) {
+        if (ilp == 1) mfma_valu_rate_kernel<1><<<blocks, 256, 0, ctx->stream>>>(in, out, n);
+        else mfma_valu_rate_kernel<2><<<blocks, 256, 0, ctx->stream>>>(in, out, n);
+    };
+    launch(8);
+    PK_LAUNCH_CHECK(ctx);
+    float ms = 0;
+    if ((rc = pk_timer_start(ctx))) return rc;
+    launch(iters);
+    PK_LAUNCH_CHECK(ctx);
+    if ((rc = pk_timer_stop(ctx, &ms))) return rc;
+    *squarings_per_s = (double)blocks * 256.0 * ilp * iters / (ms * 1e-3);
+    return PK_OK;
+}
+
+}  // extern "C"

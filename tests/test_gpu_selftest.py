@@ -70,3 +70,18 @@ def test_cooperative_square_round_prototype_matches_the_lane(ctx):
             o = list(out)
             assert value(o[0:9]) % P == value(o[18:27]) % P and value(o[9:18]) % P == value(o[27:36]) % P, (v, n)
             assert max(o[0:8]) <= 1 << 29
+
+
+def test_matrix_core_reduction_prototype_is_exact(ctx):
+    """VERDICT r03 item 5 (measured, not adopted): x^2 * 2^-256 mod p as a constant-matrix product on the matrix core --
+    v_mfma_i32_16x16x64_i8 over the 8/8/8/5-bit digits of the square's 29-bit limbs, the Montgomery factor inside the constants.
+    The 36 column sums of every value must add up (at bit positions 29 (i / 4) + 8 (i % 4)) to a non-negative integer congruent to
+    the definition, for random and edge inputs (tools/mfma_reduce.py; rates in profiles/r04_modmul_rates.json)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import mfma_reduce
+
+    info = mfma_reduce.check_parity(ctx, n=1000, seed=11)
+    assert info["max_bits_of_the_unfolded_sum"] <= 271
