@@ -456,6 +456,18 @@ int pk_witness_builders_inspect(const uint8_t *bytes, size_t len, size_t *n_buil
                                 char *err, size_t err_cap);
 int pk_witness_solve(pk_ctx *ctx, pk_witness_program *prog, const uint64_t *d_acir, size_t n_acir, const uint64_t *challenges,
                      size_t n_challenges, uint64_t *d_witness, size_t n_witness, uint8_t *d_is_set);
+/* The distinct ACIR witness indices the list's WitnessBuilder::Acir entries read, ascending (host only; size query with idx = NULL).
+ * The reference's solver does `acir_witness_idx_to_value_map.get_index(..).unwrap()` (witness_builder.rs:36-41): a value missing
+ * from the WitnessMap is a panic there.  The dense d_acir array of pk_witness_solve / pk_noir_prove cannot express "missing", so
+ * the caller checks its map against this list first (rust/provekit-prover-hip: HipNoirProver::prove names the missing index). */
+int pk_witness_program_acir_reads(const pk_witness_program *prog, uint32_t *idx, size_t cap, size_t *n);
+/* Placement advice (host only): a list whose dependence depth approaches its length is latency-bound on the device (one level
+ * ~ 2.6 us whatever its width; 16 k chained builders = 43 ms) and belongs with the reference's sequential solver on a host core
+ * (~60 ns per builder); *prefer_host = 1 then, and the Rust side keeps the stock `solve_witness_vec` for that scheme and hands
+ * pk_prove the finished witness (HipNoirProver::new -> Placement::Host).  Estimates in microseconds, from the measurements in
+ * DESIGN.md 9; pk_witness_solve itself never refuses a list on these grounds. */
+int pk_witness_program_placement(const pk_witness_program *prog, size_t *n_levels, size_t *n_items, double *est_device_us,
+                                 double *est_host_us, int *prefer_host);
 int pk_witness_program_destroy(pk_ctx *ctx, pk_witness_program *prog);
 
 /* NoirProofSchemeProver::prove after ACVM execution (provekit/prover/src/noir_proof_scheme.rs:63-92):

@@ -127,6 +127,8 @@ SIGNATURES = {
     "pk_witness_program_destroy": (C.c_int, [vp, vp]),
     "pk_witness_challenges": (C.c_int, [sz, sz, vp, sz, vp, sz]),
     "pk_witness_fill": (C.c_int, [vp, vp, vp, sz, vp, vp]),
+    "pk_witness_program_acir_reads": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
+    "pk_witness_program_placement": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "pk_noir_prove": (C.c_int, [vp, vp, vp, vp, sz, vp, sz, vp, vp, sz, C.POINTER(sz)]),
     "pk_comm_init_host": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
     "pk_shard_of_leaf": (C.c_int, [C.c_uint64, C.c_uint, vp, vp]),

@@ -272,7 +272,9 @@ void comm_turn_end(pk_ctx* ctx) {
 }
 void comm_abort(pk_ctx* ctx) {
     pk_comm* c = ctx->comm;
-    if (c && c->kind == PK_COMM_LOCAL && c->grp) c->grp->abort();
+    if (!c) return;
+    if (c->kind == PK_COMM_LOCAL && c->grp) c->grp->abort();
+    if (c->kind == PK_COMM_HOST) c->failed = true;  // this rank's later collectives fail fast; its peers are the caller's transport's to time out
 }
 
 int comm_all_reduce_sum_u64(pk_ctx* ctx, uint64_t* d_buf, size_t count) {

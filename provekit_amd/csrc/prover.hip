@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256) void fill_witness_kernel(fe* __restrict__ w, c
         fe_store(w + i, fe_to_montx(x));
         mine++;
     }
-    if (mine) atomicAdd(n_filled, (unsigned long long)mine);
+    if (mine) atomicAdd(n_filled, (unsigned long long)mine);  // n_filled is DEVICE memory: agent-scope atomics are exact there
 }
 
 // public inputs of the witness transcript: the ACIR witness values at the circuit's public indices
@@ -885,6 +885,19 @@ std::string io_pattern_mismatch(const std::string& theirs, unsigned m_0, const p
     return "";
 }
 
+// One proof over a device set: a rank that leaves early (arena exhausted, a HIP error, an unsatisfied witness on this rank only)
+// never reaches the collectives its peers are -- or will be -- waiting in.  Whatever the exit path, a failing rank aborts the
+// group (in-process transport: the waiting ranks wake with PK_ERR_RCCL; host transport: this rank's communicator is marked
+// failed), as include/provekit_hip.h promises for every sharded call.
+struct AbortOnFailure {
+    pk_ctx* c;
+    bool ok = false;
+    explicit AbortOnFailure(pk_ctx* ctx) : c(ctx) {}
+    ~AbortOnFailure() {
+        if (!ok && comm_world(c) > 1) comm_abort(c);
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -956,6 +969,7 @@ int pk_scheme_create(pk_ctx* ctx, const pk_r1cs* r1cs, size_t num_constraints, s
 int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witness, const uint8_t* rng_seed32, uint8_t* transcript_out,
              size_t cap, size_t* len) {
     PK_ENTER(ctx);
+    AbortOnFailure guard(ctx);  // before the argument checks: a rank refused here never joins its peers' collectives either
     PK_REQUIRE(ctx, s && d_witness && len, "null pointer");
     PK_REQUIRE(ctx, n_witness == s->num_witnesses, "Unexpected witness length for R1CS instance");  // whir_r1cs.rs:43-46
     RngKey key;
@@ -1153,6 +1167,7 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     if (!T.finished())
         return set_err(ctx, PK_ERR_IO_PATTERN, "%s", T.violation().empty() ? "the proof ended before its IO pattern did" : T.violation().c_str());
 
+    guard.ok = true;  // every collective of this proof has been passed
     *len = T.narg.size();
     if (!transcript_out) return PK_OK;  // size query
     PK_REQUIRE(ctx, cap >= T.narg.size(), "transcript buffer too small");
@@ -1258,16 +1273,20 @@ int pk_witness_fill(pk_ctx* ctx, uint64_t* d_witness, const uint8_t* d_is_set, s
     RngKey key;
     int rc = proof_key(ctx, rng_seed32, key);
     if (rc) return rc;
-    unsigned long long* m_count = nullptr;
-    rc = mail_alloc(ctx, 8, (void**)&m_count);
+    // the count lives in device memory (the first word of the transient workspace; the stream is in order): atomics on the pinned
+    // host mailbox would need PCIe atomics, which not every host link provides
+    rc = ensure_ws(ctx, 256);
     if (rc) return rc;
-    *m_count = 0;
-    fill_witness_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_witness, d_is_set, n, key, RNG_FILL, m_count);
+    unsigned long long* d_count = (unsigned long long*)ctx->d_ws;
+    PK_HIP(ctx, hipMemsetAsync(d_count, 0, 8, ctx->stream));
+    fill_witness_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_witness, d_is_set, n, key, RNG_FILL, d_count);
     PK_LAUNCH_CHECK(ctx);
     if (n_filled) {
-        PK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the count is read before sync_stream rewinds the mailbox
-        *n_filled = (size_t)*m_count;
-        return sync_stream(ctx);
+        unsigned long long h = 0;
+        PK_HIP(ctx, hipMemcpyAsync(&h, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+        rc = sync_stream(ctx);
+        if (rc) return rc;
+        *n_filled = (size_t)h;
     }
     return PK_OK;
 }
@@ -1297,6 +1316,7 @@ int pk_noir_prove(pk_ctx* ctx, pk_scheme* s, pk_witness_program* builders, const
         rc = sync_stream(ctx);
         if (rc) return rc;
     }
+    AbortOnFailure guard(ctx);  // a witness that fails to solve on this rank only must not leave the others inside pk_prove's collectives
     int rc = pk_witness_challenges(s->num_constraints, nw, pub.data(), n_public, chal.data(), n_chal);
     if (rc) return set_err(ctx, rc, "witness transcript");
     rc = pk_witness_solve(ctx, builders, d_acir, n_acir, chal.data(), n_chal, d_w, nw, d_set);
@@ -1306,6 +1326,7 @@ int pk_noir_prove(pk_ctx* ctx, pk_scheme* s, pk_witness_program* builders, const
     if (rc) return rc;
     rc = pk_witness_fill(ctx, d_w, d_set, nw, (const uint8_t*)key.k, nullptr);
     if (rc) return rc;
+    guard.ok = true;  // pk_prove carries its own guard
     return pk_prove(ctx, s, d_w, nw, (const uint8_t*)key.k, transcript_out, cap, len);
 }
 

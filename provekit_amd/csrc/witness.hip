@@ -788,6 +788,37 @@ void witness_program_shape(const pk_witness_program* p, size_t* n_witnesses, siz
 
 extern "C" {
 
+// the distinct ACIR witness indices the list's Acir builders read, ascending (host only; the program keeps its item list)
+int pk_witness_program_acir_reads(const pk_witness_program* p, uint32_t* idx, size_t cap, size_t* n) {
+    if (!p || !n) return PK_ERR_BAD_ARG;
+    std::vector<u32> v;
+    for (const WbItem& it : p->P.items)
+        if (it.op == OP_ACIR) v.push_back(it.w[0]);
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    *n = v.size();
+    if (idx && cap >= v.size() && !v.empty()) memcpy(idx, v.data(), 4 * v.size());
+    return PK_OK;
+}
+
+// Where should this list be solved?  Measured on MI355X (profiles/r03_witness_bench.jsonl): a level costs ~2.6 us of
+// launch / barrier / dependent-load latency whatever its width, an item ~1 ns of throughput (2^20 builders in 1.08 ms); one host
+// core runs the reference's sequential loop at ~60 ns per builder.  A chain-shaped list (depth ~ length: 16 k builders = 43 ms here,
+// ~1 ms there) belongs on the host; a real constraint system's list (depth << length) on the device.
+int pk_witness_program_placement(const pk_witness_program* p, size_t* n_levels, size_t* n_items, double* est_device_us, double* est_host_us,
+                                 int* prefer_host) {
+    if (!p) return PK_ERR_BAD_ARG;
+    const size_t levels = p->P.phase_begin.empty() ? 0 : (p->P.phase_begin.size() - 1) / 2;
+    const double dev = 2.6 * (double)levels + 1e-3 * (double)p->P.items.size() + 10.0;
+    const double host = 0.06 * (double)p->P.n_builders;
+    if (n_levels) *n_levels = levels;
+    if (n_items) *n_items = p->P.items.size();
+    if (est_device_us) *est_device_us = dev;
+    if (est_host_us) *est_host_us = host;
+    if (prefer_host) *prefer_host = dev > host ? 1 : 0;
+    return PK_OK;
+}
+
 int pk_witness_program_destroy(pk_ctx* ctx, pk_witness_program* p) {
     PK_ENTER(ctx);
     if (!p) return PK_OK;

@@ -168,6 +168,23 @@ class WitnessProgram:
         self.ctx._check(lib.pk_memcpy_d2h(self.ctx.handle, s.ctypes.data, d_set.ptr, n))
         return w, s[:n].astype(bool)
 
+    def placement(self) -> dict:
+        """pk_witness_program_placement: levels, items, the estimated device / host solve times (us) and whether the list is so
+        chain-shaped that the reference's sequential solver on a host core is the faster place for it"""
+        nl, ni, dev, host, pref = C.c_size_t(), C.c_size_t(), C.c_double(), C.c_double(), C.c_int()
+        rc = lib.pk_witness_program_placement(self.handle, C.byref(nl), C.byref(ni), C.byref(dev), C.byref(host), C.byref(pref))
+        if rc:
+            raise ProveKitHipError(rc, "pk_witness_program_placement")
+        return {"n_levels": nl.value, "n_items": ni.value, "est_device_us": dev.value, "est_host_us": host.value, "prefer_host": bool(pref.value)}
+
+    def acir_reads(self) -> list:
+        """the ACIR witness indices the list's Acir builders read (pk_witness_program_acir_reads)"""
+        n = C.c_size_t()
+        lib.pk_witness_program_acir_reads(self.handle, None, 0, C.byref(n))
+        buf = (C.c_uint32 * max(n.value, 1))()
+        lib.pk_witness_program_acir_reads(self.handle, buf, n.value, C.byref(n))
+        return list(buf[: n.value])
+
     def close(self):
         if self.handle is not None and self.ctx.handle is not None:
             lib.pk_witness_program_destroy(self.ctx.handle, self.handle)

@@ -206,6 +206,19 @@ pub struct HipNoirProver<'a> {
     builders: *mut sys::pk_witness_program,
     n_acir: usize,
     public_idx: Vec<u32>,
+    /// the ACIR witness indices the list's `WitnessBuilder::Acir` entries read: each must be present in the map (the reference
+    /// unwraps `get_index`, witness_builder.rs:36-41 -- a missing value is an error there, not a zero)
+    acir_reads: Vec<u32>,
+    /// where the post-ACVM witness fill runs for this scheme (decided once, from the list's shape)
+    placement: Placement,
+}
+
+/// `pk_witness_program_placement`: a builder list whose dependence depth approaches its length is latency-bound on the device
+/// (~2.6 us per level) and stays with the reference's sequential solver on a host core.
+#[derive(Clone, Copy, Debug, PartialEq, Eq)]
+pub enum Placement {
+    Device,
+    Host,
 }
 
 impl<'a> HipNoirProver<'a> {
@@ -217,10 +230,28 @@ impl<'a> HipNoirProver<'a> {
         // Circuit::public_inputs().indices(): ascending ACIR witness indices (noir_proof_scheme.rs:96-97, 121-123)
         let public_idx: Vec<u32> = scheme.program.functions[0].public_inputs().indices();
         let n_acir = n_acir.max(public_idx.iter().map(|&i| i as usize + 1).max().unwrap_or(0));
-        Ok(Self { prover, builders, n_acir, public_idx })
+        let mut n_reads = 0usize;
+        ctx.check(unsafe { sys::pk_witness_program_acir_reads(builders, ptr::null_mut(), 0, &mut n_reads) })?;
+        let mut acir_reads = vec![0u32; n_reads];
+        ctx.check(unsafe { sys::pk_witness_program_acir_reads(builders, acir_reads.as_mut_ptr(), acir_reads.len(), &mut n_reads) })?;
+        let mut prefer_host = 0 as c_int;
+        ctx.check(unsafe { sys::pk_witness_program_placement(builders, ptr::null_mut(), ptr::null_mut(), ptr::null_mut(), ptr::null_mut(), &mut prefer_host) })?;
+        let placement = if prefer_host != 0 { Placement::Host } else { Placement::Device };
+        Ok(Self { prover, builders, n_acir, public_idx, acir_reads, placement })
+    }
+
+    pub fn placement(&self) -> Placement {
+        self.placement
+    }
+
+    /// `Placement::Host`: the caller runs the stock tail of `NoirProofSchemeProver::prove` (witness transcript, `solve_witness_vec`,
+    /// `fill_witness`; noir_proof_scheme.rs:68-79) and hands the finished witness to the device prover.
+    pub fn prove_with_host_witness(&self, r1cs: &R1CS, witness: Vec<FieldElement>) -> Result<provekit_common::NoirProof> {
+        Ok(provekit_common::NoirProof { whir_r1cs_proof: self.prover.prove(r1cs, witness)? })
     }
 
     pub fn prove(&self, acir: &acir::native_types::WitnessMap<provekit_common::NoirElement>) -> Result<provekit_common::NoirProof> {
+        ensure!(self.placement == Placement::Device, "this scheme's witness builders form a chain: solve them on the host (prove_with_host_witness)");
         let ctx = self.prover.ctx;
         let mut dense = vec![FieldElement::from(0u64); self.n_acir];
         for (i, slot) in dense.iter_mut().enumerate() {
@@ -230,6 +261,10 @@ impl<'a> HipNoirProver<'a> {
         }
         for &i in &self.public_idx {
             ensure!(acir.get_index(i).is_some(), "missing public input"); // noir_proof_scheme.rs:126
+        }
+        for &i in &self.acir_reads {
+            // the dense array cannot say "missing": where the reference's solver would panic on the unwrap, fail by name
+            ensure!(acir.get_index(i).is_some(), "ACIR witness {i} is read by a witness builder but missing from the witness map");
         }
         let d_acir = ctx.upload(&dense)?;
         let mut transcript = vec![0u8; 8 << 20];

@@ -334,6 +334,39 @@ def test_a_failing_rank_wakes_its_peers_instead_of_hanging_them(rank_sets):
     assert res[0][1] == -4 and res[1][1] == -4  # the communicator stays unusable: nobody waits for anybody
 
 
+def test_a_rank_that_fails_inside_a_sharded_proof_wakes_its_peers(oracle, rank_sets):
+    """only the commit path aborted the group; every other early return inside pk_prove left the peers at a barrier
+    for ever.  Rank 1 is refused at the door (wrong witness length -- any exit that is not PK_OK takes the same path: arena
+    exhausted, a HIP error, an unsatisfied witness in pk_noir_prove): it gets its own error, rank 0 -- already inside the proof's
+    first collective -- returns PK_ERR_RCCL instead of hanging, and the communicator stays unusable."""
+    from test_gpu_prove import satisfiable_r1cs, to_sparse
+
+    from provekit_amd._lib import lib
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS
+
+    m, m_0, nc, n_in = 13, 11, 1500, 2000
+    nw, z, coeffs, trips = satisfiable_r1cs(nc, n_in, 6)
+    zm = oracle.to_mont(oracle.ints_to_limbs(z))
+    interner = oracle.to_mont(oracle.ints_to_limbs(coeffs))
+    cfg_w, cfg_b = WhirConfig.for_size(m, 4.0), blinding_config_for(m_0, 4.0)
+
+    def fn(r, c):
+        r1cs = R1CS(c, *(to_sparse(nc, nw, t) for t in trips), interner)
+        s = WhirR1CSScheme(c, r1cs, m, m_0, cfg_w, cfg_b)
+        d = c.upload(zm)
+        n = C.c_size_t()
+        rc = lib.pk_prove(c.handle, s.handle, d.ptr, nw - (1 if r == 1 else 0), None, s._buf, len(s._buf), C.byref(n))
+        rc2 = lib.pk_prove(c.handle, s.handle, d.ptr, nw, None, s._buf, len(s._buf), C.byref(n))
+        s.close()
+        r1cs.close()
+        return rc, rc2
+
+    res = run_ranks(rank_sets(2), fn)
+    assert res[1][0] == -1 and res[0][0] == -4, res  # PK_ERR_BAD_ARG where it happened, PK_ERR_RCCL on the rank that was waiting
+    assert res[0][1] == -4 and res[1][1] == -4, res  # nobody waits for anybody afterwards
+
+
 def test_host_transport_in_process_and_its_failure_path(ctx):
     """pk_comm_init_host with a Python callback standing in for MPI / gloo: two contexts of this process exchange through a
     rendezvous written here; then a callback that reports failure must surface as PK_ERR_RCCL and poison the communicator."""

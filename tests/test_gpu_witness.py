@@ -341,3 +341,26 @@ def test_noir_prove_at_scale(ctx, oracle):
     prog.close()
     scheme.close()
     r1cs.close()
+
+
+def test_placement_advice_and_acir_reads(ctx, oracle):
+    """pk_witness_program_placement: a chain (every builder consumes its predecessor: one level per builder, ~2.6 us each) is sent
+    to the host solver, a wide list of the same length stays on the device; pk_witness_program_acir_reads lists exactly the ACIR
+    indices the Acir builders read (the Rust side checks its WitnessMap against it where the reference would unwrap)."""
+    from provekit_amd.witness import WitnessBuilder as WB, WitnessProgram
+
+    n = 20000
+    chain = [WB.Acir(0, 7)] + [WB.Product(i, i - 1, i - 1) for i in range(1, n)]
+    wide = [WB.Acir(0, 7), WB.Acir(1, 3)] + [WB.Product(i, 0, 1) for i in range(2, n)]
+    pc, pw = WitnessProgram(ctx, chain), WitnessProgram(ctx, wide)
+    a, b = pc.placement(), pw.placement()
+    assert a["n_levels"] >= n - 1 and a["prefer_host"] and a["est_device_us"] > 10 * a["est_host_us"]
+    assert b["n_levels"] <= 3 and not b["prefer_host"] and b["est_device_us"] < b["est_host_us"]
+    assert pc.acir_reads() == [7] and pw.acir_reads() == [3, 7]
+    builders, acir, ch, nw = random_program(5, 1 << 15)
+    big = WitnessProgram(ctx, builders)
+    assert not big.placement()["prefer_host"]  # a list shaped like a constraint system's: depth far below length
+    reads = big.acir_reads()
+    assert reads == sorted(set(reads)) and all(r < big.n_acir for r in reads) and (not reads or reads[-1] == big.n_acir - 1)
+    for p in (pc, pw, big):
+        p.close()
