@@ -347,6 +347,8 @@ def test_placement_advice_and_acir_reads(ctx, oracle):
     """pk_witness_program_placement: a chain (every builder consumes its predecessor: one level per builder, ~2.6 us each) is sent
     to the host solver, a wide list of the same length stays on the device; pk_witness_program_acir_reads lists exactly the ACIR
     indices the Acir builders read (the Rust side checks its WitnessMap against it where the reference would unwrap)."""
+    from witness_gen import random_program
+
     from provekit_amd.witness import WitnessBuilder as WB, WitnessProgram
 
     n = 20000
