@@ -532,6 +532,11 @@ int pk_selftest_modmul_rate_fp52(pk_ctx *ctx, unsigned waves_per_simd, unsigned 
  * NOT adopted.  pk_selftest_mfma_reduce: the product itself, exact (d_t_limbs: n x 18 limbs of 29 bits, d_out: n x 36 column sums
  * with sum_i out[i] 2^(29 (i/4) + 8 (i%4)) == t 2^-256 mod p, non-negative, < 2^270).  The two rate probes return squarings per
  * second: the matrix pipe fed for free, and the vector work that remains with the matrix products and lane movement free. */
+/* one Fiat-Shamir round trip as pk_prove makes it (launch + stream synchronisation) against the same round trip
+ * through a persistent kernel's pinned mailbox, `host_work_permutes` sponge permutations of host work in between; microseconds per
+ * round over `rounds` dependent round trips (tools/roundtrip.py, profiles/r04_roundtrip.json). */
+int pk_selftest_roundtrip(pk_ctx *ctx, unsigned rounds, unsigned host_work_permutes, double *us_per_round_launch,
+                          double *us_per_round_mailbox);
 int pk_selftest_mfma_reduce(pk_ctx *ctx, const uint32_t *d_t_limbs, int32_t *d_out, size_t n);
 int pk_selftest_mfma_reduce_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned iters, double *squarings_per_s);
 int pk_selftest_mfma_valu_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double *squarings_per_s);

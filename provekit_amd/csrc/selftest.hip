@@ -724,3 +724,84 @@ int pk_selftest_mfma_valu_rate(pk_ctx* ctx, unsigned waves_per_simd, unsigned il
 }
 
 }  // extern "C"
+
+// ============================================================================================================================
+// VERDICT r03 item 7 -- what a persistent sumcheck kernel could save: the Fiat-Shamir round trip, measured both ways.
+//   launch form    (what pk_prove does per round): a one-workgroup kernel that publishes a word to the pinned page, then
+//                  hipStreamSynchronize, then the host's sponge work, then the next launch
+//   mailbox form   (what a persistent kernel would do): ONE kernel; per round it publishes a word to the pinned page and spins on a
+//                  word the host writes back after the same sponge work (system-scope loads over the host link, bounded spin)
+// Both run `rounds` dependent round trips with `host_work_permutes` Skyscraper permutations of host work in between (a cubic round
+// absorbs four elements and squeezes one: five).  tools/roundtrip.py -> profiles/r04_roundtrip.json.
+// ============================================================================================================================
+__global__ void roundtrip_launch_kernel(unsigned* host_word, unsigned seq, const unsigned* challenge) {
+    if (threadIdx.x == 0) {
+        const unsigned c = __hip_atomic_load(challenge, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_word, seq + (c & 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ void roundtrip_mailbox_kernel(unsigned* out_word, const unsigned* in_word, unsigned rounds, unsigned max_spin, unsigned* status) {
+    if (threadIdx.x != 0) return;
+    for (unsigned r = 1; r <= rounds; r++) {
+        __hip_atomic_store(out_word, r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        unsigned spins = 0;
+        while (__hip_atomic_load(in_word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != r) {
+            if (++spins > max_spin) {  // the host went away: leave instead of hanging the queue
+                __hip_atomic_store(status, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __hip_atomic_store(status, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int pk_selftest_roundtrip(pk_ctx* ctx, unsigned rounds, unsigned host_work_permutes, double* us_per_round_launch,
+                                     double* us_per_round_mailbox) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, rounds >= 1 && rounds <= 100000 && us_per_round_launch && us_per_round_mailbox, "bad argument");
+    int rc = ensure_pinned(ctx);
+    if (rc) return rc;
+    volatile unsigned* page = (volatile unsigned*)((char*)ctx->h_pinned + 3072);  // a quiet corner of the 4 KiB page
+    unsigned* out_word = (unsigned*)page;
+    unsigned* in_word = (unsigned*)page + 16;
+    unsigned* status = (unsigned*)page + 32;
+    fe l = fe_zero(), r = fe_one();
+    auto host_work = [&] {
+        for (unsigned k = 0; k < host_work_permutes; k++) sky_permute_host(l, r);
+    };
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    // launch form
+    page[0] = page[16] = page[32] = 0;
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto t0 = now();
+    for (unsigned i = 1; i <= rounds; i++) {
+        page[16] = i + (l.v[0] & 0u);
+        roundtrip_launch_kernel<<<1, 64, 0, ctx->stream>>>(out_word, i, in_word);
+        PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (page[0] != i) return set_err(ctx, PK_ERR_HIP, "round-trip probe: the kernel's word did not arrive");
+        host_work();
+    }
+    *us_per_round_launch = 1e6 * std::chrono::duration<double>(now() - t0).count() / rounds;
+    // mailbox form
+    page[0] = page[16] = page[32] = 0;
+    t0 = now();
+    roundtrip_mailbox_kernel<<<1, 64, 0, ctx->stream>>>(out_word, in_word, rounds, 1u << 22, status);
+    PK_LAUNCH_CHECK(ctx);
+    bool lost = false;
+    for (unsigned i = 1; i <= rounds && !lost; i++) {
+        auto t1 = now();
+        while (__atomic_load_n(page + 0, __ATOMIC_ACQUIRE) != i) {
+            if (std::chrono::duration<double>(now() - t1).count() > 2.0) {
+                lost = true;
+                break;
+            }
+        }
+        host_work();
+        __atomic_store_n(page + 16, i + (l.v[0] & 0u), __ATOMIC_RELEASE);
+    }
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *us_per_round_mailbox = 1e6 * std::chrono::duration<double>(now() - t0).count() / rounds;
+    if (lost || page[32] != 0xffffffffu) return set_err(ctx, PK_ERR_HIP, "round-trip probe: the mailbox kernel gave up at round %u", (unsigned)page[32]);
+    return PK_OK;
+}
