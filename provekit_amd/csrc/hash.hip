@@ -220,6 +220,27 @@ int pk_merkle_inner(pk_ctx* ctx, uint64_t* d_nodes, size_t n_leaves) {
     return PK_OK;
 }
 
+}  // extern "C"
+
+namespace pk {
+// the levels above heap slots [top_leaves, 2 top_leaves) (top_leaves <= 1024, a power of two), the root also to the pinned page:
+// the top of a subtree-sharded tree, whose G subtree roots arrive through an all-gather (tree.hip)
+int merkle_top_x(pk_ctx* ctx, uint64_t* d_nodes, size_t top_leaves) {
+    int rc = ensure_pinned(ctx);
+    if (rc) return rc;
+    fe* host_root = (fe*)((char*)ctx->h_pinned + PK_PIN_ROOT);
+    ProfScope prof(ctx, "merkle_inner");
+    if (ctx->hash_version == 2)
+        merkle_top_kernel<2><<<1, 512, 0, ctx->stream>>>((fe*)d_nodes, top_leaves, host_root);
+    else
+        merkle_top_kernel<1><<<1, 512, 0, ctx->stream>>>((fe*)d_nodes, top_leaves, host_root);
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+}  // namespace pk
+
+extern "C" {
+
 int pk_merkle_commit(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, int layout, uint64_t* d_nodes) {
     PK_ENTER(ctx);
     PK_REQUIRE(ctx, is_pow2(n_leaves), "n_leaves must be a power of two");

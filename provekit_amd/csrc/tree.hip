@@ -39,6 +39,7 @@ int rs_encode_x(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, un
 int rs_encode_shard_x(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate, unsigned fold,
                       unsigned shard, unsigned n_shards, uint64_t* d_leaves_local, uint64_t* d_scratch, bool scaled);
 int leaf_hash_x(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves, size_t width, uint64_t* d_digests, bool scaled_in);
+int merkle_top_x(pk_ctx* ctx, uint64_t* d_nodes, size_t top_leaves);  // hash.hip: the levels above heap slots [top_leaves, 2 top_leaves)
 bool ntt_scaled_available(unsigned log_n);
 }
 
@@ -93,6 +94,39 @@ __global__ __launch_bounds__(256) void interleave_digests_kernel(const fe* __res
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     fe_store(nodes + rows + i, fe_load(gathered + shard_gathered_slot(i, rows, G)));
+}
+
+// a rank's subtree, built as a compact heap H over loc = rows / G leaves (H[1] its root), copied into its place in the tree's
+// heap: local node y of the level with c' nodes (H slots [c', 2c')) is global node G c' + g c' + (y - c')
+__global__ __launch_bounds__(256) void scatter_subtree_kernel(const fe* __restrict__ H, fe* __restrict__ nodes, size_t loc, unsigned G, unsigned g) {
+    PK_LATENCY_PRIO();
+    const size_t y = (size_t)blockIdx.x * blockDim.x + threadIdx.x + 1;  // 1 .. loc - 1: the inner nodes (the leaf layer is in place)
+    if (y >= loc) return;
+    size_t c = 1;
+    while (2 * c <= y) c <<= 1;
+    fe_store(nodes + (size_t)G * c + (size_t)g * c + (y - c), fe_load(H + y));
+}
+__global__ void place_subtree_roots_kernel(const fe* __restrict__ roots, fe* __restrict__ nodes, unsigned G) {
+    if (threadIdx.x < G) fe_store(nodes + G + threadIdx.x, fe_load(roots + threadIdx.x));
+}
+
+// sibling digests and authentication paths of a subtree-sharded tree: the nodes this rank holds, into a ZEROED device buffer
+// laid out [k siblings | k x plen path nodes] like gather_opening_kernel's outputs; the all-reduce that follows completes them
+__global__ __launch_bounds__(256) void gather_owned_nodes_kernel(const fe* __restrict__ nodes, size_t n_leaves, unsigned logn, unsigned G, unsigned shard,
+                                                                 const unsigned long long* __restrict__ idx, size_t k, fe* __restrict__ out_sib,
+                                                                 fe* __restrict__ out_path) {
+    PK_LATENCY_PRIO();
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned plen = logn ? logn - 1 : 0;
+    if (t >= k * (size_t)(plen + 1)) return;
+    const size_t q = t / (plen + 1), d = t % (plen + 1);
+    const size_t node = n_leaves + idx[q];
+    const size_t x = d == plen ? (node ^ 1) : ((node >> (logn - (d + 1))) ^ 1);
+    // the leaf layer is complete on every rank (it came through the all-gather): rank 0 answers for it, as for the replicated top
+    const unsigned owner = x >= n_leaves ? 0u : subtree_owner_of_node(x, G);
+    if (owner != shard) return;
+    if (d == plen) fe_store(out_sib + q, fe_load(nodes + x));
+    else fe_store(out_path + q * plen + d, fe_load(nodes + x));
 }
 
 // the opened rows this rank owns, gathered leaf-major into a ZEROED device buffer (the rest stays zero: the all-reduce that
@@ -167,7 +201,27 @@ int commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, un
     if (rc) return rc;
     interleave_digests_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, ctx->stream>>>(gathered, (fe*)d_nodes, rows, G);
     PK_LAUNCH_CHECK(ctx);
-    return pk_merkle_inner(ctx, d_nodes, rows);
+    if (!subtree_sharded(G, rows)) return pk_merkle_inner(ctx, d_nodes, rows);  // small tree: hash all of it on every rank
+    // SURVEY 8e, first option: this rank hashes only the subtree over its contiguous range of leaves (1/G of the inner nodes),
+    // as a compact heap in the -- now free -- gather buffer; the G subtree roots are all-gathered (32 bytes per rank) and the
+    // top log2 G levels hashed everywhere.  Inner nodes of the other ranks' subtrees are never formed here: openings collect
+    // them from their owners (pk_tree_open).
+    const unsigned g = (unsigned)comm_rank(ctx);
+    fe* H = gathered;  // 2 * loc <= rows entries
+    PK_HIP(ctx, hipMemcpyAsync(H + loc, (fe*)d_nodes + rows + (size_t)g * loc, 32 * loc, hipMemcpyDeviceToDevice, ctx->stream));
+    rc = pk_merkle_inner(ctx, (uint64_t*)H, loc);
+    if (rc) {
+        comm_abort(ctx);
+        return rc;
+    }
+    scatter_subtree_kernel<<<(unsigned)((loc + 255) / 256), 256, 0, ctx->stream>>>(H, (fe*)d_nodes, loc, G, g);
+    PK_LAUNCH_CHECK(ctx);
+    fe* roots = dig_local;  // G <= loc entries, free since the all-gather of the digests
+    rc = comm_all_gather(ctx, H + 1, roots, 32);
+    if (rc) return rc;
+    place_subtree_roots_kernel<<<1, 64, 0, ctx->stream>>>(roots, (fe*)d_nodes, G);
+    PK_LAUNCH_CHECK(ctx);
+    return merkle_top_x(ctx, d_nodes, G);
 }
 // open k leaves of a tree described by raw buffers (same outputs as pk_tree_open)
 int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, size_t n_leaves, size_t width, const pk_commit_layout& lay,
@@ -356,19 +410,28 @@ int pk_tree_open(pk_ctx* ctx, const pk_tree* t, const uint64_t* indices, size_t 
         // SURVEY 8e "Openings": leaf i is served by rank i mod G.  Every rank gathers the rows it owns into a zeroed buffer;
         // one all-reduce (k*width*32 bytes, ~100 KiB; each element is non-zero on exactly one rank) hands all of them to
         // everybody; sibling digests and auth paths come from the replicated inner tree.
+        // Trees big enough for subtree sharding (shard_map.hpp) hold only their own subtree's inner nodes: the digests are collected
+        // the same way, in the same all-reduce.
         PK_REQUIRE(ctx, t->layout == PK_COL_MAJOR, "sharded trees are column-major");
-        rc = ensure_scratch(ctx, ((size_t)1 << 20) + 32 * n1);
+        const bool sub = subtree_sharded(t->n_shards, t->n_leaves);
+        const size_t n_red = sub ? n1 + n2 : n1;  // [rows | siblings | paths]: the order of the mailbox block
+        rc = ensure_scratch(ctx, ((size_t)1 << 20) + 32 * n_red);
         if (rc) return rc;
         fe* d_rows = (fe*)((char*)ctx->d_scratch + ((size_t)1 << 19));  // clear of the reduction area (head) and the PoW words (tail)
-        PK_HIP(ctx, hipMemsetAsync(d_rows, 0, 32 * n1, ctx->stream));
+        PK_HIP(ctx, hipMemsetAsync(d_rows, 0, 32 * n_red, ctx->stream));
         gather_owned_rows_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, ctx->stream>>>(t->d_leaves, t->n_leaves / t->n_shards, (unsigned)t->width, t->shard,
                                                                                      t->n_shards, m_idx, k, canonical_leaves, d_rows, t->scaled);
         PK_LAUNCH_CHECK(ctx);
-        rc = comm_all_reduce_sum_u64(ctx, (uint64_t*)d_rows, 4 * n1);
+        if (sub && n2) {
+            gather_owned_nodes_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, ctx->stream>>>(t->d_nodes, t->n_leaves, logn, t->n_shards, t->shard, m_idx, k,
+                                                                                          d_rows + n1, d_rows + n1 + k);
+            PK_LAUNCH_CHECK(ctx);
+        }
+        rc = comm_all_reduce_sum_u64(ctx, (uint64_t*)d_rows, 4 * n_red);
         if (rc) return rc;
-        PK_HIP(ctx, hipMemcpyAsync(m_leaves, d_rows, 32 * n1, hipMemcpyDeviceToHost, ctx->stream));
-        if (n2) gather_opening_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, ctx->stream>>>(nullptr, t->d_nodes, t->n_leaves, 0, t->layout, logn, m_idx, k, 0,
-                                                                                          m_leaves, m_sib, m_path, false);
+        PK_HIP(ctx, hipMemcpyAsync(m_leaves, d_rows, 32 * n_red, hipMemcpyDeviceToHost, ctx->stream));
+        if (!sub && n2) gather_opening_kernel<<<(unsigned)((n2 + 255) / 256), 256, 0, ctx->stream>>>(nullptr, t->d_nodes, t->n_leaves, 0, t->layout, logn, m_idx, k, 0,
+                                                                                                  m_leaves, m_sib, m_path, false);
     } else {
         gather_opening_kernel<<<(unsigned)((n1 + n2 + 255) / 256), 256, 0, ctx->stream>>>(t->d_leaves, t->d_nodes, t->n_leaves, (unsigned)t->width, t->layout,
                                                                                           logn, m_idx, k, canonical_leaves, m_leaves, m_sib, m_path, t->scaled);

@@ -9,7 +9,7 @@ src, pat = sys.argv[1], sys.argv[2]
 top = int(sys.argv[3]) if len(sys.argv) > 3 else 25
 cur, hist, label = None, collections.Counter(), None
 for line in open(src):
-    m = re.match(r"^(_Z\w+):", line)
+    m = re.match(r"^(\w+):", line)
     if m:
         cur = m.group(1) if pat in m.group(1) else None
         if cur:
