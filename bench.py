@@ -623,20 +623,27 @@ def main():
             print(f"[bench] h2d probe failed: {e}", file=sys.stderr)
         finally:
             args.h2d = False
-    # (b) BASELINE configs[4]: the 2^26 commit -- on one GPU, or SHARDED over the ranks of the run (every rank takes part)
-    commit_fig = None
-    if m == 21 and not args.sharded and not args.no_commit_probe:
+    # (b) BASELINE configs[4]: the 2^26 commit -- on one GPU, or SHARDED over the ranks of the run (every rank takes part).  On one
+    # GPU it runs AFTER the size classes (its 17 GB of buffers, just released, were measured to slow the m = 25 provers that follow);
+    # with several ranks it runs first, so that the other ranks are not left waiting in its collectives while rank 0 proves
+    def run_commit_probe():
+        if not (m == 21 and not args.sharded and not args.no_commit_probe):
+            return None
         try:
             cctx, keep = ctx, None
             if world > 1:
                 cctx = provekit_amd.Context(local_rank)
                 keep = join_device_set(cctx, rank, world, dist, "host" if one_gpu else "rccl")  # noqa: F841 (kept alive)
-            commit_fig = commit_probe(cctx, torch, local_rank, n_vars=args.commit_log2_size, world=world, dist=dist, one_gpu=one_gpu)
+            fig = commit_probe(cctx, torch, local_rank, n_vars=args.commit_log2_size, world=world, dist=dist, one_gpu=one_gpu)
             if world > 1:
                 cctx.comm_destroy()
                 cctx.close()
+            torch.cuda.empty_cache()
+            return fig
         except Exception as e:  # e.g. a GPU with less memory
-            commit_fig = {"error": str(e)[:200]}
+            return {"error": str(e)[:200]}
+
+    commit_fig = run_commit_probe() if world > 1 else None
     # (c) the other BASELINE size classes (configs[2] m = 23, configs[3] m = 25), rank 0's GPU only
     size_figs = {}
     if rank == 0 and m == 21 and not args.sharded and args.size_classes:
@@ -645,6 +652,8 @@ def main():
                 size_figs[str(mm)] = size_class_probe(provekit_amd, torch, local_rank, mm)
             except Exception as e:  # noqa: BLE001
                 size_figs[str(mm)] = {"error": str(e)[:200]}
+    if world == 1:
+        commit_fig = run_commit_probe()
     if dist is not None:
         dist.barrier()
 

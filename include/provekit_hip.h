@@ -535,6 +535,9 @@ int pk_selftest_modmul_rate_fp52(pk_ctx *ctx, unsigned waves_per_simd, unsigned 
 /* one Fiat-Shamir round trip as pk_prove makes it (launch + stream synchronisation) against the same round trip
  * through a persistent kernel's pinned mailbox, `host_work_permutes` sponge permutations of host work in between; microseconds per
  * round over `rounds` dependent round trips (tools/roundtrip.py, profiles/r04_roundtrip.json). */
+/* products by a constant per second, register-resident chains: the Montgomery product (mont261_29, shoup = 0) against the Shoup form
+ * with a precomputed quotient (shoup261_29, shoup = 1: 143 multiply-adds instead of 162 + 9); csrc/fe29.hpp */
+int pk_selftest_constmul_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, int shoup, double *modmul_per_s);
 int pk_selftest_roundtrip(pk_ctx *ctx, unsigned rounds, unsigned host_work_permutes, double *us_per_round_launch,
                           double *us_per_round_mailbox);
 int pk_selftest_mfma_reduce(pk_ctx *ctx, const uint32_t *d_t_limbs, int32_t *d_out, size_t n);

@@ -236,6 +236,97 @@ PK_HD fe29 mont261_29(const fe29& a, const fe29& b) {
     return reduce261_29(acc);
 }
 
+// ---- multiplication by a CONSTANT with a precomputed quotient (Shoup / Barrett on 29-bit limbs) -------------------------------
+// For a multiplier w known in advance (a twiddle, a round's folding challenge) keep wq = floor(w * 2^261 / p) next to it.  Then
+//     q = floor(a * wq / 2^261)   is floor(a * w / p) or one or two less (a < 8p; wq may itself be up to 2 short), and
+//     r = a * w - q * p           is a * w mod p plus at most two p's: r < 2.2 p,
+// and r needs only the LOW nine limbs of a*w and of q*p (it is smaller than 2^261), q only the HIGH columns of a*wq: columns 0..6
+// of that product change it by less than 2^-22.  53 + 45 + 45 = 143 multiply-adds and no per-step quotient digit, against the
+// 162 + 9 of a Montgomery product (mont261_29) -- and the value stays in whatever domain `a` is in (a Montgomery image times a plain
+// w is the Montgomery image of the product).  q*p is subtracted as q*(2^261 - p) added, the 2^261 multiple falling off limb 8.
+// a: limbs < 2^30.7 (lazy), value < 8p.  w, wq: normalised (limbs < 2^29).  Result normalised, < 2.2p.
+PK_HD constexpr u32 pcomp29(int k) {  // limb k of 2^261 - p
+    long long borrow = 0;
+    u32 out = 0;
+    for (int i = 0; i <= k; i++) {
+        long long d = -(long long)p29(i) + borrow;
+        borrow = d < 0 ? -1 : 0;
+        out = (u32)(d & (long long)M29);
+    }
+    return out;
+}
+PK_HD fe29 shoup261_29(const fe29& a, const fe29& w, const fe29& wq) {
+    u64 c[10];  // columns 7 .. 16 of a * wq
+#pragma unroll
+    for (int k = 0; k < 10; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            if (i + j >= 7) c[i + j - 7] += (u64)a.v[i] * wq.v[j];
+    c[1] += c[0] >> 29;
+    c[2] += c[1] >> 29;
+    u32 q[9];
+#pragma unroll
+    for (int k = 2; k < 9; k++) {
+        c[k + 1] += c[k] >> 29;
+        q[k - 2] = (u32)c[k] & M29;
+    }
+    q[7] = (u32)c[9] & M29;
+    q[8] = (u32)(c[9] >> 29);
+    u64 r[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) r[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            if (i + j <= 8) {
+                r[i + j] += (u64)a.v[i] * w.v[j];
+                r[i + j] += (u64)q[i] * pcomp29(j);
+            }
+    fe29 out;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        r[k + 1] += r[k] >> 29;
+        out.v[k] = (u32)r[k] & M29;
+    }
+    out.v[8] = (u32)r[8] & M29;
+    return out;
+}
+// wq = floor(w * 2^261 / p) for a normalised w < p: 261 steps of binary long division (tests; tables use the Barrett form)
+PK_HD fe29 shoup_quotient29(const fe29& w) {
+    u32 r[9], q[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        r[k] = w.v[k];
+        q[k] = 0;
+    }
+    for (int bit = 260; bit >= 0; bit--) {
+        u32 carry = 0;  // r = 2r (r < p < 2^254: no overflow of limb 8)
+        for (int k = 0; k < 9; k++) {
+            const u32 v = (r[k] << 1) | carry;
+            carry = v >> 29;
+            r[k] = v & M29;
+        }
+        int borrow = 0;  // t = r - p
+        u32 t[9];
+        for (int k = 0; k < 9; k++) {
+            int d = (int)r[k] - (int)p29(k) + borrow;
+            borrow = d >> 29;
+            t[k] = (u32)d & M29;
+        }
+        if (!borrow) {
+            for (int k = 0; k < 9; k++) r[k] = t[k];
+            q[bit / 29] |= 1u << (bit % 29);
+        }
+    }
+    fe29 out;
+#pragma unroll
+    for (int k = 0; k < 9; k++) out.v[k] = q[k];
+    return out;
+}
+
 // ---- sums of products with one reduction per group ------------------------------------------------
 // sum_t a_t * b_t (mod p) the cheap way: the 17 column accumulators take the partial products of up to DOT29_GROUP terms
 // before ONE Montgomery reduction (81 multiply-adds per term instead of 162).  a_t: any 256-bit value (unpack29<0>),

@@ -67,6 +67,21 @@ PK_HD fe selftest_op(int op, const fe& x, const fe& y) {
             r = dot29_result(d);
             break;
         }
+        case 24: {  // shoup261_29: x * y mod p for y < p, x any value below 8p (here < 2^256 ~ 5.3p); result almost reduced then exact
+            fe29 w = cond_sub_p29(unpack_reduce29(y));
+            fe29 t = shoup261_29(unpack29<0>(x), w, shoup_quotient29(w));
+            reduce_almost29(t);
+            r = pack29(cond_sub_p29(t));
+            break;
+        }
+        case 25: {  // the same with lazy limbs on the multiplicand: (x + y + 2p) * y, limbs < 2^30.6 as the butterflies make them
+            fe29 w = cond_sub_p29(unpack_reduce29(y));
+            fe29 a = add29(unpack_reduce29(x), w);
+            fe29 t = shoup261_29(a, w, shoup_quotient29(w));
+            reduce_almost29(t);
+            r = pack29(cond_sub_p29(t));
+            break;
+        }
         case 21: r = fe_inverse_mont(x); break;   // feinv.hpp: Montgomery in, Montgomery out (0 -> 0)
         case 22: r = fe_inverse_plain(x); break;  // plain integers mod p, constant sequence
         case 23: r = fe_inverse_plain_var(x); break;  // the same, variable-time steps
@@ -105,6 +120,29 @@ __global__ __launch_bounds__(256) void modmul_rate_kernel(const fe* __restrict__
 }
 
 // ---- the f64-FMA multiplier prototype (fe52.hpp) ----------------------------------------------------------------------------
+// general products by a constant: Montgomery (mont261_29) against Shoup (shoup261_29), register-resident chains
+template <int ILP, bool SHOUP>
+__global__ __launch_bounds__(256) void constmul_rate_kernel(const fe* __restrict__ in, fe* __restrict__ out, unsigned iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    fe29 x[ILP];
+    const fe29 w = unpack_reduce29(fe_load(in + ((i + 1) % 64)));
+    const fe29 wq = unpack_reduce29(fe_load(in + ((i + 2) % 64)));
+#pragma unroll
+    for (int k = 0; k < ILP; k++) {
+        x[k] = unpack_reduce29(fe_load(in + (i % 64)));
+        x[k].v[0] += (u32)k;
+    }
+    for (unsigned it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < ILP; k++) x[k] = SHOUP ? shoup261_29(x[k], w, wq) : mont261_29(x[k], w);
+    }
+    fe29 acc = x[0];
+#pragma unroll
+    for (int k = 1; k < ILP; k++) acc = add29(acc, x[k]);
+    normalize29(acc);
+    if (acc.v[8] == 0xffffffffu) fe_store(out + i, pack29(acc));
+}
+
 __global__ void fp52_sqr_kernel(const fe* a, u64* out, size_t n) {
     f52_enter_rtz();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -312,6 +350,36 @@ int pk_selftest_modmul_rate_fp52(pk_ctx* ctx, unsigned waves_per_simd, unsigned 
     return PK_OK;
 }
 
+// products by a constant per second: shoup = 0 the Montgomery product the NTT uses today, 1 the Shoup form
+int pk_selftest_constmul_rate(pk_ctx* ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, int shoup, double* modmul_per_s) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, modmul_per_s && waves_per_simd >= 1 && waves_per_simd <= 8 && (ilp == 1 || ilp == 2) && iters >= 1, "bad argument");
+    int rc = ensure_scratch(ctx, 1 << 20);
+    if (rc) return rc;
+    const unsigned blocks = (unsigned)ctx->num_cus * waves_per_simd;
+    fe* in = (fe*)ctx->d_scratch;
+    fe* out = in + 64;
+    PK_HIP(ctx, hipMemsetAsync(in, 0x11, 64 * 32, ctx->stream));
+    auto launch = [&](unsigned n) {
+        if (shoup) {
+            if (ilp == 1) constmul_rate_kernel<1, true><<<blocks, 256, 0, ctx->stream>>>(in, out, n);
+            else constmul_rate_kernel<2, true><<<blocks, 256, 0, ctx->stream>>>(in, out, n);
+        } else {
+            if (ilp == 1) constmul_rate_kernel<1, false><<<blocks, 256, 0, ctx->stream>>>(in, out, n);
+            else constmul_rate_kernel<2, false><<<blocks, 256, 0, ctx->stream>>>(in, out, n);
+        }
+    };
+    launch(16);
+    PK_LAUNCH_CHECK(ctx);
+    float ms = 0;
+    if ((rc = pk_timer_start(ctx))) return rc;
+    launch(iters);
+    PK_LAUNCH_CHECK(ctx);
+    if ((rc = pk_timer_stop(ctx, &ms))) return rc;
+    *modmul_per_s = (double)blocks * 256.0 * ilp * iters / (ms * 1e-3);
+    return PK_OK;
+}
+
 int pk_selftest_modmul_rate(pk_ctx* ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double* modmul_per_s) {
     if (!ctx || !modmul_per_s) return PK_ERR_BAD_ARG;
     PK_ENTER(ctx);
@@ -366,10 +434,10 @@ int pk_selftest_permute(uint64_t l[4], uint64_t r[4]) {
 // op: 0 fe_mul29(a,b)  1 compress v2  2 compress v1  3 from_mont  4 a*b*2^-256 via mont256_29  5 a^2*2^-256 via sqr256_29
 // a, b, out: n field elements (4 x u64 each).  Host only; no device needed.
 int pk_selftest_arith(int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
-    if (!a || !out || (!b && (op == 0 || op == 1 || op == 2 || op == 4 || op == 15 || op == 16 || op == 19 || op == 20))) return PK_ERR_BAD_ARG;
+    if (!a || !out || (!b && (op == 0 || op == 1 || op == 2 || op == 4 || op == 15 || op == 16 || op == 19 || op == 20 || op == 24 || op == 25))) return PK_ERR_BAD_ARG;
     for (size_t i = 0; i < n; i++) {
         fe x = load_host(a + 4 * i), y = b ? load_host(b + 4 * i) : x;
-        if (op < 0 || op > 23) return PK_ERR_BAD_ARG;
+        if (op < 0 || op > 25) return PK_ERR_BAD_ARG;
         fe r = selftest_op(op, x, y);
         store_host(out + 4 * i, r);
     }

@@ -205,3 +205,15 @@ def test_safegcd_inverse_is_the_field_inverse(oracle):
     assert oracle.limbs_to_ints(run(22, a)) == want
     assert oracle.limbs_to_ints(run(23, a)) == want  # the variable-time steps (what the witness builders run)
     assert oracle.limbs_to_ints(oracle.from_mont(run(21, oracle.to_mont(a)))) == want
+
+
+def test_shoup_product_by_a_constant(oracle):
+    """shoup261_29 (fe29.hpp): a * w mod p with the precomputed quotient floor(w 2^261 / p) -- 143 multiply-adds against the
+    Montgomery product's 171 -- on the host build of the device source: any 256-bit multiplicand (up to 5.3 p), every multiplier
+    below p incl. the edges, and the lazy-limb form the NTT butterflies feed it (a sum, limbs above 2^29)"""
+    edge = [0, 1, 2, P - 1, P - 2, (1 << 253), (1 << 29) - 1, (1 << 58) - 1, P // 2, P // 3, (1 << 254) - 1]
+    xs = [a for a in edge + [(1 << 256) - 1, 5 * P, 2 * P + 1] for _ in edge] + rand_fe(4000, 31, 1 << 256)
+    ys = [b for _ in edge + [0, 0, 0] for b in edge] + rand_fe(4000, 32)
+    a, b = oracle.ints_to_limbs(xs), oracle.ints_to_limbs(ys)
+    assert oracle.limbs_to_ints(run(24, a, b)) == [x * (y % P) % P for x, y in zip(xs, ys)]
+    assert oracle.limbs_to_ints(run(25, a, b)) == [((x % P) + (y % P)) * (y % P) % P for x, y in zip(xs, ys)]

@@ -36,7 +36,27 @@ if kind == "prove":
            "workload": f"bench.py prove, m={m}, --concurrency 1 (tools/pmc.sh)", "dispatches": n, "kernels": ks,
            "fetch_size_kib_per_dispatch": fetch / n, "write_size_kib_per_dispatch": write / n, "correction": CORR,
            "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024.0 / n}
-    path = os.path.join(ROOT, "profiles", f"{prefix}_pmc_leaf_hash.json")
+    path = os.path.join(ROOT, "profiles", f"{prefix}_pmc_leaf_hash.json" if m == 21 else f"{prefix}_m{m}_pmc_leaf_hash.json")
+    # the RS-encode kernels of the same run (BASELINE configs[2] asks for the NTT's HBM figures at the sha256 size class too)
+    nk = {**per_kernel("ntt8_pass_kernel"), **per_kernel("deinterleave_kernel"), **per_kernel("ntt_pass_kernel")}
+    if nk:
+        proofs = max(1, round(n / 7.0))  # 7 leaf-hash launches per proof (5 witness-WHIR trees + 2 blinding trees)
+        elems = 0
+        for n_vars, batch, rounds in ((m, 2, m // 4 - 1), (None, 2, None)):
+            if n_vars is None:
+                break
+            rows = 1 << (n_vars + 1 - 4)
+            elems += rows * 16 * batch
+            for _ in range(rounds):
+                rows >>= 1
+                elems += rows * 16
+        nf, nw = sum(v["fetch_kib"] for v in nk.values()), sum(v["write_kib"] for v in nk.values())
+        traffic = (2.0 * nf + nw) * 1024.0 / proofs
+        ntt = {"kernels": "deinterleave_kernel + ntt8_pass_kernel + ntt_pass_kernel of one proof (all RS-encodes)", "lib_sha16": sha, "m": m,
+               "workload": f"bench.py prove, m={m}, --concurrency 1 (tools/pmc.sh)", "proofs_in_the_trace": proofs, "per_kernel": nk,
+               "correction": CORR, "codeword_elements_per_proof_witness_whir": elems, "algorithmic_bytes_per_proof": 64.0 * elems,
+               "traffic_bytes_per_proof": traffic, "traffic_over_algorithmic": traffic / (64.0 * elems)}
+        json.dump(ntt, open(os.path.join(ROOT, "profiles", f"{prefix}_pmc_ntt_m{m}.json"), "w"), indent=1)
 else:
     log2, runs = int(sys.argv[4]), int(sys.argv[5])
     ks = {**per_kernel("ntt8_pass_kernel"), **per_kernel("deinterleave_kernel"), **per_kernel("leaf_hash_kernel")}
