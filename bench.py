@@ -459,6 +459,10 @@ def main():
     ap.add_argument("--commit-log2-size", type=int, default=26, help="log2 coefficients of the secondary commit figure (26 = BASELINE configs[4])")
     ap.add_argument("--size-classes", default="23,25",
                     help="other BASELINE size classes reported as secondary keys of the default line (configs[2]: 23, configs[3]: 25); '' = none")
+    ap.add_argument("--size-class-probe", type=int, default=0,
+                    help="internal: run ONE size-class probe in this (fresh) process and print its JSON object; the default line spawns one "
+                         "such process per class, because large buffers allocated after others were released in the same process run up to "
+                         "25 %% slower (measured: m = 25 15.1 -> 12.3 proofs/s, 2^26 commit 57.8 -> 74.6 ms; not clocks -- tools/throttle_probe.py)")
     ap.add_argument("--no-h2d-probe", action="store_true", help="skip the secondary PCIe-inclusive rate (witness uploaded before every proof)")
     ap.add_argument("--workload", choices=["prove", "commit"], default="prove",
                     help="prove = BASELINE configs[1] (default, the judged line); commit = one batch-2 WHIR commit of 2^m coefficients "
@@ -515,6 +519,8 @@ def main():
 
     if args.workload == "commit":
         return commit_workload(args, rank, local_rank, world, dist, torch)
+    if args.size_class_probe:
+        return emit(size_class_probe(provekit_amd, torch, local_rank, args.size_class_probe))
 
     import threading
 
@@ -607,25 +613,7 @@ def main():
             peak_modmul = max(peak_modmul, r.value)
 
     # ---- secondary figures of the default line (each guarded: none may break the line) -----------------------------------
-    # (a) PCIe-inclusive rate: the same waves with the witness uploaded before every proof
-    h2d_rate = None
-    if not args.h2d and not args.sharded and not args.no_h2d_probe:
-        try:
-            args.h2d = True
-            run_proofs(200000, conc)
-            barrier()
-            t1 = time.perf_counter()
-            run_proofs(300000, 4 * conc)
-            barrier()
-            h2d_rate = world * 4 * conc / max_over_ranks(time.perf_counter() - t1, dist, None if one_gpu else f"cuda:{local_rank}")
-        except Exception as e:  # noqa: BLE001
-            h2d_rate = None
-            print(f"[bench] h2d probe failed: {e}", file=sys.stderr)
-        finally:
-            args.h2d = False
-    # (b) BASELINE configs[4]: the 2^26 commit -- on one GPU, or SHARDED over the ranks of the run (every rank takes part).  On one
-    # GPU it runs AFTER the size classes (its 17 GB of buffers, just released, were measured to slow the m = 25 provers that follow);
-    # with several ranks it runs first, so that the other ranks are not left waiting in its collectives while rank 0 proves
+    # (b) BASELINE configs[4]: the 2^26 commit -- on one GPU, or SHARDED over the ranks of the run (every rank takes part)
     def run_commit_probe():
         if not (m == 21 and not args.sharded and not args.no_commit_probe):
             return None
@@ -643,17 +631,40 @@ def main():
         except Exception as e:  # e.g. a GPU with less memory
             return {"error": str(e)[:200]}
 
-    commit_fig = run_commit_probe() if world > 1 else None
+    commit_fig = run_commit_probe()  # before anything else allocates and releases large buffers in this process
     # (c) the other BASELINE size classes (configs[2] m = 23, configs[3] m = 25), rank 0's GPU only
     size_figs = {}
     if rank == 0 and m == 21 and not args.sharded and args.size_classes:
+        import subprocess
+
         for mm in [int(x) for x in args.size_classes.split(",") if x.strip()]:
-            try:
-                size_figs[str(mm)] = size_class_probe(provekit_amd, torch, local_rank, mm)
+            try:  # a fresh process per class on this GPU (see --size-class-probe); this one keeps its provers, idle, meanwhile
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "TORCHELASTIC_RUN_ID", "PK_BENCH_FORCE_DIST")}
+                env["LOCAL_RANK"] = str(local_rank)  # the same device; no process group in the child
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--size-class-probe", str(mm)], env=env, capture_output=True, text=True,
+                                     timeout=600)
+                lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+                size_figs[str(mm)] = json.loads(lines[-1]) if out.returncode == 0 and lines else {"error": (out.stderr or "no output")[-200:]}
             except Exception as e:  # noqa: BLE001
                 size_figs[str(mm)] = {"error": str(e)[:200]}
-    if world == 1:
-        commit_fig = run_commit_probe()
+    # (a) PCIe-inclusive rate: the same waves with the witness uploaded before every proof.  LAST: the pageable host-to-device copies leave
+    # the runtime in a state in which later large kernels run up to 25 % slower (measured: 2^26 commit 57.8 -> 74.6 ms, m = 25 15.1 -> 12.3
+    # proofs/s when this probe ran first), which would falsify the figures above it
+    h2d_rate = None
+    if not args.h2d and not args.sharded and not args.no_h2d_probe:
+        try:
+            args.h2d = True
+            run_proofs(200000, 2 * conc)
+            barrier()
+            t1 = time.perf_counter()
+            run_proofs(300000, 8 * conc)
+            barrier()
+            h2d_rate = world * 8 * conc / max_over_ranks(time.perf_counter() - t1, dist, None if one_gpu else f"cuda:{local_rank}")
+        except Exception as e:  # noqa: BLE001
+            h2d_rate = None
+            print(f"[bench] h2d probe failed: {e}", file=sys.stderr)
+        finally:
+            args.h2d = False
     if dist is not None:
         dist.barrier()
 
