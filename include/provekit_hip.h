@@ -68,6 +68,13 @@ int pk_ctx_destroy(pk_ctx *ctx);
 const char *pk_last_error(const pk_ctx *ctx);
 /* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream */
 int pk_ctx_set_stream(pk_ctx *ctx, void *hip_stream);
+/* Latency mode (default off).  For ONE proof at a time on an otherwise idle GPU (BASELINE configs[3]'s latency case): pk_prove
+ * enqueues each sumcheck round one ahead -- the next round's kernel, or the closing fold, is already in the queue, gated on a word of the
+ * pinned host page, while the host absorbs the current round's three evaluations and squeezes the challenge -- so those Fiat-Shamir round
+ * trips cost the host link's latency instead of a kernel launch plus a stream synchronisation (4 us against 15, profiles/r04_roundtrip.json).
+ * The transcript is byte-identical either way.  Leave it off when several provers share the GPU: a gated kernel holds its workgroup
+ * slots while it waits for the host. */
+int pk_ctx_set_latency_mode(pk_ctx *ctx, int on);
 int pk_ctx_sync(pk_ctx *ctx);
 /* Skyscraper version used by every hashing entry point: 2 (default; HEAD of the
  * reference, provekit/common/src/skyscraper/whir.rs:23) or 1 (skyscraper/core/src/v1.rs;

@@ -190,6 +190,12 @@ int pk_profile_names(pk_ctx* ctx, char* buf, size_t cap) {
     return PK_OK;
 }
 
+int pk_ctx_set_latency_mode(pk_ctx* ctx, int on) {
+    if (!ctx) return PK_ERR_BAD_ARG;
+    ctx->latency_mode = on != 0;
+    return PK_OK;
+}
+
 }  // extern "C"
 
 namespace pk {

@@ -41,6 +41,13 @@ struct pk_ctx {
     std::map<unsigned, void*> twiddles_pass;   // inter-pass twiddles in access order, per (size, pass, variant) (ntt.hip get_pass_table)
     std::map<unsigned, void*> twiddles_scaled;  // log2(N) -> 32 * w_N^e as plain integers: the hash-ready output scaling (ntt.hip)
     unsigned red_seq = 0;  // sequence number of the last reduction launch (completion flag in h_pinned)
+    // Latency mode (pk_ctx_set_latency_mode; ONE proof at a time on this context, the chip otherwise idle): the rounds of a sumcheck
+    // are enqueued one ahead -- round k+1's kernel is already in the queue, gated on a word of the pinned page, while the host
+    // absorbs round k's result and squeezes the challenge -- so a Fiat-Shamir round trip costs the link latency (~2 us) instead of a
+    // kernel launch + stream synchronisation (~13 us; profiles/r04_roundtrip.json).  Off by default: a gated kernel occupies its
+    // workgroup slots while it waits, which is wasted capacity when other provers share the chip.
+    bool latency_mode = false;
+    unsigned gate_seq = 0;  // sequence number of the last gate handed out (reduce.hpp)
     void* d_ws = nullptr;  // large reusable workspace (NTT scratch); grows, never shrinks
     size_t ws_bytes = 0;
     // "mailbox": device-visible pinned host memory the kernels read small inputs from and write small outputs to, so
@@ -63,6 +70,7 @@ struct pk_ctx {
 // fixed slots in the 4 KiB h_pinned page: [0,1024) reduction results, word 256 completion flag (reduce.hpp)
 #define PK_PIN_ROOT 2048 /* 32 B: the root of the last Merkle tree built on this context (hash.hip) */
 #define PK_PIN_POW 2112  /* 8 B: the nonce found by the last proof-of-work launch (pow.hip) */
+#define PK_PIN_GATE 2304 /* 64 B: [u32 seq | 28 B pad | 32 B challenge] -- the host publishes a round's challenge here (reduce.hpp gate) */
 
 // A launch too small to fill the chip is latency-bound, and it sits on some prover's Fiat-Shamir critical path while the
 // chip-filling kernels of the other provers share its SIMDs: let its wavefronts issue ahead of theirs (s_setprio 3).  The

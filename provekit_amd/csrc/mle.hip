@@ -230,12 +230,12 @@ __global__ __launch_bounds__(256) void eq_accumulate_kernel(fe* __restrict__ w, 
 // provekit/prover/src/whir_r1cs.rs:284-291.
 template <bool FOLD>
 __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_kernel(fe* __restrict__ a, fe* __restrict__ b, fe* __restrict__ c,
-                                                                     fe* __restrict__ eq, size_t len, fe_arg fold_arg,
+                                                                     fe* __restrict__ eq, size_t len, fe_arg fold_arg, gate_args gate,
                                                                      fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                                      fe* __restrict__ result, unsigned seq) {
     PK_LATENCY_PRIO();
     __shared__ uint4 smem[3 * 16];
-    const fe alpha = from_arg(fold_arg);
+    const fe alpha = (FOLD && gate.host) ? gate_wait(gate) : from_arg(fold_arg);
     const size_t npairs = FOLD ? len / 4 : len / 2;
     const size_t off = npairs;          // partner of i is i + off (quarter 1 after folding, or the upper half)
     const size_t foff = len / 2;        // fold partner: p2 = p0 + len/2
@@ -275,12 +275,12 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_kernel(fe* __restr
 // FOLD: first v'[i] = v[2i] + r (v[2i+1]-v[2i]) written to the *_out arrays (out-of-place).
 template <bool FOLD>
 __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_kernel(const fe* __restrict__ f, const fe* __restrict__ w,
-                                                                         size_t out_len, fe_arg fold_arg, fe* __restrict__ f_out,
+                                                                         size_t out_len, fe_arg fold_arg, gate_args gate, fe* __restrict__ f_out,
                                                                          fe* __restrict__ w_out, fe* __restrict__ partials,
                                                                          unsigned* __restrict__ ticket, fe* __restrict__ result, unsigned seq) {
     PK_LATENCY_PRIO();
     __shared__ uint4 smem[3 * 16];
-    const fe r = from_arg(fold_arg);
+    const fe r = (FOLD && gate.host) ? gate_wait(gate) : from_arg(fold_arg);
     fe acc[3] = {fe_zero(), fe_zero(), fe_zero()};
     const size_t npairs = out_len / 2;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -318,13 +318,13 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_kernel(const f
 constexpr size_t SMALL_ROUND_PAIRS = 16384;
 
 __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_small_kernel(fe* __restrict__ a, fe* __restrict__ b, fe* __restrict__ c,
-                                                                           fe* __restrict__ eq, size_t len, fe_arg fold_arg,
+                                                                           fe* __restrict__ eq, size_t len, fe_arg fold_arg, gate_args gate,
                                                                            fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                                            fe* __restrict__ result, unsigned seq) {
     PK_LATENCY_PRIO();
     __shared__ uint4 smem[3 * 16];
     __shared__ uint4 xs[2 * RED_THREADS];  // folded value of lane t at [t] (lo) and [RED_THREADS + t] (hi)
-    const fe alpha = from_arg(fold_arg);
+    const fe alpha = gate.host ? gate_wait(gate) : from_arg(fold_arg);
     const size_t npairs = len / 4, off = npairs, foff = len / 2;
     const unsigned tid = threadIdx.x, g = tid >> 3, role = tid & 7, k = role >> 1, which = role & 1;
     const size_t i = (size_t)blockIdx.x * (RED_THREADS / 8) + g;
@@ -372,13 +372,13 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_cubic_small_kernel(fe* _
 
 template <bool FOLD>
 __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_small_kernel(const fe* __restrict__ f, const fe* __restrict__ w, size_t out_len,
-                                                                               fe_arg fold_arg, fe* __restrict__ f_out, fe* __restrict__ w_out,
+                                                                               fe_arg fold_arg, gate_args gate, fe* __restrict__ f_out, fe* __restrict__ w_out,
                                                                                fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                                                fe* __restrict__ result, unsigned seq) {
     PK_LATENCY_PRIO();
     __shared__ uint4 smem[3 * 16];
     __shared__ uint4 xs[2 * RED_THREADS];
-    const fe r = from_arg(fold_arg);
+    const fe r = (FOLD && gate.host) ? gate_wait(gate) : from_arg(fold_arg);
     const size_t npairs = out_len / 2;
     const unsigned tid = threadIdx.x, g = tid >> 2, role = tid & 3;  // role: 0 f0, 1 f1, 2 w0, 3 w1
     const size_t i = (size_t)blockIdx.x * (RED_THREADS / 4) + g;
@@ -421,9 +421,9 @@ __global__ __launch_bounds__(RED_THREADS) void sumcheck_quadratic_small_kernel(c
 // the single-element tail of the fold (out_len == 1): v'[0] = v[0] + r (v[1]-v[0]); no pair to sum.  blockIdx.y selects
 // one of up to two arrays folded by the same challenge (the sumcheck's polynomial and its weights) in one launch.
 __global__ void fold_pairs_kernel(const fe* __restrict__ v0, fe* __restrict__ out0, const fe* __restrict__ v1, fe* __restrict__ out1,
-                                  size_t out_len, fe_arg r_arg) {
+                                  size_t out_len, fe_arg r_arg, gate_args gate) {
     PK_LATENCY_PRIO();
-    const fe r = from_arg(r_arg);
+    const fe r = gate.host ? gate_wait(gate) : from_arg(r_arg);
     const fe* v = blockIdx.y ? v1 : v0;
     fe* out = blockIdx.y ? out1 : out0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -664,64 +664,104 @@ int pk_eq_table(pk_ctx* ctx, const uint64_t* r, unsigned m, uint64_t* d_out) {
     return pk_eq_accumulate(ctx, d_out, m, r, one, 1, 1);
 }
 
+}  // extern "C"
+namespace pk {
+// launch only: round results go to the pinned page under sequence number *red_seq_out.  gate_seq != 0 (latency mode, folding rounds
+// only): the folding challenge is not known yet -- the kernel waits for gate_publish(ctx, gate_seq, challenge) (reduce.hpp)
+int sumcheck_cubic_launch(pk_ctx* ctx, uint64_t* d_a, uint64_t* d_b, uint64_t* d_c, uint64_t* d_eq, size_t len, const uint64_t* fold_or_null,
+                          unsigned gate_seq, unsigned* red_seq_out) {
+    PK_REQUIRE(ctx, d_a && d_b && d_c && d_eq && red_seq_out, "null pointer");
+    PK_REQUIRE(ctx, is_pow2(len) && len >= 2, "size must be a power of two >= 2");  // sumcheck.rs:22-23
+    const bool fold = fold_or_null || gate_seq;
+    PK_REQUIRE(ctx, !fold || len >= 4, "size must be >= 4 when folding");    // sumcheck.rs:27
+    int rc = reduction_scratch(ctx);
+    if (rc) return rc;
+    size_t npairs = fold ? len / 4 : len / 2;
+    unsigned blocks = reduction_blocks(ctx, npairs);
+    const gate_args gate = gate_seq ? gate_for(ctx, gate_seq) : gate_none();
+    const fe_arg farg = fold_or_null ? to_arg(fold_or_null) : fe_arg{};
+    const unsigned seq = next_seq(ctx);
+    *red_seq_out = seq;
+    {
+        ProfScope prof(ctx, "sumcheck_cubic");
+        if (fold && npairs <= SMALL_ROUND_PAIRS)
+            sumcheck_cubic_small_kernel<<<(unsigned)((npairs + RED_THREADS / 8 - 1) / (RED_THREADS / 8)), RED_THREADS, 0, ctx->stream>>>(
+                (fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, farg, gate, red_partials(ctx), red_ticket(ctx), red_result(ctx), seq);
+        else if (fold)
+            sumcheck_cubic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, farg, gate,
+                                                                                  red_partials(ctx), red_ticket(ctx), red_result(ctx), seq);
+        else
+            sumcheck_cubic_kernel<false><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, fe_arg{}, gate_none(),
+                                                                                   red_partials(ctx), red_ticket(ctx), red_result(ctx), seq);
+    }
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+int sumcheck_quadratic_launch(pk_ctx* ctx, const uint64_t* d_f, const uint64_t* d_w, size_t len, const uint64_t* fold_or_null, unsigned gate_seq,
+                              uint64_t* d_f_out, uint64_t* d_w_out, unsigned* red_seq_out) {
+    PK_REQUIRE(ctx, d_f && d_w && red_seq_out, "null pointer");
+    PK_REQUIRE(ctx, is_pow2(len), "size must be a power of two");
+    const bool fold = fold_or_null || gate_seq;
+    size_t out_len = fold ? len / 2 : len;
+    PK_REQUIRE(ctx, out_len >= 2, "at least one pair is needed after folding");
+    PK_REQUIRE(ctx, !fold || (d_f_out && d_w_out && d_f_out != d_f && d_w_out != d_w), "folding is out-of-place");
+    int rc = reduction_scratch(ctx);
+    if (rc) return rc;
+    unsigned blocks = reduction_blocks(ctx, out_len / 2);
+    const gate_args gate = gate_seq ? gate_for(ctx, gate_seq) : gate_none();
+    const fe_arg farg = fold_or_null ? to_arg(fold_or_null) : fe_arg{};
+    const unsigned seq = next_seq(ctx);
+    *red_seq_out = seq;
+    {
+        ProfScope prof(ctx, "sumcheck_quadratic");
+        const size_t npairs = out_len / 2;
+        const unsigned sblocks = (unsigned)((npairs + RED_THREADS / 4 - 1) / (RED_THREADS / 4));
+        if (npairs <= SMALL_ROUND_PAIRS && fold)
+            sumcheck_quadratic_small_kernel<true><<<sblocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, farg, gate, (fe*)d_f_out,
+                                                                                            (fe*)d_w_out, red_partials(ctx), red_ticket(ctx),
+                                                                                            red_result(ctx), seq);
+        else if (npairs <= SMALL_ROUND_PAIRS)
+            sumcheck_quadratic_small_kernel<false><<<sblocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, fe_arg{}, gate_none(),
+                                                                                             nullptr, nullptr, red_partials(ctx), red_ticket(ctx),
+                                                                                             red_result(ctx), seq);
+        else if (fold)
+            sumcheck_quadratic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, farg, gate, (fe*)d_f_out,
+                                                                                      (fe*)d_w_out, red_partials(ctx), red_ticket(ctx), red_result(ctx), seq);
+        else
+            sumcheck_quadratic_kernel<false><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, fe_arg{}, gate_none(), nullptr,
+                                                                                       nullptr, red_partials(ctx), red_ticket(ctx), red_result(ctx), seq);
+    }
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+// the host's side of a gated launch and the wait for a launch's three results without draining the stream (prover.hip, latency mode)
+int sumcheck_collect_spin(pk_ctx* ctx, unsigned red_seq, uint64_t out[12]) { return collect_reduction_spin<3>(ctx, red_seq, out); }
+unsigned sumcheck_gate_next(pk_ctx* ctx) { return gate_next(ctx); }
+void sumcheck_gate_publish(pk_ctx* ctx, unsigned gate_seq, const uint64_t challenge[4]) {
+    fe c;
+    memcpy(c.v, challenge, 32);
+    gate_publish(ctx, gate_seq, c);
+}
+}  // namespace pk
+extern "C" {
+
 int pk_sumcheck_cubic_round(pk_ctx* ctx, uint64_t* d_a, uint64_t* d_b, uint64_t* d_c, uint64_t* d_eq, size_t len,
                             const uint64_t* fold_or_null, uint64_t out[12]) {
     PK_ENTER(ctx);
-    PK_REQUIRE(ctx, d_a && d_b && d_c && d_eq && out, "null pointer");
-    PK_REQUIRE(ctx, is_pow2(len) && len >= 2, "size must be a power of two >= 2");  // sumcheck.rs:22-23
-    PK_REQUIRE(ctx, !fold_or_null || len >= 4, "size must be >= 4 when folding");    // sumcheck.rs:27
-    int rc = reduction_scratch(ctx);
+    PK_REQUIRE(ctx, out, "null pointer");
+    unsigned seq = 0;
+    int rc = sumcheck_cubic_launch(ctx, d_a, d_b, d_c, d_eq, len, fold_or_null, 0, &seq);
     if (rc) return rc;
-    size_t npairs = fold_or_null ? len / 4 : len / 2;
-    unsigned blocks = reduction_blocks(ctx, npairs);
-    {
-        ProfScope prof(ctx, "sumcheck_cubic");
-        if (fold_or_null && npairs <= SMALL_ROUND_PAIRS)
-            sumcheck_cubic_small_kernel<<<(unsigned)((npairs + RED_THREADS / 8 - 1) / (RED_THREADS / 8)), RED_THREADS, 0, ctx->stream>>>(
-                (fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, to_arg(fold_or_null), red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
-        else if (fold_or_null)
-            sumcheck_cubic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, to_arg(fold_or_null),
-                                                                                  red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
-        else
-            sumcheck_cubic_kernel<false><<<blocks, RED_THREADS, 0, ctx->stream>>>((fe*)d_a, (fe*)d_b, (fe*)d_c, (fe*)d_eq, len, fe_arg{},
-                                                                                   red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
-    }
-    PK_LAUNCH_CHECK(ctx);
     return collect_reduction<3>(ctx, out);
 }
 
 int pk_sumcheck_quadratic_round(pk_ctx* ctx, const uint64_t* d_f, const uint64_t* d_w, size_t len, const uint64_t* fold_or_null,
                                 uint64_t* d_f_out, uint64_t* d_w_out, uint64_t out[12]) {
     PK_ENTER(ctx);
-    PK_REQUIRE(ctx, d_f && d_w && out, "null pointer");
-    PK_REQUIRE(ctx, is_pow2(len), "size must be a power of two");
-    size_t out_len = fold_or_null ? len / 2 : len;
-    PK_REQUIRE(ctx, out_len >= 2, "at least one pair is needed after folding");
-    PK_REQUIRE(ctx, !fold_or_null || (d_f_out && d_w_out && d_f_out != d_f && d_w_out != d_w), "folding is out-of-place");
-    int rc = reduction_scratch(ctx);
+    PK_REQUIRE(ctx, out, "null pointer");
+    unsigned seq = 0;
+    int rc = sumcheck_quadratic_launch(ctx, d_f, d_w, len, fold_or_null, 0, d_f_out, d_w_out, &seq);
     if (rc) return rc;
-    unsigned blocks = reduction_blocks(ctx, out_len / 2);
-    {
-        ProfScope prof(ctx, "sumcheck_quadratic");
-        const size_t npairs = out_len / 2;
-        const unsigned sblocks = (unsigned)((npairs + RED_THREADS / 4 - 1) / (RED_THREADS / 4));
-        if (npairs <= SMALL_ROUND_PAIRS && fold_or_null)
-            sumcheck_quadratic_small_kernel<true><<<sblocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, to_arg(fold_or_null),
-                                                                                            (fe*)d_f_out, (fe*)d_w_out, red_partials(ctx),
-                                                                                            red_ticket(ctx), red_result(ctx), next_seq(ctx));
-        else if (npairs <= SMALL_ROUND_PAIRS)
-            sumcheck_quadratic_small_kernel<false><<<sblocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, fe_arg{}, nullptr,
-                                                                                             nullptr, red_partials(ctx), red_ticket(ctx),
-                                                                                             red_result(ctx), next_seq(ctx));
-        else if (fold_or_null)
-            sumcheck_quadratic_kernel<true><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, to_arg(fold_or_null),
-                                                                                      (fe*)d_f_out, (fe*)d_w_out, red_partials(ctx), red_ticket(ctx),
-                                                                                      red_result(ctx), next_seq(ctx));
-        else
-            sumcheck_quadratic_kernel<false><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_f, (const fe*)d_w, out_len, fe_arg{}, nullptr, nullptr,
-                                                                                       red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
-    }
-    PK_LAUNCH_CHECK(ctx);
     return collect_reduction<3>(ctx, out);
 }
 
@@ -729,7 +769,7 @@ int pk_fold_pairs(pk_ctx* ctx, const uint64_t* d_v, size_t len, const uint64_t* 
     PK_ENTER(ctx);
     PK_REQUIRE(ctx, d_v && d_out && r && d_v != d_out, "null or aliased pointer");
     PK_REQUIRE(ctx, is_pow2(len) && len >= 2, "size must be a power of two >= 2");
-    fold_pairs_kernel<<<grid_for(ctx, len / 2, 256), 256, 0, ctx->stream>>>((const fe*)d_v, (fe*)d_out, nullptr, nullptr, len / 2, to_arg(r));
+    fold_pairs_kernel<<<grid_for(ctx, len / 2, 256), 256, 0, ctx->stream>>>((const fe*)d_v, (fe*)d_out, nullptr, nullptr, len / 2, to_arg(r), gate_none());
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
 }
@@ -744,14 +784,25 @@ int lincomb2(pk_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* 
     return PK_OK;
 }
 // two arrays of the same length folded by the same challenge in one launch (the sumcheck's p and w)
-int fold_pairs2(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint64_t* d_v1, uint64_t* d_out1, size_t len, const uint64_t* r) {
-    PK_REQUIRE(ctx, d_v0 && d_out0 && d_v1 && d_out1 && r, "null pointer");
+// r = NULL with gate_seq != 0: the challenge arrives through the gate (latency mode)
+int fold_pairs2_gated(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint64_t* d_v1, uint64_t* d_out1, size_t len, const uint64_t* r,
+                      unsigned gate_seq) {
+    PK_REQUIRE(ctx, d_v0 && d_out0 && d_v1 && d_out1 && (r || gate_seq), "null pointer");
     PK_REQUIRE(ctx, is_pow2(len) && len >= 2, "size must be a power of two >= 2");
+    if (gate_seq) {
+        int rc = reduction_scratch(ctx);
+        if (rc) return rc;
+    }
     ProfScope prof(ctx, "fold_pairs");
     fold_pairs_kernel<<<dim3(grid_for(ctx, len / 2, 256), 2), 256, 0, ctx->stream>>>((const fe*)d_v0, (fe*)d_out0, (const fe*)d_v1, (fe*)d_out1,
-                                                                                     len / 2, to_arg(r));
+                                                                                     len / 2, r ? to_arg(r) : fe_arg{},
+                                                                                     gate_seq ? gate_for(ctx, gate_seq) : gate_none());
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
+}
+int fold_pairs2(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint64_t* d_v1, uint64_t* d_out1, size_t len, const uint64_t* r) {
+    PK_REQUIRE(ctx, r, "null pointer");
+    return fold_pairs2_gated(ctx, d_v0, d_out0, d_v1, d_out1, len, r, 0);
 }
 }  // namespace pk
 extern "C" {

@@ -35,6 +35,16 @@ unsigned shard_factor(const pk_ctx* ctx, size_t rows);
 size_t commit_scratch_fes(const pk_ctx* ctx, size_t rows, size_t width);
 int lincomb2(pk_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* beta, const uint64_t* d_b, size_t n);
 int fold_pairs2(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint64_t* d_v1, uint64_t* d_out1, size_t len, const uint64_t* r);
+// latency mode (ctx.hpp): launch-only rounds, gated on a challenge the host publishes later (mle.hip, reduce.hpp)
+int fold_pairs2_gated(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint64_t* d_v1, uint64_t* d_out1, size_t len, const uint64_t* r,
+                      unsigned gate_seq);
+int sumcheck_cubic_launch(pk_ctx* ctx, uint64_t* d_a, uint64_t* d_b, uint64_t* d_c, uint64_t* d_eq, size_t len, const uint64_t* fold_or_null,
+                          unsigned gate_seq, unsigned* red_seq_out);
+int sumcheck_quadratic_launch(pk_ctx* ctx, const uint64_t* d_f, const uint64_t* d_w, size_t len, const uint64_t* fold_or_null, unsigned gate_seq,
+                              uint64_t* d_f_out, uint64_t* d_w_out, unsigned* red_seq_out);
+int sumcheck_collect_spin(pk_ctx* ctx, unsigned red_seq, uint64_t out[12]);
+unsigned sumcheck_gate_next(pk_ctx* ctx);
+void sumcheck_gate_publish(pk_ctx* ctx, unsigned gate_seq, const uint64_t challenge[4]);
 int witness_bounds_strided(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, unsigned m0, unsigned stride, unsigned offset, uint64_t* d_a,
                            uint64_t* d_b, uint64_t* d_c);
 int external_row_range(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_eq_alpha, size_t first, size_t last, uint64_t* d_out);
@@ -123,6 +133,25 @@ __global__ __launch_bounds__(256) void random_fe_kernel(fe* __restrict__ out, si
 }
 // draws of one proof (the `stream` word of the nonce)
 enum { RNG_MASK = 1, RNG_G = 2, RNG_BLIND = 3, RNG_MASK_B = 4, RNG_G_B = 5, RNG_FILL = 6 };
+
+// latency mode: a gated kernel is in the queue waiting for a challenge; whatever path leaves the scope, it must be released
+// (with a zero challenge on an error path: the proof is abandoned anyway) so that the stream can drain
+struct PendingGate {
+    pk_ctx* c;
+    unsigned seq = 0;
+    explicit PendingGate(pk_ctx* ctx) : c(ctx) {}
+    void arm(unsigned s) { seq = s; }
+    void publish(const fe& challenge) {
+        if (!seq) return;
+        uint64_t w[4];
+        h_store(w, challenge);
+        sumcheck_gate_publish(c, seq, w);
+        seq = 0;
+    }
+    ~PendingGate() {
+        if (seq) publish(fe_zero());
+    }
+};
 
 struct Arena {
     char* base;
@@ -463,7 +492,38 @@ int whir_prove(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, const Commitmen
     int cur = 0;
     size_t len = B0;         // local length of p and w
     std::vector<fe> all_r;  // every folding challenge, in squeeze order
+    // latency mode (one GPU): round t+1's kernel -- and after the last round the fold -- is enqueued BEFORE round t's result is read,
+    // gated on the challenge the host publishes once it has squeezed it; the round trip then costs the link, not a launch + sync
+    auto sumcheck_rounds_pipelined = [&](unsigned rounds, std::vector<fe>& rs) -> int {
+        rs.clear();
+        if (!rounds) return PK_OK;
+        unsigned red_cur = 0, red_next = 0;
+        CK(sumcheck_quadratic_launch(ctx, U(bp_[cur]), U(bw_[cur]), len, nullptr, 0, nullptr, nullptr, &red_cur));
+        for (unsigned t = 0; t < rounds; t++) {
+            PendingGate gate(ctx);
+            // what consumes this round's challenge: the next round (folding first), or the closing fold
+            const bool more = t + 1 < rounds;
+            if (more || len >= 2) {
+                gate.arm(sumcheck_gate_next(ctx));
+                if (more) CK(sumcheck_quadratic_launch(ctx, U(bp_[cur]), U(bw_[cur]), len, nullptr, gate.seq, U(bp_[1 - cur]), U(bw_[1 - cur]), &red_next));
+                else CK(fold_pairs2_gated(ctx, U(bp_[cur]), U(bp_[1 - cur]), U(bw_[cur]), U(bw_[1 - cur]), len, nullptr, gate.seq));
+                cur = 1 - cur;
+                len /= 2;
+            }
+            uint64_t out[12];
+            CK(sumcheck_collect_spin(ctx, red_cur, out));
+            fe h[3] = {h_load(out), h_load(out + 4), h_load(out + 8)};
+            T.add_scalars(h, 3);
+            const fe fold = T.challenge_scalar();
+            gate.publish(fold);
+            rs.push_back(fold);
+            all_r.push_back(fold);
+            red_cur = red_next;
+        }
+        return PK_OK;
+    };
     auto sumcheck_rounds = [&](unsigned rounds, std::vector<fe>& rs) -> int {
+        if (ctx->latency_mode && G == 1 && rounds && len >= ((size_t)1 << rounds)) return sumcheck_rounds_pipelined(rounds, rs);
         rs.clear();
         bool have_fold = false;
         fe fold = fe_zero();
@@ -1064,7 +1124,36 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
             ALLOC(zt, cap);
             ztmp = zt;
         }
-        for (unsigned idx = 0; idx < m_0; idx++) {  // the hot loop, whir_r1cs.rs:280-345
+        const bool pipelined = ctx->latency_mode && G == 1 && m_0 >= 2;
+        unsigned red_cur = 0, red_next = 0;
+        if (pipelined) CK(sumcheck_cubic_launch(ctx, U(za), U(zb), U(zc), U(ze), length, nullptr, 0, &red_cur));
+        for (unsigned idx = 0; pipelined && idx < m_0; idx++) {  // latency mode: round idx+1 is in the queue, gated, while round idx is absorbed
+            PendingGate gate(ctx);
+            if (idx + 1 < m_0) {
+                gate.arm(sumcheck_gate_next(ctx));
+                CK(sumcheck_cubic_launch(ctx, U(za), U(zb), U(zc), U(ze), length, nullptr, gate.seq, &red_next));
+                length /= 2;
+            }
+            uint64_t out[12];
+            CK(sumcheck_collect_spin(ctx, red_cur, out));
+            const fe h0 = h_load(out), hm1 = h_load(out + 4), hinf = h_load(out + 8);
+            fe gp[4];
+            blinding_coefficients_for_round(g_univ, idx, alpha.data(), gp);
+            fe c[4];
+            c[0] = h_add(h0, h_mul(rho, gp[0]));
+            const fe g_m1 = h_sub(h_add(h_sub(gp[0], gp[1]), gp[2]), gp[3]);
+            const fe at_m1 = h_add(hm1, h_mul(rho, g_m1));
+            c[2] = h_mul(half, h_sub(h_sub(h_sub(h_add(saved, at_m1), c[0]), c[0]), c[0]));
+            c[3] = h_add(hinf, h_mul(rho, gp[3]));
+            c[1] = h_sub(h_sub(h_sub(h_sub(saved, c[0]), c[0]), c[3]), c[2]);
+            T.add_scalars(c, 4);
+            const fe a_i = T.challenge_scalar();
+            gate.publish(a_i);
+            alpha.push_back(a_i);
+            saved = eval_cubic(c, a_i);
+            red_cur = red_next;
+        }
+        for (unsigned idx = 0; !pipelined && idx < m_0; idx++) {  // the hot loop, whir_r1cs.rs:280-345
             uint64_t out[12], f[4];
             if (zk_sharded && length <= SHARD_MIN_LOCAL) {  // short shares: gather, re-interleave, finish replicated
                 fe* loc[4] = {za, zb, zc, ze};

@@ -1,5 +1,6 @@
 // reduce.hpp -- block / grid reduction of field-element sums (used by sumcheck, dot, Horner).
 #pragma once
+#include <chrono>
 #include <atomic>
 
 #include "ctx.hpp"
@@ -185,8 +186,8 @@ inline int reduction_scratch(pk_ctx* ctx) {
         rc = ensure_pinned(ctx);
         if (rc) return rc;
     }
-    if (!ctx->red_armed) {
-        PK_HIP(ctx, hipMemsetAsync((char*)ctx->d_scratch + (size_t)RED_MAX_BLOCKS * 8 * 32 + 8 * 32, 0, 64, ctx->stream));
+    if (!ctx->red_armed) {  // [ticket | ... | 64: the gate's device mirror (seq, challenge)]
+        PK_HIP(ctx, hipMemsetAsync((char*)ctx->d_scratch + (size_t)RED_MAX_BLOCKS * 8 * 32 + 8 * 32, 0, 128, ctx->stream));
         ctx->red_armed = true;
     }
     return PK_OK;
@@ -208,6 +209,69 @@ inline int collect_reduction(pk_ctx* ctx, uint64_t* host_out) {
     if (ctx->red_across) return comm_collect_fe(ctx, K, host_out);  // partial sums of a sharded operand: sum over the ranks first
     int rc = sync_stream(ctx);
     if (rc) return rc;
+    memcpy(host_out, ctx->h_pinned, 32 * K);
+    return PK_OK;
+}
+
+// ---- latency mode: a kernel that takes its challenge from a GATE instead of its arguments ------------------------------------
+// The host enqueues round k+1's kernel before it has round k's result.  Workgroup (0,0) of that kernel polls a word of the pinned
+// page (system scope, over the host link) until the host has published the challenge with the expected sequence number, copies
+// the 32 bytes into a device-side mirror and releases the other workgroups, which poll the mirror (agent scope, L2).  The spin is
+// bounded: a host that went away costs seconds, never a hung queue.  (Workgroups are dispatched in index order, so (0,0) is
+// resident whenever any workgroup of the grid is.)
+struct gate_args {
+    const unsigned* host;  // pinned page + PK_PIN_GATE, or nullptr: no gate, the challenge is in the kernel arguments
+    unsigned* dev;         // device mirror, same layout
+    unsigned seq;
+};
+__device__ __forceinline__ fe gate_wait(const gate_args& g) {
+    __shared__ unsigned s_chal[8];
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        if (blockIdx.x == 0 && blockIdx.y == 0) {
+            while (__hip_atomic_load(g.host, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != g.seq && ++spins < (1u << 23)) __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                __hip_atomic_store(g.dev + 8 + i, __hip_atomic_load(g.host + 8 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.dev, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(g.dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != g.seq && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) s_chal[i] = __hip_atomic_load(g.dev + 8 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = s_chal[i];
+    return r;
+}
+inline unsigned gate_next(pk_ctx* ctx) {
+    if (++ctx->gate_seq == 0) ctx->gate_seq = 1;
+    return ctx->gate_seq;
+}
+inline gate_args gate_none() { return gate_args{nullptr, nullptr, 0}; }
+inline gate_args gate_for(pk_ctx* ctx, unsigned seq) {  // after reduction_scratch(ctx)
+    return gate_args{(const unsigned*)((char*)ctx->h_pinned + PK_PIN_GATE), red_ticket(ctx) + 16, seq};
+}
+// the host's half: the challenge first, the sequence number last
+inline void gate_publish(pk_ctx* ctx, unsigned seq, const fe& challenge_mont) {
+    unsigned* g = (unsigned*)((char*)ctx->h_pinned + PK_PIN_GATE);
+    for (int i = 0; i < 8; i++) __atomic_store_n(g + 8 + i, challenge_mont.v[i], __ATOMIC_RELAXED);
+    __atomic_store_n(g, seq, __ATOMIC_RELEASE);
+}
+// wait for the reduction launched with sequence number `seq` WITHOUT draining the stream (a gated kernel may already sit behind it):
+// spin on the completion word its finishing workgroup publishes after the K results
+template <int K>
+inline int collect_reduction_spin(pk_ctx* ctx, unsigned seq, uint64_t* host_out) {
+    const unsigned* flag = (const unsigned*)ctx->h_pinned + PK_FLAG_WORD;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned polls = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+        if ((++polls & 0xfffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0)
+            return set_err(ctx, PK_ERR_HIP, "a gated reduction did not complete within 10 s");
+    }
     memcpy(host_out, ctx->h_pinned, 32 * K);
     return PK_OK;
 }

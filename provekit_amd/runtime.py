@@ -88,6 +88,10 @@ class Context:
         """join an RCCL communicator of `world` single-GPU processes (rank 0 made unique_id; the launcher broadcast it)"""
         self._check(lib.pk_comm_init_rank(self.handle, (C.c_uint8 * 128).from_buffer_copy(unique_id), world, rank))
 
+    def set_latency_mode(self, on: bool = True):
+        """pk_ctx_set_latency_mode: sumcheck rounds enqueued one ahead behind a host-published gate (one proof at a time only)"""
+        self._check(lib.pk_ctx_set_latency_mode(self.handle, 1 if on else 0))
+
     def comm_info(self):
         r, w, k = C.c_int(), C.c_int(), C.c_int()
         self._check(lib.pk_comm_info(self.handle, C.byref(r), C.byref(w), C.byref(k)))

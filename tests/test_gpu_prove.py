@@ -445,3 +445,40 @@ def test_prove_under_a_caller_supplied_io_pattern(ctx, oracle):
     assert scheme.domain_separator == ours and scheme.prove(d_z, seed=4) == p_ours
     scheme.close()
     r1cs.close()
+
+
+@pytest.mark.parametrize("m,m_0,nc,n_in,pow_bits", [(9, 7, 100, 60, 5.0), (12, 9, 500, 700, 4.0), (17, 16, 60000, 5000, 8.0)])
+def test_latency_mode_gives_the_same_transcript(oracle, m, m_0, nc, n_in, pow_bits):
+    """pk_ctx_set_latency_mode: every sumcheck round (20 cubic ones at the bench size, 4 per WHIR round) is enqueued one ahead,
+    gated on a word of the pinned page the host writes once it has squeezed the challenge.  Same kernels, same challenges:
+    the transcript must be byte for byte the one the plain mode writes -- seeded and, with both modes on one key, for fresh
+    randomness too -- and the verifier accepts it; switching the mode off again restores the plain path."""
+    import provekit_amd
+    import verifier as V
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS
+
+    ctx = provekit_amd.Context(0)
+    nw, z, coeffs, trips = satisfiable_r1cs(nc, n_in, 31)
+    r1cs = R1CS(ctx, *(to_sparse(nc, nw, t) for t in trips), oracle.to_mont(oracle.ints_to_limbs(coeffs)))
+    cfg_w, cfg_b = WhirConfig.for_size(m, pow_bits), blinding_config_for(m_0, pow_bits)
+    scheme = WhirR1CSScheme(ctx, r1cs, m, m_0, cfg_w, cfg_b)
+    d_z = ctx.upload(oracle.to_mont(oracle.ints_to_limbs(z)))
+    plain = [scheme.prove(d_z, seed=s) for s in (1, 2, 3)]
+    ctx.set_latency_mode(True)
+    fast = [scheme.prove(d_z, seed=s) for s in (1, 2, 3)]
+    assert fast == plain
+    for _ in range(20):  # many proofs back to back: the gate's sequence numbers keep advancing, nothing is left pending
+        assert scheme.prove(d_z, seed=2) == plain[1]
+    ctx.set_latency_mode(False)
+    assert scheme.prove(d_z, seed=3) == plain[2]
+
+    def vcfg(c):
+        return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
+
+    mats = [(t[0], t[1], [coeffs[v] for v in t[2]]) for t in trips]
+    assert V.verify(fast[0], scheme.domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b), r1cs=(nc, nw, mats) if m <= 12 else None)
+    scheme.close()
+    r1cs.close()
+    ctx.close()
