@@ -463,6 +463,8 @@ def main():
                     help="internal: run ONE size-class probe in this (fresh) process and print its JSON object; the default line spawns one "
                          "such process per class, because large buffers allocated after others were released in the same process run up to "
                          "25 %% slower (measured: m = 25 15.1 -> 12.3 proofs/s, 2^26 commit 57.8 -> 74.6 ms; not clocks -- tools/throttle_probe.py)")
+    ap.add_argument("--no-latency-pass", action="store_true", help="skip the untimed one-at-a-time passes after the isolated-kernel pass (rocprofv3 runs: keeps the trace to "
+                                                                   "the timed region + 8 isolated proofs)")
     ap.add_argument("--no-h2d-probe", action="store_true", help="skip the secondary PCIe-inclusive rate (witness uploaded before every proof)")
     ap.add_argument("--workload", choices=["prove", "commit"], default="prove",
                     help="prove = BASELINE configs[1] (default, the judged line); commit = one batch-2 WHIR commit of 2^m coefficients "
@@ -612,9 +614,10 @@ def main():
             ts.append(time.perf_counter() - t1)
         return sorted(ts[2:])[iso_steps // 2]
 
-    iso_dt = one_at_a_time(5500)  # the single-stream figure proper: no event pairs around the launches
+    if not args.no_latency_pass:
+        iso_dt = one_at_a_time(5500)  # the single-stream figure proper: no event pairs around the launches
     lat_dt = None
-    if not args.sharded:
+    if not args.sharded and not args.no_latency_pass:
         try:
             ctx.set_latency_mode(True)
             lat_dt = one_at_a_time(6000)

@@ -9,6 +9,6 @@ mkdir -p "$R/gpurun_out/$TAG"
 cd /tmp && rocprofv3 --kernel-trace --stats -f csv -d "$R/gpurun_out/$TAG" -o bench -- python "$R/bench.py" --no-cpu-baseline "$@" > "$R/gpurun_out/$TAG/bench.log" 2>&1
 grep '^{' "$R/gpurun_out/$TAG/bench.log" > "$R/gpurun_out/$TAG/bench.json"
 # keep only the summaries (the full kernel trace is large)
-find "$R/gpurun_out/$TAG" -name '*kernel_trace.csv' -size +4M -delete
+[ -n "${KEEP_TRACE:-}" ] || find "$R/gpurun_out/$TAG" -name '*kernel_trace.csv' -size +4M -delete
 ls -la "$R/gpurun_out/$TAG"
 head -25 "$R/gpurun_out/$TAG"/*kernel_stats.csv 2>/dev/null | cut -c1-220
