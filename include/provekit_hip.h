@@ -547,6 +547,9 @@ int pk_selftest_modmul_rate_fp52(pk_ctx *ctx, unsigned waves_per_simd, unsigned 
 int pk_selftest_constmul_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, int shoup, double *modmul_per_s);
 int pk_selftest_roundtrip(pk_ctx *ctx, unsigned rounds, unsigned host_work_permutes, double *us_per_round_launch,
                           double *us_per_round_mailbox);
+/* `launches` dependent one-wavefront kernels back to back on the context's stream, one synchronisation at the end: microseconds per
+ * kernel boundary with no host in the loop */
+int pk_selftest_launch_chain(pk_ctx *ctx, unsigned launches, unsigned threads_per_launch, double *us_per_launch);
 int pk_selftest_mfma_reduce(pk_ctx *ctx, const uint32_t *d_t_limbs, int32_t *d_out, size_t n);
 int pk_selftest_mfma_reduce_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned iters, double *squarings_per_s);
 int pk_selftest_mfma_valu_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double *squarings_per_s);

@@ -164,6 +164,7 @@ SIGNATURES = {
     "pk_selftest_fp52_sqr_device": (C.c_int, [vp, vp, vp, sz]),
     "pk_selftest_modmul_rate_fp52": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),
     "pk_selftest_constmul_rate": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.POINTER(C.c_double)]),
+    "pk_selftest_launch_chain": (C.c_int, [vp, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),
     "pk_selftest_roundtrip": (C.c_int, [vp, C.c_uint, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pk_selftest_mfma_reduce": (C.c_int, [vp, vp, vp, sz]),
     "pk_selftest_mfma_reduce_rate": (C.c_int, [vp, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),

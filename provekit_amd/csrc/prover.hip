@@ -1127,24 +1127,32 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
         const bool pipelined = ctx->latency_mode && G == 1 && m_0 >= 2;
         unsigned red_cur = 0, red_next = 0;
         if (pipelined) CK(sumcheck_cubic_launch(ctx, U(za), U(zb), U(zc), U(ze), length, nullptr, 0, &red_cur));
+        double t_launch = 0, t_wait = 0, t_host = 0;  // PK_PROVE_TIMING: where a pipelined round's wall time goes
         for (unsigned idx = 0; pipelined && idx < m_0; idx++) {  // latency mode: round idx+1 is in the queue, gated, while round idx is absorbed
             PendingGate gate(ctx);
+            auto q0 = now();
             if (idx + 1 < m_0) {
                 gate.arm(sumcheck_gate_next(ctx));
                 CK(sumcheck_cubic_launch(ctx, U(za), U(zb), U(zc), U(ze), length, nullptr, gate.seq, &red_next));
                 length /= 2;
             }
-            uint64_t out[12];
-            CK(sumcheck_collect_spin(ctx, red_cur, out));
-            const fe h0 = h_load(out), hm1 = h_load(out + 4), hinf = h_load(out + 8);
+            // the round's blinding coefficients depend only on the earlier challenges: computed while the kernel runs
             fe gp[4];
             blinding_coefficients_for_round(g_univ, idx, alpha.data(), gp);
-            fe c[4];
-            c[0] = h_add(h0, h_mul(rho, gp[0]));
             const fe g_m1 = h_sub(h_add(h_sub(gp[0], gp[1]), gp[2]), gp[3]);
-            const fe at_m1 = h_add(hm1, h_mul(rho, g_m1));
+            const fe rg0 = h_mul(rho, gp[0]), rgm1 = h_mul(rho, g_m1), rg3 = h_mul(rho, gp[3]);
+            auto q1 = now();
+            uint64_t out[12];
+            CK(sumcheck_collect_spin(ctx, red_cur, out));
+            auto q2 = now();
+            t_launch += std::chrono::duration<double>(q1 - q0).count();
+            t_wait += std::chrono::duration<double>(q2 - q1).count();
+            const fe h0 = h_load(out), hm1 = h_load(out + 4), hinf = h_load(out + 8);
+            fe c[4];
+            c[0] = h_add(h0, rg0);
+            const fe at_m1 = h_add(hm1, rgm1);
             c[2] = h_mul(half, h_sub(h_sub(h_sub(h_add(saved, at_m1), c[0]), c[0]), c[0]));
-            c[3] = h_add(hinf, h_mul(rho, gp[3]));
+            c[3] = h_add(hinf, rg3);
             c[1] = h_sub(h_sub(h_sub(h_sub(saved, c[0]), c[0]), c[3]), c[2]);
             T.add_scalars(c, 4);
             const fe a_i = T.challenge_scalar();
@@ -1152,7 +1160,10 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
             alpha.push_back(a_i);
             saved = eval_cubic(c, a_i);
             red_cur = red_next;
+            t_host += std::chrono::duration<double>(now() - q2).count();
         }
+        if (timing && pipelined)
+            fprintf(stderr, "[pk_prove]   pipelined cubic rounds: launch %.3f ms, wait %.3f ms, host %.3f ms\n", 1e3 * t_launch, 1e3 * t_wait, 1e3 * t_host);
         for (unsigned idx = 0; !pipelined && idx < m_0; idx++) {  // the hot loop, whir_r1cs.rs:280-345
             uint64_t out[12], f[4];
             if (zk_sharded && length <= SHARD_MIN_LOCAL) {  // short shares: gather, re-interleave, finish replicated

@@ -224,22 +224,49 @@ struct gate_args {
     unsigned* dev;         // device mirror, same layout
     unsigned seq;
 };
+// Layout of the gate (48 bytes, 64-byte aligned, the same in the pinned page and in the device mirror): three 16-byte chunks
+// [c0 c1 c2 seq] [c3 c4 c5 seq] [c6 c7 seq seq] -- every chunk carries the sequence number in its LAST word, which the writer stores last,
+// so a reader that finds the expected number in all three chunks of ONE set of 16-byte loads holds the whole challenge: a poll is a single
+// trip over the host link (three loads in flight), not nine dependent ones (a first version read word by word: +10 us per round).
+typedef unsigned gate_v4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bool gate_try(const gate_v4* g, unsigned seq, fe& out) {
+    // three system-coherent 16-byte loads in flight, one wait: volatile asm, so the poll loop really re-reads (a plain load is hoisted)
+    gate_v4 a, b, c;
+    asm volatile(
+        "global_load_dwordx4 %0, %3, off sc0 sc1\n\t"
+        "global_load_dwordx4 %1, %3, off offset:16 sc0 sc1\n\t"
+        "global_load_dwordx4 %2, %3, off offset:32 sc0 sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(a), "=&v"(b), "=&v"(c)
+        : "v"(g)
+        : "memory");
+    if (a.w != seq || b.w != seq || c.z != seq || c.w != seq) return false;
+    out.v[0] = a.x; out.v[1] = a.y; out.v[2] = a.z;
+    out.v[3] = b.x; out.v[4] = b.y; out.v[5] = b.z;
+    out.v[6] = c.x; out.v[7] = c.y;
+    return true;
+}
 __device__ __forceinline__ fe gate_wait(const gate_args& g) {
     __shared__ unsigned s_chal[8];
     if (threadIdx.x == 0) {
+        fe c = fe_zero();
         unsigned spins = 0;
         if (blockIdx.x == 0 && blockIdx.y == 0) {
-            while (__hip_atomic_load(g.host, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != g.seq && ++spins < (1u << 23)) __builtin_amdgcn_s_sleep(2);
+            while (!gate_try(reinterpret_cast<const gate_v4*>(g.host), g.seq, c) && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
+            // mirror: the eight data words, then ONE release store of the sequence number (agent scope: the other workgroups' L2)
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                __hip_atomic_store(g.dev + 8 + i, __hip_atomic_load(g.host + 8 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g.dev, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < 8; i++) __hip_atomic_store(g.dev + i, c.v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g.dev + 11, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            while (__hip_atomic_load(g.dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != g.seq && ++spins < (1u << 26)) __builtin_amdgcn_s_sleep(1);
+            // thousands of wavefronts wait here on one L2 line: one word per poll and a real pause between polls, or the channel that
+            // holds the line is saturated and workgroup (0,0)'s own stores queue behind the readers (measured: +10 us per round)
+            while (__hip_atomic_load(g.dev + 11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.seq && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(8);
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);  // once, after the word arrived (an acquire per poll invalidates caches thousands of times)
+#pragma unroll
+            for (int i = 0; i < 8; i++) c.v[i] = __hip_atomic_load(g.dev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
-        for (int i = 0; i < 8; i++) s_chal[i] = __hip_atomic_load(g.dev + 8 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 8; i++) s_chal[i] = c.v[i];
     }
     __syncthreads();
     fe r;
@@ -253,13 +280,18 @@ inline unsigned gate_next(pk_ctx* ctx) {
 }
 inline gate_args gate_none() { return gate_args{nullptr, nullptr, 0}; }
 inline gate_args gate_for(pk_ctx* ctx, unsigned seq) {  // after reduction_scratch(ctx)
-    return gate_args{(const unsigned*)((char*)ctx->h_pinned + PK_PIN_GATE), red_ticket(ctx) + 16, seq};
+    return gate_args{(const unsigned*)((char*)ctx->h_pinned + PK_PIN_GATE), red_ticket(ctx) + 16, seq};  // both 64-byte aligned
 }
 // the host's half: the challenge first, the sequence number last
-inline void gate_publish(pk_ctx* ctx, unsigned seq, const fe& challenge_mont) {
+inline void gate_publish(pk_ctx* ctx, unsigned seq, const fe& c) {
     unsigned* g = (unsigned*)((char*)ctx->h_pinned + PK_PIN_GATE);
-    for (int i = 0; i < 8; i++) __atomic_store_n(g + 8 + i, challenge_mont.v[i], __ATOMIC_RELAXED);
-    __atomic_store_n(g, seq, __ATOMIC_RELEASE);
+    const unsigned w[12] = {c.v[0], c.v[1], c.v[2], seq, c.v[3], c.v[4], c.v[5], seq, c.v[6], c.v[7], seq, seq};
+    for (int i = 0; i < 12; i++)
+        if (i != 3 && i != 7 && i < 10) __atomic_store_n(g + i, w[i], __ATOMIC_RELAXED);
+    __atomic_store_n(g + 3, seq, __ATOMIC_RELEASE);  // the tails last (x86 keeps the order of stores; a 16-byte read of a chunk sees a prefix)
+    __atomic_store_n(g + 7, seq, __ATOMIC_RELEASE);
+    __atomic_store_n(g + 10, seq, __ATOMIC_RELEASE);
+    __atomic_store_n(g + 11, seq, __ATOMIC_RELEASE);
 }
 // wait for the reduction launched with sequence number `seq` WITHOUT draining the stream (a gated kernel may already sit behind it):
 // spin on the completion word its finishing workgroup publishes after the K results

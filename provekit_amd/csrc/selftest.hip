@@ -873,3 +873,23 @@ extern "C" int pk_selftest_roundtrip(pk_ctx* ctx, unsigned rounds, unsigned host
     if (lost || page[32] != 0xffffffffu) return set_err(ctx, PK_ERR_HIP, "round-trip probe: the mailbox kernel gave up at round %u", (unsigned)page[32]);
     return PK_OK;
 }
+
+// back-to-back dependent launches on one stream, one synchronisation at the end: microseconds per launch (the in-queue cost of a
+// kernel boundary -- dispatch, end-of-kernel release, start-of-kernel acquire -- with no host in the loop)
+extern "C" int pk_selftest_launch_chain(pk_ctx* ctx, unsigned launches, unsigned threads_per_launch, double* us_per_launch) {
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, launches >= 1 && launches <= 1000000 && us_per_launch, "bad argument");
+    int rc = ensure_pinned(ctx);
+    if (rc) return rc;
+    unsigned* word = (unsigned*)((char*)ctx->h_pinned + 3072);
+    unsigned* chal = word + 16;
+    *chal = 0;
+    const unsigned blocks = threads_per_launch ? (threads_per_launch + 63) / 64 : 1;
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto t0 = std::chrono::steady_clock::now();
+    for (unsigned i = 1; i <= launches; i++) roundtrip_launch_kernel<<<blocks, 64, 0, ctx->stream>>>(word, i, chal);
+    PK_LAUNCH_CHECK(ctx);
+    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *us_per_launch = 1e6 * std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / launches;
+    return PK_OK;
+}

@@ -18,10 +18,16 @@ for work in (0, 5):
         a, b = C.c_double(), C.c_double()
         ctx._check(lib.pk_selftest_roundtrip(ctx.handle, 2000, work, C.byref(a), C.byref(b)))
         rows.append({"host_work_permutes": work, "us_per_round_launch_sync": a.value, "us_per_round_mailbox": b.value})
+chain = []
+for threads in (64, 64 * 1024):
+    v = C.c_double()
+    ctx._check(lib.pk_selftest_launch_chain(ctx.handle, 5000, threads, C.byref(v)))
+    chain.append({"threads_per_launch": threads, "us_per_dependent_launch_no_host": v.value})
 best = lambda k, w: min(r[k] for r in rows if r["host_work_permutes"] == w)
 launch, mailbox = best("us_per_round_launch_sync", 5), best("us_per_round_mailbox", 5)
 res = {"probe": "pk_selftest_roundtrip: 2000 dependent round trips, one workgroup, idle chip", "runs": rows,
-       "us_per_round_launch_sync": launch, "us_per_round_mailbox": mailbox, "saving_us_per_round": launch - mailbox}
+       "us_per_round_launch_sync": launch, "us_per_round_mailbox": mailbox, "saving_us_per_round": launch - mailbox,
+       "back_to_back_dependent_launches": chain}
 print(json.dumps(res, indent=1))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "r04_roundtrip.json"), "w"), indent=1)
