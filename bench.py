@@ -461,8 +461,10 @@ def main():
                     help="other BASELINE size classes reported as secondary keys of the default line (configs[2]: 23, configs[3]: 25); '' = none")
     ap.add_argument("--size-class-probe", type=int, default=0,
                     help="internal: run ONE size-class probe in this (fresh) process and print its JSON object; the default line spawns one "
-                         "such process per class, because large buffers allocated after others were released in the same process run up to "
-                         "25 %% slower (measured: m = 25 15.1 -> 12.3 proofs/s, 2^26 commit 57.8 -> 74.6 ms; not clocks -- tools/throttle_probe.py)")
+                         "such process per class: run back to back inside one process, whichever probe comes later measures up to 25 %% "
+                         "low (m = 25 15.1 -> 12.3 proofs/s, 2^26 commit 57.8 -> 74.6 ms).  Cause not established -- allocate/free churn alone does "
+                         "not reproduce it (tools/alloc_effect.py), a 25 s loop of commits shows no clock drop (tools/throttle_probe.py) -- but the idle "
+                         "seconds a fresh process brings remove it, and every figure then matches a dedicated run of that size")
     ap.add_argument("--no-latency-pass", action="store_true", help="skip the untimed one-at-a-time passes after the isolated-kernel pass (rocprofv3 runs: keeps the trace to "
                                                                    "the timed region + 8 isolated proofs)")
     ap.add_argument("--no-h2d-probe", action="store_true", help="skip the secondary PCIe-inclusive rate (witness uploaded before every proof)")
@@ -668,9 +670,8 @@ def main():
                 size_figs[str(mm)] = json.loads(lines[-1]) if out.returncode == 0 and lines else {"error": (out.stderr or "no output")[-200:]}
             except Exception as e:  # noqa: BLE001
                 size_figs[str(mm)] = {"error": str(e)[:200]}
-    # (a) PCIe-inclusive rate: the same waves with the witness uploaded before every proof.  LAST: the pageable host-to-device copies leave
-    # the runtime in a state in which later large kernels run up to 25 % slower (measured: 2^26 commit 57.8 -> 74.6 ms, m = 25 15.1 -> 12.3
-    # proofs/s when this probe ran first), which would falsify the figures above it
+    # (a) PCIe-inclusive rate: the same waves with the witness uploaded before every proof.  LAST, so that it cannot disturb the figures above
+    # (see --size-class-probe: probes run back to back in one process were measured to depress whichever comes later)
     h2d_rate = None
     if not args.h2d and not args.sharded and not args.no_h2d_probe:
         try:
