@@ -462,9 +462,10 @@ def main():
     ap.add_argument("--size-class-probe", type=int, default=0,
                     help="internal: run ONE size-class probe in this (fresh) process and print its JSON object; the default line spawns one "
                          "such process per class: run back to back inside one process, whichever probe comes later measures up to 25 %% "
-                         "low (m = 25 15.1 -> 12.3 proofs/s, 2^26 commit 57.8 -> 74.6 ms).  Cause not established -- allocate/free churn alone does "
-                         "not reproduce it (tools/alloc_effect.py), a 25 s loop of commits shows no clock drop (tools/throttle_probe.py) -- but the idle "
-                         "seconds a fresh process brings remove it, and every figure then matches a dedicated run of that size")
+                         "low (m = 25 15.1 -> 12.3 proofs/s, 2^26 commit 57.8 -> 74.6 ms).  Not the allocator (allocate/free churn alone does not "
+                         "reproduce it, tools/alloc_effect.py); most likely the package power limit: 16 provers draw ~1.28 kW and already run at 2.26 GHz "
+                         "instead of 2.39 (tools/power_trace.sh), and seconds of that heat the package for whatever follows.  The idle seconds a fresh "
+                         "process brings remove the effect; every figure then matches a dedicated run of that size")
     ap.add_argument("--no-latency-pass", action="store_true", help="skip the untimed one-at-a-time passes after the isolated-kernel pass (rocprofv3 runs: keeps the trace to "
                                                                    "the timed region + 8 isolated proofs)")
     ap.add_argument("--no-h2d-probe", action="store_true", help="skip the secondary PCIe-inclusive rate (witness uploaded before every proof)")
