@@ -445,7 +445,8 @@ int pk_scheme_domain_separator(const pk_scheme *scheme, char *buf, size_t cap, s
  *   pk_witness_builders_from_postcard   `bytes` = postcard(&Vec<WitnessBuilder>) -- the enum and everything inside it are defined
  *                                        in the reference tree (provekit/common/src/witness/witness_builder.rs:33-117), and this is
  *                                        how the list sits inside a .nps.  Decodes, checks (an input no EARLIER builder produced is a
- *                                        None the reference would unwrap: PK_ERR_BAD_ARG names it; so is a witness written twice),
+ *                                        None the reference would unwrap: PK_ERR_BAD_ARG names it; a witness written by several builders keeps the
+ *                                        sequential meaning -- the last writer wins, readers see the version of their place in the list),
  *                                        levels the list by data dependence and uploads it.
  *   pk_witness_builders_inspect         the same decode + levelling on the host only (no device): shape of the program.
  *   pk_witness_solve                    d_witness[n_witness] (zeroed, then every solved entry written), d_is_set[n_witness] = 1 where

@@ -335,6 +335,7 @@ int emit_opening_hints(pk_ctx* ctx, Transcript& T, const fe* d_leaves, const fe*
     const size_t plen = logn ? logn - 1 : 0;
     std::vector<uint64_t> leaves(4 * k * width), sib(4 * (k ? k : 1)), paths(4 * (k * plen ? k * plen : 1));
     CK(open_raw(ctx, U(d_leaves), U(d_nodes), n_leaves, width, lay, idx.data(), k, /*canonical=*/1, leaves.data(), sib.data(), paths.data()));
+    const auto ser0 = std::chrono::steady_clock::now();
     std::vector<uint8_t> buf;
     auto put_u64 = [&](uint64_t v) {
         for (int i = 0; i < 8; i++) buf.push_back((uint8_t)(v >> (8 * i)));
@@ -351,6 +352,7 @@ int emit_opening_hints(pk_ctx* ctx, Transcript& T, const fe* d_leaves, const fe*
     std::vector<uint8_t> mp(len ? len : 1);
     CK(pk_multipath_serialize(idx.data(), k, plen, sib.data(), paths.data(), mp.data(), len, &len));
     T.hint(mp.data(), len);
+    T.hint_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - ser0).count();
     return PK_OK;
 }
 
@@ -1051,8 +1053,8 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
         if (!timing) return;
         (void)hipStreamSynchronize(ctx->stream);
         auto t = now();
-        fprintf(stderr, "[pk_prove] %-28s %8.3f ms (sponge: %u permutes, %.3f ms)\n", what,
-                1e3 * std::chrono::duration<double>(t - t_start).count(), T.permutes, 1e3 * T.permute_seconds);
+        fprintf(stderr, "[pk_prove] %-28s %8.3f ms (sponge: %u permutes, %.3f ms; hint serialisation so far %.3f ms)\n", what,
+                1e3 * std::chrono::duration<double>(t - t_start).count(), T.permutes, 1e3 * T.permute_seconds, 1e3 * T.hint_seconds);
         t_start = t;
     };
     const unsigned m = s->m, m_0 = s->m_0;

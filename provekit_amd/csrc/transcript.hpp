@@ -263,6 +263,7 @@ class Transcript {
   public:
     std::vector<uint8_t> narg;  // the proof string (WhirR1CSProof::transcript)
     double permute_seconds = 0.0;  // host time spent in the sponge permutation (PK_PROVE_TIMING)
+    double hint_seconds = 0.0;     // host time spent serialising opening hints (PK_PROVE_TIMING)
     unsigned permutes = 0;
 
     explicit Transcript(const std::string& io_pattern) {

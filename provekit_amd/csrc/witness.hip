@@ -688,10 +688,13 @@ bool build_program(const uint8_t* bytes, size_t len, Program& P, size_t* consume
     }
     P.n_witnesses = nw;
     // level(b) = 1 + max level of the producers of its inputs; an input nobody produced EARLIER in the list is a `None`
-    // the reference would unwrap (panic): refuse the list instead
+    // the reference would unwrap (panic): refuse the list instead.  The reference's solver runs the list in order, so a witness may
+    // be written more than once (the last writer wins) and a Spice block may copy a `None` that a later builder solves: both keep
+    // their sequential meaning here because a writer is also levelled after the previous writer of its witness (write after write) and
+    // after every earlier reader or copier of the version it replaces (write after read) -- there is one witness array, no renaming.
     std::vector<int> producer(nw, -1);
+    std::vector<int> reader_level(nw, -1);  // highest level among the builders that read / copied the CURRENT version (or the None)
     std::vector<u32> level(B.size(), 0);
-    std::vector<std::pair<u32, size_t>> copied_none;  // (witness, builder) copied while still None
     u32 max_level = 0;
     for (size_t i = 0; i < B.size(); i++) {
         u32 lv = 0;
@@ -699,26 +702,29 @@ bool build_program(const uint8_t* bytes, size_t len, Program& P, size_t* consume
             if (producer[w] < 0) return P.error = "builder " + std::to_string(i) + " reads witness " + std::to_string(w) + " before it is solved", false;
             lv = std::max(lv, level[(size_t)producer[w]] + 1);
         }
-        for (u32 w : B[i].copies) {
-            if (producer[w] < 0) copied_none.push_back({w, i});
-            else lv = std::max(lv, level[(size_t)producer[w]] + 1);
+        for (u32 w : B[i].copies)
+            if (producer[w] >= 0) lv = std::max(lv, level[(size_t)producer[w]] + 1);
+        {  // one builder writing the same witness twice would race inside its level: not a list the compiler emits
+            std::vector<u32> ws(B[i].writes);
+            std::sort(ws.begin(), ws.end());
+            if (std::adjacent_find(ws.begin(), ws.end()) != ws.end())
+                return P.error = "builder " + std::to_string(i) + " writes witness " + std::to_string(*std::adjacent_find(ws.begin(), ws.end())) + " twice", false;
         }
         for (u32 w : B[i].writes) {
-            if (producer[w] >= 0) return P.error = "witness " + std::to_string(w) + " is written twice (builders " + std::to_string(producer[w]) + ", " + std::to_string(i) + ")", false;
+            if (producer[w] >= 0 && (size_t)producer[w] != i) lv = std::max(lv, level[(size_t)producer[w]] + 1);
+            if (reader_level[w] >= 0) lv = std::max(lv, (u32)reader_level[w] + 1);
+        }
+        for (u32 w : B[i].reads) reader_level[w] = std::max(reader_level[w], (int)lv);
+        for (u32 w : B[i].copies) reader_level[w] = std::max(reader_level[w], (int)lv);
+        for (u32 w : B[i].writes) {
             producer[w] = (int)i;
+            reader_level[w] = -1;  // a new version: nobody has read it yet
         }
         level[i] = lv;
         max_level = std::max(max_level, lv);
         if (B[i].spice >= 0) P.spice[(size_t)B[i].spice].level = lv;
         if (B[i].heavy_sum >= 0) P.heavy_sums[(size_t)B[i].heavy_sum].level = lv;
     }
-    // a None copied by a Spice block must still be None when the block runs here, whatever the level order: refuse the (contrived)
-    // list in which a LATER builder solves it
-    for (auto& cn : copied_none)
-        if (producer[cn.first] >= 0)
-            return P.error = "builder " + std::to_string(cn.second) + " copies witness " + std::to_string(cn.first) + " before builder " +
-                             std::to_string(producer[cn.first]) + " solves it",
-                   false;
     // phase = 2 * level (+1 for the second-phase items of multiplicity builders); counting sort of the items by phase
     const size_t n_phases = 2 * ((size_t)max_level + 1);
     std::vector<size_t> cnt(n_phases + 1, 0);

@@ -366,3 +366,27 @@ def test_placement_advice_and_acir_reads(ctx, oracle):
     assert reads == sorted(set(reads)) and all(r < big.n_acir for r in reads) and (not reads or reads[-1] == big.n_acir - 1)
     for p in (pc, pw, big):
         p.close()
+
+
+def test_overwritten_witnesses_keep_their_sequential_meaning(ctx, oracle):
+    """the reference's solve_witness_vec runs the list in order, so a builder may overwrite a witness an earlier one
+    solved (the last writer wins) and readers in between see the value of their place in the list; a Spice block may copy a None a
+    later builder solves.  The levelled solver must agree with the sequential restatement on such lists: a writer is ordered after
+    the previous writer and after every reader of the version it replaces."""
+    import witness_ref as R
+
+    from provekit_amd.witness import WitnessBuilder as WB
+
+    P = oracle.P
+    builders = [WB.Acir(0, 0), WB.Acir(1, 1), WB.Constant(2, 7), WB.Product(3, 2, 0),  # w3 = 7 a0
+                WB.Constant(2, 11),                                                     # w2 overwritten
+                WB.Product(4, 2, 1),                                                    # w4 = 11 a1 (the new version)
+                WB.Sum(2, [(None, 2), (5, 3)]),                                         # w2 = w2 + 5 w3: reads and rewrites itself
+                WB.Product(5, 2, 2), WB.Inverse(6, 5), WB.Constant(3, 1), WB.Product(7, 3, 6)]
+    for k in range(40):  # a longer ping-pong on two cells, wide enough to cross the narrow-run path
+        builders += [WB.Product(8, 7 if k == 0 else 9, 2), WB.Sum(9, [(3, 8), (None, 0)]), WB.Constant(8, k + 2)]
+    acir = [123456789, 987654321]
+    nw = 10
+    want = R.solve_witness_vec(builders, acir, [], nw)
+    got = _check(ctx, oracle, builders, acir, [], nw)
+    assert got == want and want[2] == (11 + 5 * 7 * acir[0]) % P and want[8] == 41

@@ -61,8 +61,10 @@ def test_library_decodes_and_levels_the_postcard_list_on_the_host():
 
     with pytest.raises(ProveKitHipError, match="before it is solved"):
         inspect_witness_builders(encode_witness_builders([WB.Constant(0, 1), WB.Product(2, 0, 1)]))
-    with pytest.raises(ProveKitHipError, match="written twice"):
-        inspect_witness_builders(encode_witness_builders([WB.Constant(0, 1), WB.Constant(0, 2)]))
+    # the reference's solver runs the list in order, so a later builder may overwrite a witness (the last writer wins): accepted, and
+    # levelled so that it keeps that meaning -- the second writer after the first AND after the first version's readers
+    over = inspect_witness_builders(encode_witness_builders([WB.Constant(0, 1), WB.Product(1, 0, 0), WB.Constant(0, 2), WB.Product(2, 0, 0)]))
+    assert over["n_levels"] == 4
     with pytest.raises(ProveKitHipError, match="malformed"):
         inspect_witness_builders(data[: len(data) // 2])
     with pytest.raises(ProveKitHipError, match="malformed"):  # a field element >= p is not a canonical encoding
