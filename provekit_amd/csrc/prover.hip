@@ -60,6 +60,7 @@ struct pk_scheme {
     size_t arena_bytes = 0;
     std::string domain_separator;
     char* noir_witness = nullptr;  // pk_noir_prove: num_witnesses elements + num_witnesses is-set bytes, allocated on first use
+    pk_ctx* side = nullptr;        // latency mode: a second context (stream, workspace) of the same device for the blinding commitment
 };
 
 namespace {
@@ -371,7 +372,9 @@ struct Commitment {  // whir::committer::Witness
 };
 
 // CommitmentWriter::commit_batch (call site provekit/prover/src/whir_r1cs.rs:200-206; transcript order mtUtilities.go:51-76)
-int whir_commit(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, fe* const* polys, unsigned batch, Transcript& T, Commitment& C) {
+// the commitment's device work (RS-encode, leaf hashes, tree) on `ctx`'s stream, nothing read back: the half of whir_commit that needs no
+// transcript -- in latency mode the blinding commitment's runs on a second stream while the witness commitment fills the chip
+int whir_commit_compute(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, fe* const* polys, unsigned batch, Commitment& C) {
     C.n_vars = cfg.n_vars;
     C.batch = batch;
     const unsigned k = cfg.folding_factor;
@@ -385,9 +388,19 @@ int whir_commit(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, fe* const* pol
     CK(ensure_ws(ctx, commit_scratch_fes(ctx, C.rows, C.width) * 32));
     const uint64_t* ptrs[4];
     for (unsigned b = 0; b < batch; b++) ptrs[b] = U(polys[b]);
-    CK(commit_into(ctx, ptrs, batch, cfg.n_vars, cfg.starting_log_inv_rate, k, U(leaves), U(nodes), (uint64_t*)ctx->d_ws, &C.layout));
+    return commit_into(ctx, ptrs, batch, cfg.n_vars, cfg.starting_log_inv_rate, k, U(leaves), U(nodes), (uint64_t*)ctx->d_ws, &C.layout);
+}
+int whir_commit_transcript(pk_ctx* ctx, const pk_whir_config& cfg, const fe& root, Transcript& T, Commitment& C);
+int whir_commit(pk_ctx* ctx, Arena& A, const pk_whir_config& cfg, fe* const* polys, unsigned batch, Transcript& T, Commitment& C) {
+    CK(whir_commit_compute(ctx, A, cfg, polys, batch, C));
     fe root;
-    CK(read_root(ctx, U(nodes), C.rows, (uint64_t*)root.v));
+    CK(read_root(ctx, U(C.nodes), C.rows, (uint64_t*)root.v));
+    return whir_commit_transcript(ctx, cfg, root, T, C);
+}
+// ... and the half that talks: root, OOD points and answers, batching randomness (mtUtilities.go:51-76)
+int whir_commit_transcript(pk_ctx* ctx, const pk_whir_config& cfg, const fe& root, Transcript& T, Commitment& C) {
+    const unsigned batch = C.batch;
+    fe* const* polys = C.polys;
     T.add_canon(root);
     C.ood_points.resize(cfg.commitment_ood_samples);
     T.challenge_scalars(C.ood_points.data(), C.ood_points.size());
@@ -738,8 +751,9 @@ struct BatchCommit {
     fe* f_evals = nullptr;  // masked polynomial, evaluation form (2^m)
     fe* g_evals = nullptr;  // random polynomial, evaluation form (2^m)
 };
-int batch_commit(pk_ctx* ctx, Arena& A, unsigned m, const pk_whir_config& cfg, const fe* d_evals, size_t n_evals, const RngKey& key,
-                 u32 stream_mask, u32 stream_g, Transcript& T, BatchCommit& out) {
+// masks, coefficient forms and the commitment's device work on `ctx`'s stream; nothing is read back and the transcript is not touched
+int batch_commit_compute(pk_ctx* ctx, Arena& A, unsigned m, const pk_whir_config& cfg, const fe* d_evals, size_t n_evals, const RngKey& key,
+                         u32 stream_mask, u32 stream_g, BatchCommit& out) {
     const size_t half = (size_t)1 << (m - 1), N = 2 * half;
     ALLOC(f, N);
     ALLOC(g, N);
@@ -760,10 +774,17 @@ int batch_commit(pk_ctx* ctx, Arena& A, unsigned m, const pk_whir_config& cfg, c
     out.f_evals = f;
     out.g_evals = g;
     fe* polys[2] = {fe_, ge_};
-    int rc = whir_commit(ctx, A, cfg, polys, 2, T, out.com);
+    int rc = whir_commit_compute(ctx, A, cfg, polys, 2, out.com);
     out.com.evals[0] = f;
     out.com.evals[1] = g;
     return rc;
+}
+int batch_commit(pk_ctx* ctx, Arena& A, unsigned m, const pk_whir_config& cfg, const fe* d_evals, size_t n_evals, const RngKey& key,
+                 u32 stream_mask, u32 stream_g, Transcript& T, BatchCommit& out) {
+    CK(batch_commit_compute(ctx, A, m, cfg, d_evals, n_evals, key, stream_mask, stream_g, out));
+    fe root;
+    CK(read_root(ctx, U(out.com.nodes), out.com.rows, (uint64_t*)root.v));
+    return whir_commit_transcript(ctx, cfg, root, T, out.com);
 }
 
 // 256-bit key of one proof's random draws: fresh from the OS CSPRNG (the reference's thread_rng) unless injected.  One proof
@@ -970,6 +991,7 @@ int pk_scheme_destroy(pk_ctx* ctx, pk_scheme* s) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(s->arena);
     (void)hipFree(s->noir_witness);
+    if (s->side) (void)pk_ctx_destroy(s->side);
     delete s;
     return PK_OK;
 }
@@ -1059,9 +1081,45 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     };
     const unsigned m = s->m, m_0 = s->m_0;
 
+    // blinding univariates: 4 random coefficients per variable [RNG], committed with the small WHIR (whir_r1cs.rs:212-226)
+    unsigned nb = 0;
+    while (((size_t)1 << nb) < 4 * (size_t)m_0) nb++;
+    const size_t NB = (size_t)1 << nb;
+    BatchCommit B;
+    fe* d_blind = nullptr;
+    fe* side_univ = nullptr;  // pinned: the 4 m_0 blinding coefficients as the side stream copied them out
+    // Latency mode, one GPU: the blinding commitment depends on nothing but the proof's key -- 0.6 ms of launches that keep 32 lanes
+    // busy (its two leaf hashes are chains of 31 compressions).  Its device work goes to a second stream NOW and runs underneath the
+    // witness commitment, which fills the chip for 2.6 ms; only the transcript half (root, OOD, batching) waits for its turn.
+    const bool overlap_blinding = ctx->latency_mode && comm_world(ctx) == 1 && !getenv("PK_NO_BLINDING_OVERLAP");  // (the env switch: A/B only)
     // --- commit to the masked witness polynomial (whir_r1cs.rs:57-69)
     BatchCommit W;
-    CK(batch_commit(ctx, A, m, s->whir_witness, (const fe*)d_witness, n_witness, key, RNG_MASK, RNG_G, T, W));
+    if (overlap_blinding) {
+        // the witness commitment's launches first (the chip starts on them at once), then the side stream's, then the witness root
+        CK(batch_commit_compute(ctx, A, m, s->whir_witness, (const fe*)d_witness, n_witness, key, RNG_MASK, RNG_G, W));
+        if (!s->side) {
+            int dev = 0;
+            PK_HIP(ctx, hipGetDevice(&dev));
+            CK(pk_ctx_create(dev, &s->side));
+        }
+        pk_ctx* sc = s->side;
+        sc->hash_version = ctx->hash_version;
+        d_blind = A.alloc(NB);
+        if (!d_blind) return set_err(ctx, PK_ERR_OOM, "prover arena exhausted (d_blind)");
+        int rc = pk_memset_zero(sc, d_blind, 32 * NB);
+        if (!rc) {
+            random_fe_kernel<<<1, 256, 0, sc->stream>>>(d_blind, 4 * (size_t)m_0, key, RNG_BLIND);
+            rc = mail_alloc(sc, 32 * 4 * (size_t)m_0, (void**)&side_univ);
+        }
+        if (!rc && hipMemcpyAsync(side_univ, d_blind, 32 * 4 * (size_t)m_0, hipMemcpyDeviceToHost, sc->stream) != hipSuccess) rc = PK_ERR_HIP;
+        if (!rc) rc = batch_commit_compute(sc, A, nb + 1, s->whir_hiding, d_blind, NB, key, RNG_MASK_B, RNG_G_B, B);
+        if (rc) return set_err(ctx, rc, "blinding commitment on the side stream: %s", pk_last_error(sc));
+        fe root_w;
+        CK(read_root(ctx, U(W.com.nodes), W.com.rows, (uint64_t*)root_w.v));
+        CK(whir_commit_transcript(ctx, s->whir_witness, root_w, T, W.com));
+    } else {
+        CK(batch_commit(ctx, A, m, s->whir_witness, (const fe*)d_witness, n_witness, key, RNG_MASK, RNG_G, T, W));
+    }
 
     lap("witness commit");
     // --- run_zk_sumcheck_prover (whir_r1cs.rs:228-369)
@@ -1086,18 +1144,25 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
         CK(pk_r1cs_witness_bounds(ctx, s->r1cs, d_witness, m_0, U(d_a), U(d_b), U(d_cc)));  // S1
         CK(pk_eq_table(ctx, (const uint64_t*)r.data(), m_0, U(d_eq)));                       // S2
     }
-    // blinding univariates: 4 random coefficients per variable [RNG], committed with the small WHIR
-    unsigned nb = 0;
-    while (((size_t)1 << nb) < 4 * (size_t)m_0) nb++;
-    const size_t NB = (size_t)1 << nb;
-    ALLOC(d_blind, NB);
-    CK(pk_memset_zero(ctx, d_blind, 32 * NB));
-    random_fe_kernel<<<1, 256, 0, ctx->stream>>>(d_blind, 4 * (size_t)m_0, key, RNG_BLIND);
-    PK_LAUNCH_CHECK(ctx);
     std::vector<fe> g_univ(4 * (size_t)m_0);
-    CK(pk_memcpy_d2h(ctx, g_univ.data(), d_blind, 32 * g_univ.size()));
-    BatchCommit B;
-    CK(batch_commit(ctx, A, nb + 1, s->whir_hiding, d_blind, NB, key, RNG_MASK_B, RNG_G_B, T, B));
+    if (overlap_blinding) {  // the side stream finished long ago: take its root and the coefficients, then the transcript half here
+        pk_ctx* sc = s->side;
+        if (hipStreamSynchronize(sc->stream) != hipSuccess) return set_err(ctx, PK_ERR_HIP, "side stream synchronisation failed");
+        memcpy(g_univ.data(), side_univ, 32 * g_univ.size());
+        sc->mail_off = 0;
+        fe root_b;
+        if (B.com.rows < 2) CK(pk_memcpy_d2h(ctx, root_b.v, B.com.nodes + 1, 32));
+        else memcpy(root_b.v, (char*)sc->h_pinned + PK_PIN_ROOT, 32);
+        CK(whir_commit_transcript(ctx, s->whir_hiding, root_b, T, B.com));
+    } else {
+        ALLOC(d_blind_, NB);
+        d_blind = d_blind_;
+        CK(pk_memset_zero(ctx, d_blind, 32 * NB));
+        random_fe_kernel<<<1, 256, 0, ctx->stream>>>(d_blind, 4 * (size_t)m_0, key, RNG_BLIND);
+        PK_LAUNCH_CHECK(ctx);
+        CK(pk_memcpy_d2h(ctx, g_univ.data(), d_blind, 32 * g_univ.size()));
+        CK(batch_commit(ctx, A, nb + 1, s->whir_hiding, d_blind, NB, key, RNG_MASK_B, RNG_G_B, T, B));
+    }
     lap("bounds+eq+blinding commit");
     // sum_over_hypercube (whir_r1cs.rs:172-180)
     fe sum_g;
