@@ -72,8 +72,8 @@ int pk_ctx_set_stream(pk_ctx *ctx, void *hip_stream);
  * enqueues each sumcheck round one ahead -- the next round's kernel, or the closing fold, is already in the queue, gated on a word of the
  * pinned host page, while the host absorbs the current round's three evaluations and squeezes the challenge -- so those Fiat-Shamir round
  * trips cost the host link's latency instead of a kernel launch plus a stream synchronisation (4 us against 15, profiles/r04_roundtrip.json);
- * and the blinding commitment, which depends on nothing but the proof's key, runs on a second stream of the same GPU underneath the witness
- * commitment.  9.5 -> 8.7 ms per proof at the poseidon size; the transcript is byte-identical either way.  Leave it off when several provers share the GPU: a gated kernel holds its workgroup
+ * and the blinding commitment (which depends on nothing but the proof's key) and the statement's external rows and sums (on alpha only) run
+ * on a second stream of the same GPU underneath the witness commitment and the blinding WHIR proof.  9.5 -> 8.6 ms per proof at the poseidon size; the transcript is byte-identical either way.  Leave it off when several provers share the GPU: a gated kernel holds its workgroup
  * slots while it waits for the host. */
 int pk_ctx_set_latency_mode(pk_ctx *ctx, int on);
 int pk_ctx_sync(pk_ctx *ctx);

@@ -909,9 +909,18 @@ int eval_univariate_multi(pk_ctx* ctx, const uint64_t* const* d_polys, unsigned 
     return np == 1 ? collect_reduction<1>(ctx, out) : collect_reduction<2>(ctx, out);
 }
 // nrows (1..3) weight rows against f and (nv == 2) g in one pass: out[4 * (nv * k + v)]
+// defer: launch only -- the caller synchronises `ctx`'s stream later and takes the 3 * nv results from its pinned page (latency mode: the
+// statement's sums run on a side stream underneath the blinding WHIR proof)
+int dot_rows_x(pk_ctx* ctx, const uint64_t* d_w, size_t row_stride, unsigned nrows, const uint64_t* d_f, const uint64_t* d_g, size_t n, uint64_t* out,
+               bool defer);
 int dot_rows(pk_ctx* ctx, const uint64_t* d_w, size_t row_stride, unsigned nrows, const uint64_t* d_f, const uint64_t* d_g, size_t n, uint64_t* out) {
+    return dot_rows_x(ctx, d_w, row_stride, nrows, d_f, d_g, n, out, false);
+}
+int dot_rows_x(pk_ctx* ctx, const uint64_t* d_w, size_t row_stride, unsigned nrows, const uint64_t* d_f, const uint64_t* d_g, size_t n, uint64_t* out,
+               bool defer) {
     const int nv = d_g ? 2 : 1;
-    PK_REQUIRE(ctx, nrows == 3 && out && (n == 0 || (d_w && d_f)), "three weight rows");
+    PK_REQUIRE(ctx, nrows == 3 && (out || defer) && (n == 0 || (d_w && d_f)), "three weight rows");
+    PK_REQUIRE(ctx, !defer || (n != 0 && !ctx->red_across), "a deferred dot product needs work and a lone context");
     if (n == 0) {
         if (ctx->red_across) {
             PK_HIP(ctx, hipMemsetAsync(ctx->d_xred, 0, 32 * 3 * nv, ctx->stream));
@@ -933,6 +942,7 @@ int dot_rows(pk_ctx* ctx, const uint64_t* d_w, size_t row_stride, unsigned nrows
                                                                           red_ticket(ctx), red_result(ctx), next_seq(ctx));
     }
     PK_LAUNCH_CHECK(ctx);
+    if (defer) return PK_OK;
     return nv == 2 ? collect_reduction<6>(ctx, out) : collect_reduction<3>(ctx, out);
 }
 }  // namespace pk

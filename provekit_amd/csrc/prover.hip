@@ -33,6 +33,8 @@ int open_raw(pk_ctx* ctx, const uint64_t* d_leaves, const uint64_t* d_nodes, siz
              const uint64_t* indices, size_t k, int canonical_leaves, uint64_t* leaves_out, uint64_t* sibling_digests, uint64_t* auth_paths);
 unsigned shard_factor(const pk_ctx* ctx, size_t rows);
 size_t commit_scratch_fes(const pk_ctx* ctx, size_t rows, size_t width);
+int dot_rows_x(pk_ctx* ctx, const uint64_t* d_w, size_t row_stride, unsigned nrows, const uint64_t* d_f, const uint64_t* d_g, size_t n, uint64_t* out,
+               bool defer);
 int lincomb2(pk_ctx* ctx, uint64_t* d_out, const uint64_t* d_a, const uint64_t* beta, const uint64_t* d_b, size_t n);
 int fold_pairs2(pk_ctx* ctx, const uint64_t* d_v0, uint64_t* d_out0, const uint64_t* d_v1, uint64_t* d_out1, size_t len, const uint64_t* r);
 // latency mode (ctx.hpp): launch-only rounds, gated on a challenge the host publishes later (mle.hip, reduce.hpp)
@@ -1266,6 +1268,21 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
         }
     }
     lap("zk sumcheck rounds");
+    // latency mode: the witness statement's external rows and its six weighted sums depend on alpha and nothing else, and the transcript
+    // wants them only AFTER the blinding WHIR proof -- 0.4 ms of kernels that go to the side stream now and run underneath that proof
+    fe* d_eq_alpha_side = nullptr;
+    fe* d_rows_side = nullptr;
+    const bool overlap_rows = overlap_blinding && n_witness > 0;
+    if (overlap_rows) {
+        pk_ctx* sc = s->side;
+        d_eq_alpha_side = A.alloc((size_t)1 << m_0);
+        d_rows_side = A.alloc(3 * n_witness);
+        if (!d_eq_alpha_side || !d_rows_side) return set_err(ctx, PK_ERR_OOM, "prover arena exhausted (external rows)");
+        int rc = pk_eq_table(sc, (const uint64_t*)alpha.data(), m_0, U(d_eq_alpha_side));
+        if (!rc) rc = pk_r1cs_external_row(sc, s->r1cs, U(d_eq_alpha_side), U(d_rows_side));
+        if (!rc) rc = dot_rows_x(sc, U(d_rows_side), n_witness, 3, U(W.f_evals), U(W.g_evals), n_witness, nullptr, /*defer=*/true);
+        if (rc) return set_err(ctx, rc, "external rows on the side stream: %s", pk_last_error(sc));
+    }
     // statement over the blinding commitment: weight = expand_powers(alpha) zero-extended (whir_r1cs.rs:347-366,371-380)
     {
         const size_t NB2 = 2 * NB;
@@ -1288,15 +1305,19 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     }
     lap("blinding WHIR proof");
     // --- external rows and the statement over the witness commitment (whir_r1cs.rs:81-91, 382-412)
-    ALLOC(d_eq_alpha, M0);
-    CK(pk_eq_table(ctx, (const uint64_t*)alpha.data(), m_0, U(d_eq_alpha)));
-    ALLOC(d_rows, 3 * (n_witness ? n_witness : 1));
     // sharded witness WHIR: a rank needs (and computes) only the columns of the rows inside its block of the hypercube
     const bool st_sharded = whir_sharded(ctx, m);
     const size_t blk = st_sharded ? ((size_t)1 << m) / G : (size_t)1 << m, blk_lo = st_sharded ? (size_t)rank * blk : 0;
     const size_t col_hi = n_witness < blk_lo + blk ? n_witness : blk_lo + blk, col_n = col_hi > blk_lo ? col_hi - blk_lo : 0;
-    if (st_sharded) CK(external_row_range(ctx, s->r1cs, U(d_eq_alpha), blk_lo, col_hi, U(d_rows)));  // S4, this rank's columns
-    else CK(pk_r1cs_external_row(ctx, s->r1cs, U(d_eq_alpha), U(d_rows)));                            // S4
+    fe* d_rows = d_rows_side;
+    if (!overlap_rows) {
+        ALLOC(d_eq_alpha, M0);
+        CK(pk_eq_table(ctx, (const uint64_t*)alpha.data(), m_0, U(d_eq_alpha)));
+        ALLOC(d_rows_, 3 * (n_witness ? n_witness : 1));
+        d_rows = d_rows_;
+        if (st_sharded) CK(external_row_range(ctx, s->r1cs, U(d_eq_alpha), blk_lo, col_hi, U(d_rows)));  // S4, this rank's columns
+        else CK(pk_r1cs_external_row(ctx, s->r1cs, U(d_eq_alpha), U(d_rows)));                            // S4
+    }
     fe* wts[3];
     const size_t wlen[3] = {n_witness, n_witness, n_witness};
     std::vector<uint8_t> claimed;
@@ -1308,7 +1329,12 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
         // the three rows share f and g, so all six sums come from one pass (S5)
         for (int k = 0; k < 3; k++) wts[k] = d_rows + (size_t)k * n_witness;
         uint64_t o[24] = {};
-        if (st_sharded || n_witness) CK(dot_rows(ctx, U(d_rows + blk_lo), n_witness, 3, U(W.f_evals + blk_lo), U(W.g_evals + blk_lo), col_n, o));
+        if (overlap_rows) {  // launched before the blinding WHIR proof: finished long ago
+            CK(sync_stream(s->side));
+            memcpy(o, s->side->h_pinned, 32 * 6);
+        } else if (st_sharded || n_witness) {
+            CK(dot_rows(ctx, U(d_rows + blk_lo), n_witness, 3, U(W.f_evals + blk_lo), U(W.g_evals + blk_lo), col_n, o));
+        }
         for (int k = 0; k < 3; k++) {
             fsum[k] = h_load(o + 8 * k);
             gsum[k] = h_load(o + 8 * k + 4);
