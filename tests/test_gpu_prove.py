@@ -203,6 +203,12 @@ def prove_verify_size_class(ctx, oracle, m, check_layout=False):
     scheme = WhirR1CSScheme(ctx, r1cs, m, m_0, cfg_w, cfg_b)
     proof = scheme.prove(d_z, seed=1)
     assert scheme.prove(d_z, seed=1) == proof
+    # latency mode (gated sumcheck rounds, blinding commitment and external rows on a side stream) writes the same bytes at this size too
+    ctx.set_latency_mode(True)
+    try:
+        assert scheme.prove(d_z, seed=1) == proof
+    finally:
+        ctx.set_latency_mode(False)
 
     def vcfg(c):
         return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,

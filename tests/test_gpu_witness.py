@@ -165,6 +165,11 @@ def test_noir_prove_is_challenges_then_builders_then_fill_then_prove(ctx, oracle
     d_acir = ctx.upload(_mont(oracle, acir))
     proof = scheme.noir_prove(prog, d_acir, len(acir), pub_idx, seed=seed)
     assert proof == scheme.noir_prove(prog, d_acir, len(acir), pub_idx, seed=seed)
+    ctx.set_latency_mode(True)  # the same call in latency mode (pk_ctx_set_latency_mode): the same bytes
+    try:
+        assert proof == scheme.noir_prove(prog, d_acir, len(acir), pub_idx, seed=seed)
+    finally:
+        ctx.set_latency_mode(False)
 
     # step by step, with the oracle beside every step
     pub = [acir[i] for i in pub_idx]
