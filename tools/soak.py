@@ -25,9 +25,14 @@ for case, (m, m_0, nc, n_in, pb) in enumerate([(9, 7, 100, 60, 5.0), (10, 8, 200
     d_z = ctx.upload(oracle.to_mont(oracle.ints_to_limbs(z)))
     mats = [(t[0], t[1], [coeffs[v] for v in t[2]]) for t in trips]
     for seed in range(40):
+        ctx.set_latency_mode(seed % 2 == 1)  # every other proof in latency mode (gated rounds, side stream): the same verifier must accept it
         proof = scheme.prove(d_z, seed=seed * 7919 + case)
+        if seed % 8 == 1:
+            ctx.set_latency_mode(False)
+            assert scheme.prove(d_z, seed=seed * 7919 + case) == proof, (case, seed, "latency mode wrote another transcript")
         assert V.verify(proof, scheme.domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b), r1cs=(nc, nw, mats) if seed % 10 == 0 else None), (case, seed)
         n_ok += 1
+    ctx.set_latency_mode(False)
     scheme.close(); r1cs.close()
     print("case", case, "ok", n_ok, round(time.time() - t0, 1), "s", flush=True)
 print("soak passed:", n_ok, "proofs")
