@@ -261,6 +261,30 @@ def main():
         "T3": {"root": hx(fe(233312)), "height": 15, "opened": idx3, "leaves": [[hx(x) for x in l] for l in l3],
                "sumcheck_evals": [[hx(x) for x in h] for h in H3], "folding_randomness": [hx(x) for x in r3]},
     }
+    # the proof-of-work nonces, in wire order (blinding WHIR: round 0, final; witness WHIR: rounds 0..3, final): the difficulties are not in
+    # the proof, but a valid nonce of a d-bit grind is geometric with mean 2^d -- their magnitudes test the derived pow_bits statistically
+    sys.path.insert(0, ROOT)
+    import verifier as V
+    from provekit_amd.scheme import WhirConfig, blinding_config_for
+
+    nonces = []
+
+    def collect(A, bits):
+        if bits > 0:
+            A.challenge_bytes(32)
+            nonces.append(int.from_bytes(A.next_bytes(8), "big"))
+
+    keep, V.check_pow = V.check_pow, collect
+    try:
+        def vcfg(c):
+            return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
+                                c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
+
+        V.verify(T, b"", 21, 20, vcfg(WhirConfig.for_size(21)), vcfg(blinding_config_for(20)), structure_only=True, hash_version=1)
+    finally:
+        V.check_pow = keep
+    assert len(nonces) == 7
+    out["pow_nonces"] = {"blinding": nonces[:2], "witness": nonces[2:]}
     json.dump(out, open(os.path.join(HERE, "fixture_whir.json"), "w"), indent=0)
     print("fixture_whir.json written; all relations hold")
 

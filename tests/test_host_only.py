@@ -145,3 +145,35 @@ def test_sparse_matrix_rejects_malformed_arrays():
         SparseMatrix(3, 4, np.array([0, 2, 1], np.uint32), np.array([0, 1, 3], np.uint32), np.array([0, 0, 1], np.uint32))  # offsets not sorted
     with pytest.raises(ValueError):
         SparseMatrix(3, 4, np.array([0, 1, 5], np.uint32), np.array([0, 1, 3], np.uint32), np.array([0, 0, 1], np.uint32))  # offset beyond nnz
+
+
+def test_derived_pow_bits_are_consistent_with_the_reference_proofs_nonces():
+    """the grinding difficulties pk_whir_config_derive computes (blinding 6 / 4, witness 19 / 16 / 16 / 18 / 11 bits) cannot be
+    read off a proof -- but the reference's proof carries the seven nonces its grinder found, and a valid nonce of a d-bit grind is (close to)
+    geometric with mean 2^d.  The fixture's nonces are 67, 2 | 332221, 106952, 37657, 156995, 1587: log2 = 6.1, 1.6 | 18.3, 16.7, 15.2, 17.3,
+    10.6.  A statistical pin, not an exact one: (i) every nonce lies in the window a d-bit search produces with probability 0.97, (ii) the
+    derived vector is more likely than the same vector shifted by two bits or more either way, than a flat 16-bit schedule (round 1 of this
+    repository) and than no grinding at all, (iii) the mean of log2(nonce) - d sits where an exponential puts it (-0.83 +- 0.7)."""
+    import json
+    import math
+    import os
+
+    from provekit_amd.scheme import WhirConfig, blinding_config_for
+
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fixture_whir.json")))
+    cb, cw = blinding_config_for(20), WhirConfig.derive(21)
+    bits = list(cb.pow_bits) + [cb.final_pow_bits] + list(cw.pow_bits) + [cw.final_pow_bits]
+    nonces = fx["pow_nonces"]["blinding"] + fx["pow_nonces"]["witness"]
+    assert bits == [6.0, 4.0, 19.0, 16.0, 16.0, 18.0, 11.0] and len(nonces) == 7
+
+    def loglik(ds):  # the smallest valid nonce of a d-bit grind: P(n) = p (1 - p)^n, p = 2^-d (the verifier's threshold, pow.rs:24-26)
+        return sum(math.log(2.0 ** -d) + n * math.log1p(-(2.0 ** -d)) if d > 0 else (0.0 if n == 0 else -math.inf) for d, n in zip(ds, nonces))
+
+    for d, n in zip(bits, nonces):
+        assert 2.0 ** (d - 5) <= n + 1 <= 2.0 ** (d + 4), (d, n)
+    ours = loglik(bits)
+    for shift in (-6, -4, -3, -2, 2, 3, 4, 6):
+        assert ours > loglik([d + shift for d in bits]), shift
+    assert ours > loglik([16.0] * 7) and ours > loglik([10.0] * 7) and loglik([0.0] * 7) == -math.inf
+    dev = [math.log2(n + 1) - d for d, n in zip(bits, nonces)]
+    assert -1.6 < sum(dev) / len(dev) < -0.1, dev
