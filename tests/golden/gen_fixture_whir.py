@@ -142,6 +142,89 @@ def common_root(f0, a0, f1, a1):
     return (-g[0]) * inv(g[1]) % P
 
 
+
+# ---- small polynomial arithmetic over F_p (lists, low degree first) for the zk-sumcheck recovery ------------------------------
+def ptrim(a):
+    a = [x % P for x in a]
+    while a and a[-1] == 0:
+        a.pop()
+    return a
+
+
+def pmod(a, f):
+    a, f = ptrim(a), ptrim(f)
+    iv = inv(f[-1])
+    while len(a) >= len(f):
+        q = a[-1] * iv % P
+        d = len(a) - len(f)
+        for k, c in enumerate(f):
+            a[d + k] = (a[d + k] - q * c) % P
+        a = ptrim(a)
+    return a
+
+
+def pmulmod(a, b, f):
+    r = [0] * (len(a) + len(b) - 1 if a and b else 0)
+    for i, x in enumerate(a):
+        for j, y in enumerate(b):
+            r[i + j] = (r[i + j] + x * y) % P
+    return pmod(r, f)
+
+
+def ppowmod(base, e, f):
+    res, base = [1], pmod(base, f)
+    while e:
+        if e & 1:
+            res = pmulmod(res, base, f)
+        base = pmulmod(base, base, f)
+        e >>= 1
+    return res
+
+
+def pgcd2(a, b):
+    a, b = ptrim(a), ptrim(b)
+    while b:
+        a, b = b, pmod(a, b)
+    return a
+
+
+def roots_in_field(f):
+    """all roots in F_p of a polynomial of degree <= 3 (Cantor-Zassenhaus equal-degree splitting of gcd(f, x^p - x))"""
+    f = ptrim(f)
+    if len(f) <= 1:
+        return []
+    xp = ppowmod([0, 1], P, f)
+    lin = pgcd2(f, ptrim([(xp[0] if xp else 0), ((xp[1] if len(xp) > 1 else 0) - 1)] + list(xp[2:])))
+    out, stack, shift = [], [lin], 1
+    while stack:
+        g = stack.pop()
+        if len(g) <= 1:
+            continue
+        if len(g) == 2:
+            out.append((-g[0]) * inv(g[1]) % P)
+            continue
+        while True:
+            h = ppowmod([shift, 1], (P - 1) // 2, g)
+            shift += 1
+            h = pgcd2(g, ptrim([(h[0] if h else 0) - 1] + list(h[1:])))
+            if 1 < len(h) < len(g):
+                break
+        stack.append(h)
+        q, rem = [], ptrim(g)
+        # g / h
+        hv = inv(h[-1])
+        quo = [0] * (len(rem) - len(h) + 1)
+        while len(rem) >= len(h):
+            c = rem[-1] * hv % P
+            d = len(rem) - len(h)
+            quo[d] = c
+            for k, x in enumerate(h):
+                rem[d + k] = (rem[d + k] - c * x) % P
+            rem = ptrim(rem)
+        stack.append(ptrim(quo))
+    return sorted(out)
+
+
 def main():
     T = G.read_transcript()
     fe = lambda off: int.from_bytes(T[off : off + 32], "little")
@@ -261,6 +344,37 @@ def main():
         "T3": {"root": hx(fe(233312)), "height": 15, "opened": idx3, "leaves": [[hx(x) for x in l] for l in l3],
                "sumcheck_evals": [[hx(x) for x in h] for h in H3], "folding_randomness": [hx(x) for x in r3]},
     }
+    # ---------------------------------------------------------------- the zk sumcheck (whir_r1cs.rs:228-369), recovered
+    # 20 x 4 coefficients @224: the verifier checks hhat_i(alpha_i) == hhat_{i+1}(0) + hhat_{i+1}(1) (verifier/src/whir_r1cs.rs:131-144), so
+    # alpha_i is a root of a cubic (1 or 3 candidates); the two "Polynomial sums" @2784 are <expand_powers(alpha), f_b> over the blinding
+    # commitment's two polynomials in EVALUATION form (whir_r1cs.rs:347-366, 371-380) = sum_i cubic_{b,i}(alpha_i): two more equations
+    # that single out one candidate per round AND determine the last challenge as the common root of two cubics.
+    hh = [[fe(224 + 128 * i + 32 * k) for k in range(4)] for i in range(20)]
+    bs = [fe(2784), fe(2816)]
+    cands = []
+    for i in range(19):
+        c = hh[i][:]
+        c[0] = (c[0] - (cub(hh[i + 1], 0) + cub(hh[i + 1], 1))) % P
+        r = roots_in_field(c)
+        assert r, "round %d: no challenge satisfies the sumcheck relation under this coefficient convention" % i
+        cands.append(r)
+    ev1 = to_evals(f[1])
+    cubs = [[ev[4 * i : 4 * i + 4] for i in range(20)], [ev1[4 * i : 4 * i + 4] for i in range(20)]]
+    hits = []
+    for combo in itertools.product(*cands):
+        res = [(bs[b] - sum(cub(cubs[b][i], combo[i]) for i in range(19))) % P for b in range(2)]
+        g0 = cubs[0][19][:]
+        g0[0] = (g0[0] - res[0]) % P
+        g1 = cubs[1][19][:]
+        g1[0] = (g1[0] - res[1]) % P
+        common = pgcd2(g0, g1)
+        if len(common) == 2:
+            hits.append(list(combo) + [(-common[0]) * inv(common[1]) % P])
+    assert len(hits) == 1, "expected exactly one consistent challenge vector, found %d" % len(hits)
+    alpha = hits[0]
+    rho = (cub(hh[0], 0) + cub(hh[0], 1)) * inv(fe(192)) % P
+    out["zk_sumcheck"] = {"coefficients": [[hx(x) for x in h] for h in hh], "polynomial_sums": [hx(x) for x in bs], "alpha": [hx(x) for x in alpha],
+                          "rho": hx(rho), "candidates_per_round": [len(c) for c in cands]}
     # the proof-of-work nonces, in wire order (blinding WHIR: round 0, final; witness WHIR: rounds 0..3, final): the difficulties are not in
     # the proof, but a valid nonce of a d-bit grind is geometric with mean 2^d -- their magnitudes test the derived pow_bits statistically
     sys.path.insert(0, ROOT)

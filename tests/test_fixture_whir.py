@@ -87,6 +87,35 @@ def test_oracle_witness_tail(oracle):
         assert np.array_equal(lhs, oracle.eval_univariate(f4, x))
 
 
+
+def test_oracle_zk_sumcheck_messages_are_the_references(oracle):
+    """Round 4: the reference's 20 zk-sumcheck challenges and rho, RECOVERED from its proof (gen_fixture_whir.py): alpha_i is a root of
+    hhat_i(X) = hhat_{i+1}(0) + hhat_{i+1}(1) -- the relation provekit/verifier/src/whir_r1cs.rs:131-144 checks, with the four scalars read as
+    monomial coefficients, low degree first -- and exactly ONE choice among the 3^10 candidate vectors also gives both "Polynomial sums" the
+    prover absorbed: <expand_powers(alpha) zero-extended, f_b> over the EVALUATION forms of the two committed blinding polynomials
+    (whir_r1cs.rs:347-366, 371-380), the last challenge being the common root of two cubics.  That pins, against the reference's own bytes: the
+    cubic message convention (row S3's wire form), the weight layout w[4 i + k] = alpha_i^k (S6) and the weighted sums over evaluation tables
+    (S5) -- rows the earlier rounds could only pin to definitions."""
+    z, b = FX["zk_sumcheck"], FX["blinding"]
+    hh, alpha, rho = [ints(h) for h in z["coefficients"]], ints(z["alpha"]), int(z["rho"], 16)
+    cub = lambda c, x: (c[0] + x * (c[1] + x * (c[2] + x * c[3]))) % P
+    assert len(alpha) == 20 and z["candidates_per_round"].count(3) == 10
+    assert rho * int(b["sum_g"], 16) % P == (cub(hh[0], 0) + cub(hh[0], 1)) % P  # whir_r1cs.rs:126-129: saved = rho * sum_g
+    for i in range(19):
+        assert cub(hh[i], alpha[i]) == (cub(hh[i + 1], 0) + cub(hh[i + 1], 1)) % P, i
+    # the statement over the blinding commitment, through the C oracle: weights, to_evals, dot
+    w = [0] * 256
+    for i, a in enumerate(alpha):
+        w[4 * i : 4 * i + 4] = [1, a, a * a % P, a * a * a % P]
+    wm = mont(oracle, w)
+    for f, want in zip((b["f0"], b["f1"]), z["polynomial_sums"]):
+        ev = oracle.to_evals(mont(oracle, ints(f)), 8)
+        assert canon_ints(oracle, oracle.dot(wm, ev)[None])[0] == int(want, 16)
+    # the same sums from this repository's restatement of the prover's host algebra: f0's first 80 evaluations ARE the blinding cubics
+    ev0 = canon_ints(oracle, oracle.to_evals(mont(oracle, ints(b["f0"])), 8))
+    assert sum(cub(ev0[4 * i : 4 * i + 4], alpha[i]) for i in range(20)) % P == int(z["polynomial_sums"][0], 16)
+
+
 # ------------------------------------------------------------------------------------------------ GPU: HIP path
 @pytest.fixture()
 def ctx_v1(ctx):
@@ -151,3 +180,22 @@ def test_hip_witness_tail(ctx_v1, oracle):
         x = np.empty(4, dtype=np.uint64)
         oracle.L.pko_fe_pow(oracle._p(w15), int(i), oracle._p(x))
         assert np.array_equal(folded[k], sc.eval_univariate(ctx, d4, 32, x))
+
+
+@pytest.mark.gpu
+def test_hip_blinding_statement_sums_are_the_references(ctx_v1, oracle):
+    """the two "Polynomial sums" of the reference's proof through the C ABI: to_evals of the two committed blinding polynomials (pk_to_evals)
+    and their weighted sums against expand_powers(alpha) (pk_dot), alpha = the reference's own challenges as recovered from its proof"""
+    from provekit_amd import sumcheck as sc
+
+    ctx, z, b = ctx_v1, FX["zk_sumcheck"], FX["blinding"]
+    alpha = ints(z["alpha"])
+    w = [0] * 256
+    for i, a in enumerate(alpha):
+        w[4 * i : 4 * i + 4] = [1, a, a * a % P, a * a * a % P]
+    d_w = ctx.upload(mont(oracle, w))
+    for f, want in zip((b["f0"], b["f1"]), z["polynomial_sums"]):
+        d = ctx.upload(mont(oracle, ints(f)))
+        sc.to_evals(ctx, d, 8)
+        assert canon_ints(oracle, sc.weighted_sum(ctx, d_w, d, 256)[None])[0] == int(want, 16)
+        assert canon_ints(oracle, sc.weighted_sum(ctx, d_w, d, 80)[None])[0] == int(want, 16)  # the weight is zero beyond 4 m_0 entries
