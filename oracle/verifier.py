@@ -26,11 +26,16 @@ class VerifyError(Exception):
 # structure_only: walk a transcript in the verifier's read order checking framing only (lengths, counts, hint shapes,
 # Merkle openings under `hash_version`) and none of the Fiat-Shamir-dependent relations -- used to replay the REFERENCE's
 # own proof fixture, whose domain-separator labels (hence challenges) this restatement cannot reproduce.
-_MODE = {"structure_only": False, "hash_version": 2}
+# solved: replay a transcript whose CHALLENGES were recovered algebraically from the proof itself (tests/golden/gen_fixture_whir.py: the
+# reference's own proof, whose sponge IV is unknown): every relation between scalars is checked with those challenges; only the two checks
+# that consume challenge BYTES (proof of work, STIR indices) are skipped.
+_MODE = {"structure_only": False, "hash_version": 2, "solved": False}
 
 
-def ensure(cond, msg, structural=False):
+def ensure(cond, msg, structural=False, challenge_bytes=False):
     if _MODE["structure_only"] and not structural:
+        return
+    if _MODE["solved"] and challenge_bytes:
         return
     if not cond:
         raise VerifyError(msg)
@@ -187,6 +192,63 @@ class Arthur:
         return self.i == len(self.t) and not self.ops
 
 
+class SolvedArthur(Arthur):
+    """Arthur whose scalar challenges come from a list (in squeeze order) instead of a sponge; challenge bytes are zeros.  `None` entries are
+    challenges nobody recovered: they may be squeezed but must not decide anything that is checked (the caller stops before they would)."""
+
+    def __init__(self, transcript: bytes, challenges):
+        super().__init__(b"", transcript)
+        self.pending = list(challenges)
+
+    def _absorb(self, x):
+        pass
+
+    def challenge_scalars(self, n):
+        out = []
+        for _ in range(n):
+            if not self.pending:
+                raise VerifyError("more scalar challenges squeezed than were supplied")
+            out.append(self.pending.pop(0))
+        return out
+
+    def challenge_bytes(self, n):
+        return bytes(n)
+
+
+def verify_solved_prefix(transcript_prefix: bytes, challenges, m: int, m_0: int, cfg_w: WhirConfig, cfg_b: WhirConfig, hash_version: int = 2):
+    """WhirR1CSVerifier::verify up to and including the blinding WHIR proof, on a transcript whose challenges were recovered from the proof
+    itself (see _MODE["solved"]).  challenges, in squeeze order: witness OOD point(s), witness batching randomness, r (m_0), blinding OOD
+    point(s), blinding batching randomness, rho, alpha (m_0), then the blinding WHIR's (initial combination randomness, k folding challenges,
+    per round: OOD point(s), combination randomness, k folding challenges, ...).  Returns (alpha, total folding randomness reversed)."""
+    old = dict(_MODE)
+    _MODE.update(structure_only=False, hash_version=hash_version, solved=True)
+    try:
+        A = SolvedArthur(transcript_prefix, challenges)
+        parse_commitment(A, cfg_w)
+        A.challenge_scalars(m_0)
+        bcom = parse_commitment(A, cfg_b)
+        (sum_g,) = A.next_scalars(1)
+        (rho,) = A.challenge_scalars(1)
+        saved = rho * sum_g % P
+        alpha = []
+        for _ in range(m_0):
+            hhat = A.next_scalars(4)
+            (a_i,) = A.challenge_scalars(1)
+            ensure(saved == (eval_cubic(hhat, 0) + eval_cubic(hhat, 1)) % P, "Sumcheck equality assertion failed")
+            saved = eval_cubic(hhat, a_i)
+            alpha.append(a_i)
+        bsums = A.next_scalars(2)
+        brev, bdef = whir_verify(A, bcom, cfg_b, [(bsums[0] + bcom["beta"] * bsums[1]) % P])
+        table = [0] * (1 << cfg_b.n_vars)
+        for i, a in enumerate(alpha):
+            table[4 * i : 4 * i + 4] = [1, a, a * a % P, a * a * a % P]
+        ensure(bdef[0] == mle_eval_table(table, brev), "deferred evaluation of the blinding weight is wrong")
+        ensure(A.i == len(transcript_prefix) and not A.pending, "the prefix or the challenge list was not consumed exactly", True)
+        return alpha, brev
+    finally:
+        _MODE.update(old)
+
+
 # ------------------------------------------------------------------ helpers
 def eval_cubic(c, x):
     return (c[0] + x * (c[1] + x * (c[2] + x * c[3]))) % P
@@ -293,7 +355,7 @@ def check_pow(A: Arthur, bits: float):  # utilities.go:84-101; pow.rs:24-26
         return
     ch = int.from_bytes(A.challenge_bytes(32), "little")
     nonce = int.from_bytes(A.next_bytes(8), "big")
-    ensure(pr.compress(ch, nonce) < pr.pow_threshold(bits), "proof of work below difficulty")
+    ensure(pr.compress(ch, nonce) < pr.pow_threshold(bits), "proof of work below difficulty", challenge_bytes=True)
 
 
 def stir_indexes(A: Arthur, domain_size, fold, nq):  # whir_utilities.go:48-77
@@ -347,7 +409,7 @@ def whir_verify(A: Arthur, com, cfg: WhirConfig, claimed_sums):
         leaves = parse_vec_vec(A.hint())
         sib, paths, idx = parse_multipath(A.hint())
         verify_merkle(leaves, sib, paths, idx, prev_root)
-        ensure(idx == idx_expected, "opened leaves are not the STIR challenge set")
+        ensure(idx == idx_expected, "opened leaves are not the STIR challenge set", challenge_bytes=True)
         if first:  # rlcBatchedLeaves (mtUtilities.go:98-114)
             fw = 1 << k
             leaves = [[sum(l[b * fw + j] * pow(beta, b, P) for b in range(cfg.batch_size)) % P for j in range(fw)] for l in leaves]
@@ -370,7 +432,7 @@ def whir_verify(A: Arthur, com, cfg: WhirConfig, claimed_sums):
     leaves = parse_vec_vec(A.hint())
     sib, paths, idx = parse_multipath(A.hint())
     verify_merkle(leaves, sib, paths, idx, prev_root)
-    ensure(idx == idx_expected, "final opened leaves are not the STIR challenge set")
+    ensure(idx == idx_expected, "final opened leaves are not the STIR challenge set", challenge_bytes=True)
     if first:
         fw = 1 << k
         leaves = [[sum(l[b * fw + j] * pow(beta, b, P) for b in range(cfg.batch_size)) % P for j in range(fw)] for l in leaves]
@@ -417,7 +479,7 @@ def verify(transcript: bytes, domain_separator: bytes, m: int, m_0: int, cfg_w: 
     (alpha, point) -> [eq(alpha)^T M_k eq(point) for k in A, B, C] over canonical ints (tests/oracle_lib.matrix_evaluator).
     structure_only / hash_version: see _MODE."""
     old = dict(_MODE)
-    _MODE.update(structure_only=structure_only, hash_version=hash_version)
+    _MODE.update(structure_only=structure_only, hash_version=hash_version, solved=False)
     try:
         return _verify(transcript, domain_separator, m, m_0, cfg_w, cfg_b, r1cs)
     finally:

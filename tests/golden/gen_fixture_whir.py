@@ -375,6 +375,83 @@ def main():
     rho = (cub(hh[0], 0) + cub(hh[0], 1)) * inv(fe(192)) % P
     out["zk_sumcheck"] = {"coefficients": [[hx(x) for x in h] for h in hh], "polynomial_sums": [hx(x) for x in bs], "alpha": [hx(x) for x in alpha],
                           "rho": hx(rho), "candidates_per_round": [len(c) for c in cands]}
+    # ---------------------------------------------------------------- the blinding WHIR proof (whir.go:51-220), every challenge recovered
+    # With alpha known the rest of the blinding WHIR can be SOLVED: gamma_0 from the first sumcheck claim; r4..r6 are roots of the second group's
+    # quadratics, r7 makes the fold of f' the final coefficient; the deferred hint must be the MLE of expand_powers(alpha) at the reversed
+    # folding point (one of the 8 candidates); gamma_1 is a root of the degree-32 combination polynomial, z1 a root of f'(X) = OOD answer,
+    # and the final WHIR check picks the pair.  Exactly one solution: the verifier equations restated in oracle/verifier.py hold on the
+    # reference's own proof.
+    sys.path.insert(0, ROOT)
+    import verifier as V
+
+    quad = V.quad_from_evals
+    off = 2848
+    H0 = [[fe(off + 96 * k + 32 * i) for i in range(3)] for k in range(4)]
+    assert H0 == H
+    off += 384 + 72  # the sumcheck, then root (3232), OOD answer, nonce
+    ood1 = fe(3264)
+    pay, off2 = G.parse_hint(T, off)
+    leaves0 = G.parse_stir_answers(pay)
+    pay2, off = G.parse_hint(T, off2)
+    idx0 = G.parse_multipath(pay2)[3]
+    H1 = [[fe(off + 96 * k + 32 * i) for i in range(3)] for k in range(4)]
+    off += 384
+    fin = fe(off)
+    off += 32 + 8
+    pay, off2 = G.parse_hint(T, off)
+    leaves1 = G.parse_stir_answers(pay)
+    pay2, off = G.parse_hint(T, off2)
+    pay, end_blinding = G.parse_hint(T, off)
+    rd = V.Rd(pay)
+    deferred = V.parse_vec(rd)
+    assert len(deferred) == 1 and idx0 == list(range(32)) and end_blinding == 47228
+    # the hint sets above are the ones already used: leaves0 == leaves (T0), leaves1 == l1 (T1)
+    assert leaves0 == leaves and leaves1 == l1
+    r03 = list(r0)
+    claim = (bs[0] + beta * bs[1]) % P
+    gamma0 = (H0[0][0] + H0[0][1] - (fe(128) + beta * fe(160))) * inv(claim) % P
+    last = quad(H0[3], r03[3])
+    rlc = [[(l[j] + beta * l[16 + j]) % P for j in range(16)] for l in leaves0]
+    folds = [pr.multivar_poly(l, r03) for l in rlc]
+    gen9 = pr.root_of_unity(9)
+    exp_gen = pow(gen9, 16, P)
+    assert all(pr.eval_univariate(fp, pow(exp_gen, i, P)) == folds[k] for k, i in enumerate(idx0))
+
+    def quad_roots(evs, target):
+        i2 = inv(2)
+        return roots_in_field([(evs[0] - target) % P, (-evs[2] + 4 * evs[1] - 3 * evs[0]) * i2 % P, (evs[2] - 2 * evs[1] + evs[0]) * i2 % P])
+
+    table = [0] * 256
+    for i, a in enumerate(alpha):
+        table[4 * i : 4 * i + 4] = [1, a, a * a % P, a * a * a % P]
+    r47 = []
+    for r456 in itertools.product(*[quad_roots(H1[k], (H1[k + 1][0] + H1[k + 1][1]) % P) for k in range(3)]):
+        base, one = pr.multivar_poly(fp, list(r456) + [0]), pr.multivar_poly(fp, list(r456) + [1])
+        if (one - base) % P == 0:
+            continue
+        cand = list(r456) + [(fin - base) * inv(one - base) % P]
+        if V.mle_eval_table(table, (r03 + cand)[::-1]) == deferred[0]:
+            r47.append(cand)
+    assert len(r47) == 1, "deferred weight evaluation: %d consistent folding points" % len(r47)
+    r47 = r47[0]
+    rev = (r03 + r47)[::-1]
+    cpoly = [ood1] + folds
+    cpoly[0] = (cpoly[0] - (H1[0][0] + H1[0][1] - last)) % P
+    zpoly = fp[:]
+    zpoly[0] = (zpoly[0] - ood1) % P
+    pairs = []
+    for g1 in roots_in_field(cpoly):
+        comb = V.expand_randomness(g1, 1 + len(folds))
+        for z1 in roots_in_field(zpoly):
+            value = (V.eq_poly(pr.expand_from_univariate(z, 8), rev) + gamma0 * deferred[0]) % P
+            for c, pt in zip(comb, [z1] + [pow(exp_gen, i, P) for i in idx0]):
+                value = (value + c * V.eq_poly(pr.expand_from_univariate(pt, 4), rev[:4])) % P
+            if quad(H1[3], r47[3]) == value * fin % P:
+                pairs.append((g1, z1))
+    assert len(pairs) == 1, "final WHIR check: %d consistent (combination randomness, OOD point) pairs" % len(pairs)
+    out["blinding_whir"] = {"initial_combination_randomness": hx(gamma0), "round0_ood_point": hx(pairs[0][1]), "round0_combination_randomness": hx(pairs[0][0]),
+                            "round0_folding_randomness": [hx(x) for x in r47], "deferred_weight_evaluation": hx(deferred[0]),
+                            "transcript_prefix_hex": bytes(T[:end_blinding]).hex()}
     # the proof-of-work nonces, in wire order (blinding WHIR: round 0, final; witness WHIR: rounds 0..3, final): the difficulties are not in
     # the proof, but a valid nonce of a d-bit grind is geometric with mean 2^d -- their magnitudes test the derived pow_bits statistically
     sys.path.insert(0, ROOT)

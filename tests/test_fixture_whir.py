@@ -124,6 +124,54 @@ def ctx_v1(ctx):
     ctx.set_hash_version(2)
 
 
+def test_the_references_own_proof_verifies_with_its_recovered_challenges():
+    """Round 4: every challenge of the reference proof's first 47,228 bytes -- blinding commitment, the 20 zk-sumcheck rounds, the whole
+    blinding WHIR proof -- was recovered from the proof by algebra (gen_fixture_whir.py; each is the UNIQUE solution of the verifier's own
+    equations).  Replaying those bytes through oracle/verifier.py with the recovered values in place of the sponge (the sponge's IV is the
+    one thing that cannot be recovered) runs every scalar relation of WhirR1CSVerifier::verify / RunZKWhir on the reference's real data:
+    sumcheck chains (cubic and quadratic), OOD and STIR point conventions, the batched-leaf combination, the coefficient fold against the
+    final polynomial, the deferred weight evaluation (MLE of expand_powers(alpha) at the reversed folding point), computeWPoly and the final
+    WHIR check -- under Skyscraper v1 for the 45 Merkle openings.  Only the two checks that consume challenge BYTES (proof of work, STIR
+    indices) are skipped.  A verifier restated from the Go circuit that accepts the reference's own proof, and rejects it when any
+    recovered challenge or any proof byte is changed, is what pins rows E1, W1-W3, S3, S5, S6 and the verifier equations themselves."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import verifier as V
+    from provekit_amd.scheme import WhirConfig, blinding_config_for
+
+    b, z, w = FX["blinding"], FX["zk_sumcheck"], FX["blinding_whir"]
+    prefix = bytes.fromhex(w["transcript_prefix_hex"])
+    assert len(prefix) == 47228
+    m, m_0 = 21, 20
+
+    def vcfg(c):
+        return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, c.num_queries, c.ood_samples, c.pow_bits,
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
+
+    cfg_w, cfg_b = vcfg(WhirConfig.for_size(m)), vcfg(blinding_config_for(m_0))
+    h = lambda x: int(x, 16)
+    challenges = ([None, None] + [None] * m_0  # the witness commitment's OOD point and batching randomness, r: not recoverable, not used here
+                  + [h(b["ood_point"]), h(b["batching_randomness"]), h(z["rho"])] + ints(z["alpha"])
+                  + [h(w["initial_combination_randomness"])] + ints(b["folding_randomness"])
+                  + [h(w["round0_ood_point"]), h(w["round0_combination_randomness"])] + ints(w["round0_folding_randomness"]))
+    alpha, rev = V.verify_solved_prefix(prefix, challenges, m, m_0, cfg_w, cfg_b, hash_version=1)
+    assert alpha == ints(z["alpha"]) and rev == (ints(b["folding_randomness"]) + ints(w["round0_folding_randomness"]))[::-1]
+    # it is a real check: one changed challenge, or one changed byte of a scalar or a hint, and the same walk fails
+    for pos in (len([None, None] + [None] * m_0) + 2, len(challenges) - 1, len(challenges) - 6, len(challenges) - 5):
+        bad = list(challenges)
+        bad[pos] = (bad[pos] + 1) % P
+        with pytest.raises(V.VerifyError):
+            V.verify_solved_prefix(prefix, bad, m, m_0, cfg_w, cfg_b, hash_version=1)
+    for off in (200, 2784, 2900, 3264, 3400, 40000, 47200):
+        bad = bytearray(prefix)
+        bad[off] ^= 1
+        with pytest.raises(V.VerifyError):
+            V.verify_solved_prefix(bytes(bad), challenges, m, m_0, cfg_w, cfg_b, hash_version=1)
+    with pytest.raises(V.VerifyError):  # ... and under the v2 hash the openings do not reach their roots
+        V.verify_solved_prefix(prefix, challenges, m, m_0, cfg_w, cfg_b, hash_version=2)
+
+
 @pytest.mark.gpu
 def test_hip_blinding_commitment_is_the_references(ctx_v1, oracle):
     from provekit_amd import sumcheck as sc
