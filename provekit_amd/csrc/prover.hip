@@ -1094,9 +1094,20 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     // busy (its two leaf hashes are chains of 31 compressions).  Its device work goes to a second stream NOW and runs underneath the
     // witness commitment, which fills the chip for 2.6 ms; only the transcript half (root, OOD, batching) waits for its turn.
     const bool overlap_blinding = ctx->latency_mode && comm_world(ctx) == 1 && !getenv("PK_NO_BLINDING_OVERLAP");  // (the env switch: A/B only)
+    struct SideDrain {  // whatever path leaves pk_prove, the side stream must not still be working in this proof's arena
+        pk_scheme* s;
+        bool used = false;
+        ~SideDrain() {
+            if (used && s->side) {
+                (void)hipStreamSynchronize(s->side->stream);
+                s->side->mail_off = 0;
+            }
+        }
+    } side_drain{s};
     // --- commit to the masked witness polynomial (whir_r1cs.rs:57-69)
     BatchCommit W;
     if (overlap_blinding) {
+        side_drain.used = true;
         // the witness commitment's launches first (the chip starts on them at once), then the side stream's, then the witness root
         CK(batch_commit_compute(ctx, A, m, s->whir_witness, (const fe*)d_witness, n_witness, key, RNG_MASK, RNG_G, W));
         if (!s->side) {
