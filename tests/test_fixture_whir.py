@@ -247,3 +247,162 @@ def test_hip_blinding_statement_sums_are_the_references(ctx_v1, oracle):
         sc.to_evals(ctx, d, 8)
         assert canon_ints(oracle, sc.weighted_sum(ctx, d_w, d, 256)[None])[0] == int(want, 16)
         assert canon_ints(oracle, sc.weighted_sum(ctx, d_w, d, 80)[None])[0] == int(want, 16)  # the weight is zero beyond 4 m_0 entries
+
+
+# ------------------------------------------------------------------------------------------------ the blinding WHIR proof, REPLAYED
+def _blinding_whir_inputs():
+    b, z, w = FX["blinding"], FX["zk_sumcheck"], FX["blinding_whir"]
+    hx = lambda x: int(x, 16)
+    alpha = ints(z["alpha"])
+    table = [0] * 256
+    for i, a in enumerate(alpha):
+        table[4 * i : 4 * i + 4] = [1, a, a * a % P, a * a * a % P]
+    return dict(f0=ints(b["f0"]), f1=ints(b["f1"]), beta=hx(b["batching_randomness"]), z0=hx(b["ood_point"]), r03=ints(b["folding_randomness"]),
+                gamma0=hx(w["initial_combination_randomness"]), z1=hx(w["round0_ood_point"]), gamma1=hx(w["round0_combination_randomness"]),
+                r47=ints(w["round0_folding_randomness"]), table=table, alpha=alpha, prefix=bytes.fromhex(w["transcript_prefix_hex"]))
+
+
+def _frame_hint(payload: bytes) -> bytes:
+    return len(payload).to_bytes(4, "little") + payload
+
+
+def _stir_answers_payload(leaves_canon) -> bytes:  # Vec<Vec<F>>, ark-serialize uncompressed (common.go:36-61)
+    out = len(leaves_canon).to_bytes(8, "little")
+    for leaf in leaves_canon:
+        out += len(leaf).to_bytes(8, "little") + b"".join(int(x).to_bytes(32, "little") for x in leaf)
+    return out
+
+
+def _expected_sections(prefix):
+    """the reference's bytes of the blinding WHIR proof, split where the two 8-byte nonces sit (a nonce is found by search on a challenge this
+    replay does not have): [2848, 3296) | nonce | [3304, n1) | nonce | [n1 + 8, 47228)"""
+    import struct
+
+    off = 3304
+    for _ in range(2):
+        off += 4 + struct.unpack_from("<I", prefix, off)[0]
+    n1 = off + 384 + 32  # the round's sumcheck, the final coefficient
+    return prefix[2848:3296], prefix[3304:n1], prefix[n1 + 8 : 47228]
+
+
+def test_oracle_replays_the_references_blinding_whir_bytes(oracle):
+    """With the polynomials recovered from the blinding commitment and every challenge recovered from the proof, the WHIR PROVER's side can
+    be replayed: the C oracle regenerates the reference proof's bytes 2848..47228 -- 24 sumcheck evaluations, the round commitment's root, the
+    OOD answer, the final coefficient, both `stir_answers` hints and the deferred weight evaluation -- byte for byte (the two `merkle_proof`
+    hints are compared in tests/test_host_only.py and the GPU half; the two nonces are found by search on a challenge nobody has)."""
+    import pyref as pr
+
+    I = _blinding_whir_inputs()
+    m = lambda xs: mont(oracle, xs)
+    one = m([1])[0]
+    sc32 = lambda x: int(x).to_bytes(32, "little")
+    c = oracle.vec_axpy(m(I["f0"]), m([I["beta"]])[0], m(I["f1"]))  # f0 + beta f1 (mtUtilities.go:98-114)
+    p = oracle.to_evals(c, 8)
+    w = oracle.eq_accumulate_point(np.zeros((256, 4), np.uint64), 8, m(pr.expand_from_univariate(I["z0"], 8)), one)
+    w = oracle.vec_axpy(w, m([I["gamma0"]])[0], m(I["table"]))
+
+    def group(p, w, rs):
+        out_bytes, fold = b"", None
+        for r in rs:
+            ev, p, w = oracle.sumcheck_quadratic_round(p, w, fold)
+            if fold is not None:
+                p, w = p[: len(p) // 2], w[: len(w) // 2]
+            out_bytes += b"".join(sc32(x) for x in canon_ints(oracle, ev))
+            fold = m([r])[0]
+        p, w = p.copy(), w.copy()
+        oracle.L.pko_fold_pairs(oracle._p(p), len(p), oracle._p(fold))
+        oracle.L.pko_fold_pairs(oracle._p(w), len(w), oracle._p(fold))
+        return out_bytes, p[: len(p) // 2], w[: len(w) // 2]
+
+    sec_a, p, w = group(p, w, I["r03"])
+    fprime = oracle.fold_coeffs(c, 8, m(I["r03"]))
+    leaves1 = oracle.rs_encode(fprime, 1, 4, 4, 4)
+    root1 = oracle.limbs_to_ints(oracle.merkle_commit(leaves1, version=1)[1:2])[0]
+    ans1 = canon_ints(oracle, oracle.eval_univariate(fprime, m([I["z1"]])[0])[None])[0]
+    sec_a += sc32(root1) + sc32(ans1)
+    leaves0 = oracle.rs_encode(m(I["f0"] + I["f1"]), 2, 8, 1, 4)
+    sec_b = _frame_hint(_stir_answers_payload([canon_ints(oracle, l) for l in leaves0]))
+    exp_gen = pow(pr.root_of_unity(9), 16, P)
+    g = 1
+    for pt in [I["z1"]] + [pow(exp_gen, i, P) for i in range(32)]:
+        w = oracle.eq_accumulate_point(w, 4, m(pr.expand_from_univariate(pt, 4)), m([g])[0])
+        g = g * I["gamma1"] % P
+    sc_bytes, p, w = group(p, w, I["r47"])
+    final = canon_ints(oracle, oracle.fold_coeffs(fprime, 4, m(I["r47"])))
+    assert len(final) == 1 and canon_ints(oracle, p) == final  # the sumcheck's polynomial IS the final polynomial
+    rev = (I["r03"] + I["r47"])[::-1]
+    deferred = canon_ints(oracle, oracle.dot(m(I["table"]), oracle.eq_table(m(rev)))[None])[0]
+    want_a, want_b, want_c = _expected_sections(I["prefix"])
+    assert sec_a == want_a
+    assert want_b.startswith(sec_b) and want_b.endswith(sc_bytes + sc32(final[0]))
+    idx1 = [0, 1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14]  # the 13 leaves of the round tree the reference opened
+    sec_c = _frame_hint(_stir_answers_payload([canon_ints(oracle, leaves1[i]) for i in idx1]))
+    assert want_c.startswith(sec_c) and want_c.endswith(_frame_hint((1).to_bytes(8, "little") + sc32(deferred)))
+
+
+@pytest.mark.gpu
+def test_hip_replays_the_references_blinding_whir_bytes(ctx_v1, oracle):
+    """the same replay through the C ABI, Merkle hints included: pk_to_evals, pk_eq_accumulate, pk_fe_axpy, pk_sumcheck_quadratic_round,
+    pk_fold_pairs, pk_fold_coeffs, pk_commit, pk_tree_open, pk_multipath_serialize, pk_eval_univariate, pk_eq_table and pk_dot regenerate
+    bytes 2848..47228 of the reference prover's own proof -- everything but the two nonces -- bit for bit (Skyscraper v1)."""
+    import pyref as pr
+    from provekit_amd import sumcheck as sc
+    from provekit_amd.whir import commit_batch, multipath_serialize
+
+    ctx, I = ctx_v1, _blinding_whir_inputs()
+    m = lambda xs: mont(oracle, xs)
+    sc32 = lambda x: int(x).to_bytes(32, "little")
+    d_f0, d_f1 = ctx.upload(m(I["f0"])), ctx.upload(m(I["f1"]))
+    com0 = commit_batch(ctx, [d_f0, d_f1], 8, 1, 4)
+    d_c = ctx.upload(m(I["f0"]))
+    sc.axpy(ctx, d_c, m([I["beta"]])[0], d_f1, 256)
+    d_p = ctx.upload(ctx.download_fe(d_c, 256))
+    sc.to_evals(ctx, d_p, 8)
+    d_w = ctx.alloc_fe(256)
+    sc.eq_accumulate(ctx, d_w, 8, m(pr.expand_from_univariate(I["z0"], 8)), m([1]), overwrite=True)
+    sc.axpy(ctx, d_w, m([I["gamma0"]])[0], ctx.upload(m(I["table"])), 256)
+
+    def group(d_p, d_w, length, rs):
+        out, fold = b"", None
+        for r in rs:
+            if fold is None:
+                ev = sc.sumcheck_quadratic_round(ctx, d_p, d_w, length)
+            else:
+                d_p2, d_w2 = ctx.alloc_fe(length // 2), ctx.alloc_fe(length // 2)
+                ev = sc.sumcheck_quadratic_round(ctx, d_p, d_w, length, fold, d_p2, d_w2)
+                d_p, d_w, length = d_p2, d_w2, length // 2
+            out += b"".join(sc32(x) for x in canon_ints(oracle, ev))
+            fold = m([r])[0]
+        d_p2, d_w2 = ctx.alloc_fe(max(length // 2, 1)), ctx.alloc_fe(max(length // 2, 1))
+        sc.fold_pairs(ctx, d_p, length, fold, d_p2)
+        sc.fold_pairs(ctx, d_w, length, fold, d_w2)
+        return out, d_p2, d_w2, length // 2
+
+    got, d_p, d_w, length = group(d_p, d_w, 256, I["r03"])
+    d_fp = sc.fold_coeffs(ctx, d_c, 8, m(I["r03"]))
+    com1 = commit_batch(ctx, [d_fp], 4, 4, 4)
+    got += com1.root + sc32(canon_ints(oracle, sc.eval_univariate(ctx, d_fp, 16, m([I["z1"]])[0])[None])[0])
+    want_a, want_b, want_c = _expected_sections(I["prefix"])
+    assert got == want_a
+    lv, sib, paths = com0.open(np.arange(32, dtype=np.uint64), canonical_leaves=True)
+    got_b = _frame_hint(_stir_answers_payload([oracle.limbs_to_ints(l) for l in lv])) + _frame_hint(multipath_serialize(list(range(32)), sib, paths))
+    exp_gen = pow(pr.root_of_unity(9), 16, P)
+    pts = [I["z1"]] + [pow(exp_gen, i, P) for i in range(32)]
+    scales = [pow(I["gamma1"], j, P) for j in range(33)]
+    sc.eq_accumulate(ctx, d_w, 4, np.concatenate([m(pr.expand_from_univariate(pt, 4)) for pt in pts]), m(scales), overwrite=False)
+    evs, d_p, d_w, length = group(d_p, d_w, 16, I["r47"])
+    d_fin = sc.fold_coeffs(ctx, d_fp, 4, m(I["r47"]))
+    final = canon_ints(oracle, ctx.download_fe(d_fin, 1))
+    assert canon_ints(oracle, ctx.download_fe(d_p, 1)) == final
+    got_b += evs + sc32(final[0])
+    assert got_b == want_b
+    idx1 = [0, 1, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14]
+    lv, sib, paths = com1.open(np.array(idx1, dtype=np.uint64), canonical_leaves=True)
+    rev = (I["r03"] + I["r47"])[::-1]
+    d_eq = sc.calculate_evaluations_over_boolean_hypercube_for_eq(ctx, m(rev))
+    deferred = canon_ints(oracle, sc.weighted_sum(ctx, ctx.upload(m(I["table"])), d_eq, 256)[None])[0]
+    got_c = (_frame_hint(_stir_answers_payload([oracle.limbs_to_ints(l) for l in lv])) + _frame_hint(multipath_serialize(idx1, sib, paths))
+             + _frame_hint((1).to_bytes(8, "little") + sc32(deferred)))
+    assert got_c == want_c
+    com0.close()
+    com1.close()
