@@ -4,9 +4,12 @@ prover produced.  CPU half: the C oracle reproduces them.  GPU half (marked gpu)
 the C ABI.  Hash version 1 throughout (the fixture predates the Skyscraper v2 switch)."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))  # pyref, verifier
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FX = json.load(open(os.path.join(G, "fixture_whir.json")))
