@@ -548,6 +548,8 @@ def main():
         srank = 0 if args.sharded else rank  # the ranks of a sharded prover hold the SAME statement and witness
         r1cs_w, mats, interner, nc, n_in = synth_r1cs(c, m_0, n_wit, seed=1234 + srank)
         d_z, z_host = satisfying_witness(c, r1cs_w, n_wit, nc, n_in, 99 + srank + 1000 * w)
+        if os.environ.get("PK_BENCH_LATENCY_ALL") == "1":  # experiment: every prover in latency mode while they share the chip
+            c.set_latency_mode(True)
         workers.append((c, WhirR1CSScheme(c, r1cs_w, m, m_0, cfg_w, cfg_b), d_z, r1cs_w, z_host))
     ctx = workers[0][0]
 

@@ -41,6 +41,10 @@ workers = []
 for _ in range(T):
     c = provekit_amd.Context(0)
     r = R1CS(c, *(SparseMatrix(nc, nw, *t) for t in mats), interner)
+    # PK_STRESS_LATENCY=1: every odd prover in latency mode (gated kernels + side streams of 8 provers among 8 plain ones): not a configuration
+    # to run for speed -- a check that the gates cannot deadlock or corrupt anything when the chip is shared
+    if os.environ.get("PK_STRESS_LATENCY") == "1" and len(workers) % 2 == 1:
+        c.set_latency_mode(True)
     workers.append((c, r, WhirR1CSScheme(c, r, m, m_0, cfg_w, cfg_b), c.upload(z)))
 out = [None] * T
 
