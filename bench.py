@@ -657,7 +657,45 @@ def main():
         except Exception as e:  # e.g. a GPU with less memory
             return {"error": str(e)[:200]}
 
-    commit_fig = run_commit_probe()  # before anything else allocates and releases large buffers in this process
+    # (a) PCIe-inclusive rate: the same waves with the witness uploaded before every proof.  On one GPU it runs LAST, so that it cannot disturb
+    # the figures above (see --size-class-probe: probes run back to back in one process were measured to depress whichever comes later)
+    def run_h2d_probe():
+        if args.h2d or args.sharded or args.no_h2d_probe:
+            return None
+        try:
+            args.h2d = True
+            run_proofs(200000, 2 * conc)
+            barrier()
+            t1 = time.perf_counter()
+            run_proofs(300000, 8 * conc)
+            barrier()
+            return world * 8 * conc / max_over_ranks(time.perf_counter() - t1, dist, None if one_gpu else f"cuda:{local_rank}")
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] h2d probe failed: {e}", file=sys.stderr)
+            return None
+        finally:
+            args.h2d = False
+
+    # Order.  One GPU: the commit probe first (before anything else allocates and releases large buffers in this process), the h2d probe last.
+    # Several ranks: every figure that needs only torch's collectives first, then the sharded commit -- the one step of this file that goes
+    # through the library's own RCCL communicator -- under a watchdog: if it does not come back, the line is printed without it and the
+    # process leaves without another collective, so a stuck communicator can cost the run that one figure and nothing else.
+    h2d_rate, hung = None, False
+    if world > 1:
+        h2d_rate = run_h2d_probe()
+        time.sleep(2.0)  # idle seconds after 16 provers at the power limit (see --size-class-probe)
+        box = {}
+        def guarded():
+            torch.cuda.set_device(local_rank)  # the current device is per thread
+            box.update(fig=run_commit_probe())
+
+        th = threading.Thread(target=guarded, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("PK_BENCH_COMMIT_LIMIT_S", "240")))
+        hung = th.is_alive()
+        commit_fig = {"error": "the sharded commit did not return within its limit; skipped"} if hung else box.get("fig")
+    else:
+        commit_fig = run_commit_probe()
     # (c) the other BASELINE size classes (configs[2] m = 23, configs[3] m = 25), rank 0's GPU only
     size_figs = {}
     if rank == 0 and m == 21 and not args.sharded and args.size_classes:
@@ -673,24 +711,9 @@ def main():
                 size_figs[str(mm)] = json.loads(lines[-1]) if out.returncode == 0 and lines else {"error": (out.stderr or "no output")[-200:]}
             except Exception as e:  # noqa: BLE001
                 size_figs[str(mm)] = {"error": str(e)[:200]}
-    # (a) PCIe-inclusive rate: the same waves with the witness uploaded before every proof.  LAST, so that it cannot disturb the figures above
-    # (see --size-class-probe: probes run back to back in one process were measured to depress whichever comes later)
-    h2d_rate = None
-    if not args.h2d and not args.sharded and not args.no_h2d_probe:
-        try:
-            args.h2d = True
-            run_proofs(200000, 2 * conc)
-            barrier()
-            t1 = time.perf_counter()
-            run_proofs(300000, 8 * conc)
-            barrier()
-            h2d_rate = world * 8 * conc / max_over_ranks(time.perf_counter() - t1, dist, None if one_gpu else f"cuda:{local_rank}")
-        except Exception as e:  # noqa: BLE001
-            h2d_rate = None
-            print(f"[bench] h2d probe failed: {e}", file=sys.stderr)
-        finally:
-            args.h2d = False
-    if dist is not None:
+    if world == 1:
+        h2d_rate = run_h2d_probe()
+    if dist is not None and not hung:
         dist.barrier()
 
     if rank == 0:
@@ -813,6 +836,9 @@ def main():
                           "openings (Merkle paths + leaf gathers) and the transcript are omitted, so the real CPU figure is lower still",
             }
         emit(line)
+    if hung:
+        sys.stderr.flush()
+        os._exit(0)  # a thread of this process is still inside the stuck collective
     if dist is not None:
         dist.destroy_process_group()
 
