@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the bench workload: witness resident vs uploaded before every proof from pageable vs pinned host memory
-(16 provers, dynamic hand-out as in bench.py).  GPU box.  usage: h2d_probe.py [waves]"""
+(16 provers, dynamic hand-out as in bench.py); "sleep" = the prover thread idle for 1.6 ms instead, nothing copied.  GPU box.  usage: h2d_probe.py [waves]"""
 import itertools, json, os, sys, threading, time
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,6 +39,8 @@ def run(count, mode, first_seed):
                 c.upload_into(d_z.ptr, z_host)
             elif mode == "pinned":
                 c._check(provekit_amd._lib.lib.pk_memcpy_h2d(c.handle, d_z.ptr, pinned.data_ptr(), pinned.numel() * 8))
+            elif mode == "sleep":  # the prover thread idle for about as long as an upload takes, nothing copied
+                time.sleep(0.0016)
             prover.prove_nocopy(d_z, seed=first_seed + i)
 
     ths = [threading.Thread(target=work, args=(w,)) for w in range(conc)]
@@ -52,7 +54,7 @@ def run(count, mode, first_seed):
 
 
 run(2 * conc, "resident", 0)
-res = {"resident": [], "pageable": [], "pinned": []}
+res = {"resident": [], "pageable": [], "pinned": [], "sleep": []}
 for rep in range(3):
     for mode in res:
         run(conc, mode, 1000)
