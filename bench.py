@@ -240,13 +240,15 @@ def cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg):
     return dt, o.L.pko_num_threads()
 
 
-def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3, world=1, dist=None, one_gpu=False):
+def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3, world=1, dist=None, one_gpu=False, takes_part=True, transport=None):
     """BASELINE configs[4] as a secondary figure of the default line: one batch-2 WHIR commit of 2^26 seeded coefficients
     (RS-encode of 2 x 16 NTTs of 2^23 + 2^23 leaf hashes of width 32 + the tree), buffers allocated once.  At world 1 it is
     timed with hipEvents on the context's stream; at world > 1 `ctx` has joined the run's device set, the commit is SHARDED
     by leaf index behind the C ABI (rank g encodes and hashes the rows i = g mod G, one all-gather of leaf digests) and the
     clock is the launcher contract's: barrier, wall time, max over ranks -- so one `--gpus N` run yields both the weak-scaling
-    proofs/s and north_star's strong-scaling commit curve.  Algorithmic bytes as BASELINE.md 4."""
+    proofs/s and north_star's strong-scaling commit curve.  `world` here is the number of ranks the commit is sharded over (G, a
+    power of two <= the run's world size); ranks outside the group (`takes_part` False: `ctx` is None) only keep the barriers
+    and the max-over-ranks clock company.  Algorithmic bytes as BASELINE.md 4."""
     import ctypes as C
 
     from provekit_amd._lib import lib
@@ -254,15 +256,16 @@ def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3, world=1, dist=None, 
 
     n, rows, width = 1 << n_vars, 1 << (n_vars + 1 - 4), 32
     polys = []
-    for b in range(2):
-        t = torch.randint(0, 2**62, (n, 4), dtype=torch.int64, device=f"cuda:{local_rank}", generator=torch.Generator(device=f"cuda:{local_rank}").manual_seed(17 + b))
-        t[:, 3] &= (1 << 60) - 1
-        polys.append(t)
-    torch.cuda.synchronize()
-    ptrs = (C.c_void_p * 2)(*[int(t.data_ptr()) for t in polys])
-    szs = [C.c_size_t() for _ in range(3)]
-    ctx._check(lib.pk_commit_sizes(ctx.handle, 2, n_vars, 1, 4, *[C.byref(x) for x in szs]))
-    leaves, nodes, scratch = (ctx.alloc_fe(x.value) for x in szs)
+    if takes_part:
+        for b in range(2):
+            t = torch.randint(0, 2**62, (n, 4), dtype=torch.int64, device=f"cuda:{local_rank}", generator=torch.Generator(device=f"cuda:{local_rank}").manual_seed(17 + b))
+            t[:, 3] &= (1 << 60) - 1
+            polys.append(t)
+        torch.cuda.synchronize()
+        ptrs = (C.c_void_p * 2)(*[int(t.data_ptr()) for t in polys])
+        szs = [C.c_size_t() for _ in range(3)]
+        ctx._check(lib.pk_commit_sizes(ctx.handle, 2, n_vars, 1, 4, *[C.byref(x) for x in szs]))
+        leaves, nodes, scratch = (ctx.alloc_fe(x.value) for x in szs)
     root_buf = (C.c_uint8 * 32)()
 
     def barrier():
@@ -273,10 +276,11 @@ def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3, world=1, dist=None, 
 
     ms = []
     for i in range(reps + 1):
-        if world > 1:
+        if dist is not None:
             barrier()
             t0 = time.perf_counter()
-            ctx._check(lib.pk_commit_into(ctx.handle, ptrs, 2, n_vars, 1, 4, leaves.ptr, nodes.ptr, scratch.ptr, root_buf, None))
+            if takes_part:
+                ctx._check(lib.pk_commit_into(ctx.handle, ptrs, 2, n_vars, 1, 4, leaves.ptr, nodes.ptr, scratch.ptr, root_buf, None))
             barrier()
             t = 1e3 * max_over_ranks(time.perf_counter() - t0, dist, None if one_gpu else f"cuda:{local_rank}")
         else:
@@ -285,14 +289,92 @@ def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3, world=1, dist=None, 
             t = ctx.timer_stop()
         if i:
             ms.append(t)
+    if takes_part:
+        for b in (leaves, nodes, scratch):
+            b.free()
+    del polys
     root = bytes(root_buf).hex()
     alg = 32 * 2 * n + 32 * 2 * 2 * n + 64 * rows
     best = min(ms)
-    how = "one GPU" if world == 1 else (f"sharded by leaf index over {world} ranks, " + ("host-transport (gloo) all-gather, single-GPU development mode" if one_gpu
-                                                                                      else "RCCL all-gather of leaf digests over xGMI") + "; wall clock, max over ranks")
+    how = ("one GPU" + ("" if dist is None else "; wall clock, max over ranks")) if world == 1 else (
+        f"sharded by leaf index over {world} ranks, " + ("host-transport (gloo) all-gather, single-GPU development mode" if one_gpu
+                                                        else "RCCL all-gather of leaf digests over xGMI") + "; wall clock, max over ranks")
     return {"workload": f"batch-2 WHIR commit of 2^{n_vars} coefficients (rate 1/2, fold 16): {rows * 31 + rows - 1} compressions, 32 NTTs of 2^{n_vars - 3}; {how}",
             "n_gpus": world, "scaling": "strong", "ms_per_commit": best, "commits_per_s": 1e3 / best, "algorithmic_GB": alg / 1e9,
-            "achieved_GBps": alg / (best * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (best * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), "root": root}
+            "achieved_GBps": alg / (best * 1e-3) / 1e9, "frac_of_hbm_peak": alg / (best * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), "root": root,
+            "transport": transport or ("none" if world == 1 else ("host" if one_gpu else "rccl"))}
+
+
+def join_subgroup(ctx, rank, G, dist, one_gpu, groups):
+    """make `ctx` rank `rank` of the first G ranks of the run (every rank of the run calls this; ranks >= G pass ctx = None).
+    RCCL: rank 0's unique id goes round through the launcher's process group.  Development mode (every rank on GPU 0): the
+    library's host transport over a gloo subgroup.  Returns the object to keep alive."""
+    from provekit_amd.device_set import HostTransport
+    from provekit_amd._lib import lib
+
+    if one_gpu:
+        if G not in groups:
+            groups[G] = dist.new_group(ranks=list(range(G)), backend="gloo")  # collective over the whole run
+        if ctx is None:
+            return None
+        ht = HostTransport(dist, groups[G])
+        ctx._check(lib.pk_comm_init_host(ctx.handle, G, rank, ht.callback, None))
+        return ht
+    import provekit_amd
+
+    box = [provekit_amd.Context.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    if ctx is not None:
+        ctx.comm_init_rank(box[0], G, rank)
+    return None
+
+
+def rccl_probe(provekit_amd, torch, rank, local_rank, world, dist, one_gpu, groups, mib=32, reps=5):
+    """Evidence that the library's OWN communicator (not torch's) spans the ranks of this run: a context joins the device set
+    exactly as the sharded commit's will, reports what pk_comm_info says, and times an all-gather of `mib` MiB per rank (the
+    2^26 commit's digest block per GPU at 8 ranks) with hipEvents on the context's stream.  World 1: the RCCL the library would
+    use, nothing to gather."""
+    import ctypes as C
+
+    from provekit_amd._lib import lib
+
+    out = {"world": 1, "transport": "none"}
+    try:
+        v, path = provekit_amd.Context.rccl_version()
+        out["version"], out["library"] = v, path
+    except Exception as e:  # noqa: BLE001
+        out["version"], out["library"] = None, f"not loadable: {e}"[:120]
+    if world == 1:
+        return out
+    ctx = provekit_amd.Context(local_rank)
+    keep = join_subgroup(ctx, rank, world, dist, one_gpu, groups)  # noqa: F841
+    r, w, kind = ctx.comm_info()
+    out.update(world=w, rank=r, transport={1: "local", 2: "rccl", 3: "host"}.get(kind, str(kind)))
+    nbytes = mib << 20
+    send, recv = ctx.alloc(nbytes), ctx.alloc(nbytes * world)
+    torch.cuda.synchronize()
+    dist.barrier()
+    ts = []
+    for i in range(reps + 1):
+        ctx.timer_start()
+        ctx._check(lib.pk_comm_all_gather(ctx.handle, send.ptr, recv.ptr, nbytes))
+        t = ctx.timer_stop()
+        if i:
+            ts.append(t)
+    # every rank's block arrived: a checksum word written by each rank before one more (small) gather
+    tag = np.full((8,), 0x5EED0000 + rank, dtype=np.uint64)
+    ctx.upload_into(send.ptr, tag)
+    ctx._check(lib.pk_comm_all_gather(ctx.handle, send.ptr, recv.ptr, 64))
+    got = ctx.download(recv, (world, 8))
+    out["ranks_seen"] = sorted(int(x) - 0x5EED0000 for x in got[:, 0])
+    us = 1e3 * sorted(ts)[len(ts) // 2]
+    out[f"allgather_{mib}MiB_us"] = us
+    out["allgather_GBps_per_rank_received"] = nbytes * (world - 1) / (us * 1e-6) / 1e9
+    send.free()
+    recv.free()
+    ctx.comm_destroy()
+    ctx.close()
+    return out
 
 
 def size_class_probe(provekit_amd, torch, local_rank, m, proofs_per_prover=3):
@@ -339,7 +421,9 @@ def size_class_probe(provekit_amd, torch, local_rank, m, proofs_per_prover=3):
         t1 = time.perf_counter()
         provers[0].prove_nocopy(wit[0], seed=77 + i)
         singles.append(time.perf_counter() - t1)
-    out = {"m": m, "m_0": m_0, "constraints": nc, "witnesses": n_wit, "queries": list(cfg_w.num_queries) + [cfg_w.final_queries],
+    out = {"m": m, "m_0": m_0, "schedule": "derived by pk_whir_config_derive (a restatement of WhirConfig::new pinned against the reference at n = 21 and n = 8 only: "
+                                       "queries / pow_bits at this size are an extrapolation)",
+           "constraints": nc, "witnesses": n_wit, "queries": list(cfg_w.num_queries) + [cfg_w.final_queries],
            "pow_bits": list(cfg_w.pow_bits) + [cfg_w.final_pow_bits], "provers": conc, "proofs_timed": conc * proofs_per_prover,
            "proofs_per_s": conc * proofs_per_prover / dt, "single_proof_ms": 1e3 * sorted(singles)[1]}
     for p in provers:
@@ -435,6 +519,49 @@ def emit_commit_line(args, world, m, dt, prof, root_hex, how):
     })
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks of this file under torch.distributed.run on this
+    node (one process per GPU, rendezvous on 127.0.0.1 at a free port) and pass rank 0's JSON line through.  N is clamped to
+    the GPUs the library sees (pk_device_count) unless PK_BENCH_ONE_GPU=1 (development aid: every rank on GPU 0 over gloo)."""
+    import ctypes as C
+    import socket
+    import subprocess
+
+    n = args.gpus
+    if os.environ.get("PK_BENCH_ONE_GPU") != "1":
+        from provekit_amd._lib import lib
+
+        have = C.c_int(0)
+        lib.pk_device_count(C.byref(have))
+        if have.value < n:
+            print(f"[bench] --gpus {n} asked for, {have.value} GPU(s) visible: running on {max(have.value, 1)}", file=sys.stderr)
+            n = max(have.value, 1)
+    argv = [a for a in sys.argv[1:]]
+    for i, a in enumerate(argv):  # rewrite --gpus to what will really run
+        if a == "--gpus":
+            argv[i + 1] = str(n)
+        elif a.startswith("--gpus="):
+            argv[i] = f"--gpus={n}"
+    for i, a in enumerate(argv):  # the launcher's own parser rejects --m as an ambiguous abbreviation
+        if a == "--m":
+            argv[i] = "--log2-size"
+    if n <= 1:
+        os.environ["WORLD_SIZE"] = "1"
+        sys.argv = [sys.argv[0]] + argv
+        return main()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, PK_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    rc = subprocess.call(cmd, env=env)
+    if rc:
+        raise SystemExit(rc)
+
+
 _STDOUT_FD = None
 
 
@@ -482,6 +609,8 @@ def main():
                     help="upload the witness from (pageable) host memory before every proof: the PCIe-inclusive rate DESIGN.md quotes; "
                          "never the judged line (inputs are resident when the clock starts)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     # stdout carries exactly one JSON line: libraries that print banners there (RCCL's version block at communicator
     # creation) are sent to stderr for the duration of the run
@@ -585,10 +714,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The library's own communicator, before anything is timed (under a watchdog: a communicator that cannot form costs the run its
+    # collective figures and nothing else)
+    groups, hung = {}, False
+    rccl_fig = None
+    if not args.sharded:
+        box = {}
+
+        def probe():
+            torch.cuda.set_device(local_rank)  # the current device is per thread
+            try:
+                box.update(fig=rccl_probe(provekit_amd, torch, rank, local_rank, world, dist, one_gpu, groups))
+            except Exception as e:  # noqa: BLE001
+                box.update(fig={"world": world, "error": str(e)[:300]})
+
+        th = threading.Thread(target=probe, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("PK_BENCH_RCCL_LIMIT_S", "120")))
+        hung = th.is_alive()
+        rccl_fig = {"world": world, "error": "the library's communicator did not form / gather within its limit"} if hung else box.get("fig")
+    dev_for_flags = None if one_gpu else f"cuda:{local_rank}"
+    # the ranks must agree on what happens next (a rank that skips a collective the others enter would hang them): flags travel over the
+    # launcher's process group, which is torch's own communicator, not the library's
+    hung_any = max_over_ranks(1.0 if hung else 0.0, dist, dev_for_flags) > 0
+    comm_ok = not hung_any and not max_over_ranks(1.0 if (rccl_fig or {}).get("error") else 0.0, dist, dev_for_flags) > 0
+
     # one step = one wave of `conc` proofs (a batch of synthetic statements through the hot path), so any --steps the driver
     # passes measures the steady state of a full chip rather than a ragged tail
     run_proofs(100000, args.warmup * conc)
-    ctx.profile(True)
+    # hipEvent pairs around the launches of ONE of the `conc` provers (worker 0) during the timed region: the source of the
+    # *_under_load figures.  PK_BENCH_NO_TIMED_PROFILE=1 turns it off for an A/B (profiles/r05_timed_profile_ab.json: no
+    # measurable difference)
+    timed_profile = os.environ.get("PK_BENCH_NO_TIMED_PROFILE") != "1"
+    ctx.profile(timed_profile)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -598,6 +756,7 @@ def main():
     prof = ctx.profile_read()
     # untimed extra pass, one proof at a time on worker 0: isolated kernel durations for the roofline
     # (with several provers in flight the per-launch times above include interference from the other streams)
+    ctx.profile(True)
     ctx.profile_reset()
     iso_steps = 8
     iso_times = []
@@ -639,20 +798,39 @@ def main():
             peak_modmul = max(peak_modmul, r.value)
 
     # ---- secondary figures of the default line (each guarded: none may break the line) -----------------------------------
-    # (b) BASELINE configs[4]: the 2^26 commit -- on one GPU, or SHARDED over the ranks of the run (every rank takes part)
+    # (b) BASELINE configs[4]: the 2^26 commit -- on one GPU, and under several ranks SHARDED over the first G = 1, 2, 4, 8 <= N of them
+    # in the same invocation, so that one `--gpus N` run yields north_star's whole strong-scaling curve
     def run_commit_probe():
         if not (m == 21 and not args.sharded and not args.no_commit_probe):
             return None
         try:
-            cctx, keep = ctx, None
-            if world > 1:
-                cctx = provekit_amd.Context(local_rank)
-                keep = join_device_set(cctx, rank, world, dist, "host" if one_gpu else "rccl")  # noqa: F841 (kept alive)
-            fig = commit_probe(cctx, torch, local_rank, n_vars=args.commit_log2_size, world=world, dist=dist, one_gpu=one_gpu)
-            if world > 1:
-                cctx.comm_destroy()
-                cctx.close()
-            torch.cuda.empty_cache()
+            if world == 1:
+                fig = commit_probe(ctx, torch, local_rank, n_vars=args.commit_log2_size)
+                torch.cuda.empty_cache()
+                return fig
+            curve = {}
+            G = 1
+            while G <= world:
+                takes_part = rank < G
+                cctx = provekit_amd.Context(local_rank) if takes_part else None
+                keep = join_subgroup(cctx, rank, G, dist, one_gpu, groups) if G > 1 else None  # noqa: F841 (kept alive)
+                try:
+                    curve[str(G)] = commit_probe(cctx, torch, local_rank, n_vars=args.commit_log2_size, world=G, dist=dist, one_gpu=one_gpu,
+                                                 takes_part=takes_part)
+                finally:
+                    if takes_part:
+                        if G > 1:
+                            cctx.comm_destroy()
+                        cctx.close()
+                    torch.cuda.empty_cache()
+                G *= 2
+            top = str(max(int(k) for k in curve))
+            fig = dict(curve[top])
+            base = curve["1"]["ms_per_commit"]
+            fig["curve"] = {k: {"n_gpus": v["n_gpus"], "ms_per_commit": v["ms_per_commit"], "speedup_vs_1": base / v["ms_per_commit"],
+                                "achieved_GBps": v["achieved_GBps"], "frac_of_hbm_peak": v["frac_of_hbm_peak"], "transport": v["transport"],
+                                "root": v["root"]} for k, v in curve.items()}
+            fig["roots_agree"] = len({v["root"] for v in curve.values()}) == 1
             return fig
         except Exception as e:  # e.g. a GPU with less memory
             return {"error": str(e)[:200]}
@@ -680,8 +858,11 @@ def main():
     # Several ranks: every figure that needs only torch's collectives first, then the sharded commit -- the one step of this file that goes
     # through the library's own RCCL communicator -- under a watchdog: if it does not come back, the line is printed without it and the
     # process leaves without another collective, so a stuck communicator can cost the run that one figure and nothing else.
-    h2d_rate, hung = None, False
-    if world > 1:
+    h2d_rate = None
+    if world > 1 and not comm_ok:
+        h2d_rate = run_h2d_probe()  # torch's collectives only
+        commit_fig = {"error": "skipped: the library's communicator did not pass its probe on every rank (see `rccl`)"}
+    elif world > 1:
         h2d_rate = run_h2d_probe()
         time.sleep(2.0)  # idle seconds after 16 provers at the power limit (see --size-class-probe)
         box = {}
@@ -693,7 +874,8 @@ def main():
         th.start()
         th.join(float(os.environ.get("PK_BENCH_COMMIT_LIMIT_S", "240")))
         hung = th.is_alive()
-        commit_fig = {"error": "the sharded commit did not return within its limit; skipped"} if hung else box.get("fig")
+        hung_any = max_over_ranks(1.0 if hung else 0.0, dist, dev_for_flags) > 0
+        commit_fig = {"error": "the sharded commit did not return within its limit on some rank; skipped"} if hung_any else box.get("fig")
     else:
         commit_fig = run_commit_probe()
     # (c) the other BASELINE size classes (configs[2] m = 23, configs[3] m = 25), rank 0's GPU only
@@ -713,7 +895,7 @@ def main():
                 size_figs[str(mm)] = {"error": str(e)[:200]}
     if world == 1:
         h2d_rate = run_h2d_probe()
-    if dist is not None and not hung:
+    if dist is not None and not hung_any:
         dist.barrier()
 
     if rank == 0:
@@ -765,6 +947,9 @@ def main():
                             f"queries {cfg_w.num_queries}/{cfg_w.final_queries}, pow_bits {cfg_w.pow_bits}/{cfg_w.final_pow_bits} (WhirConfig::new derivation, security 128, "
                             f"ConjectureList), blinding WHIR n={cfg_b.n_vars} queries {cfg_b.num_queries}/{cfg_b.final_queries}, Skyscraper-sponge transcript, ChaCha12 masks",
                 "proofs_per_step": conc * (1 if args.sharded else world),
+                "profiling_in_timed_region": (f"hipEvent pairs around the launches of 1 of the {conc} provers per GPU" if timed_profile else False),
+                "launcher": ("bench.py --gpus N started its own ranks (torch.distributed.run, 127.0.0.1)" if os.environ.get("PK_BENCH_SELF_LAUNCHED") else
+                             ("torch.distributed.run" if dist is not None else "single process")),
                 "parallelism": (f"one step = one proof, sharded over {world} GPU(s): every commit of >= 64 rows per rank split by leaf index, "
                                 "RCCL all-gather of leaf digests + all-reduce of opened rows behind the C ABI; the rest of the proof is "
                                 "replicated on every rank") if args.sharded else f"one step = one wave of {conc} proofs per GPU; {world} GPU(s) x {conc} concurrent provers per GPU, work handed out "
@@ -820,6 +1005,8 @@ def main():
             line["h2d_inclusive_proofs_per_s"] = h2d_rate
             line["h2d_note"] = (f"same workload, {conc} provers, the 32 x {n_wit} B witness uploaded from pageable host memory before every proof; "
                                 "never `value` (inputs are resident when the clock starts)")
+        if rccl_fig is not None:
+            line["rccl"] = rccl_fig
         if commit_fig is not None:
             line["commit_2p26" if args.commit_log2_size == 26 else f"commit_2p{args.commit_log2_size}"] = commit_fig
         if size_figs:
@@ -836,9 +1023,9 @@ def main():
                           "openings (Merkle paths + leaf gathers) and the transcript are omitted, so the real CPU figure is lower still",
             }
         emit(line)
-    if hung:
+    if hung_any:
         sys.stderr.flush()
-        os._exit(0)  # a thread of this process is still inside the stuck collective
+        os._exit(0)  # a thread of this process (or of a peer) is still inside the stuck collective: no orderly teardown
     if dist is not None:
         dist.destroy_process_group()
 

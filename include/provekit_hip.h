@@ -102,7 +102,11 @@ int pk_ctx_set_hash_version(pk_ctx *ctx, int version);
  *                       ranks.  Slower than RCCL (two PCIe hops) but works wherever a host collective does -- several processes
  *                       on one GPU included, which is how the multi-process launch is tested on a single-GPU box.
  * PK_ERR_RCCL: librccl could not be loaded (it is resolved with dlopen at first use), one of its calls failed, a host
- * transport's callback returned non-zero, or another rank of the set failed (the communicator is then unusable). */
+ * transport's callback returned non-zero, or another rank of the set failed (the communicator is then unusable).
+ * A rank whose sharded call fails before it reaches a collective aborts its communicator so that its peers do not wait for
+ * it: the in-process group wakes them with PK_ERR_RCCL, an RCCL communicator is torn down with ncclCommAbort (the peers'
+ * pending collective then fails through RCCL's asynchronous error path), a host transport's peers are the caller's to time
+ * out.  After any of these: pk_comm_destroy on every rank and join again. */
 #define PK_MAX_RANKS 16
 #define PK_COMM_ID_BYTES 128
 #define PK_COMM_NONE 0
@@ -121,6 +125,10 @@ int pk_comm_unique_id(uint8_t id[PK_COMM_ID_BYTES]);
 int pk_comm_init_rank(pk_ctx *ctx, const uint8_t id[PK_COMM_ID_BYTES], int world, int rank);
 int pk_comm_init_local(pk_ctx *const *ctxs, int n);
 int pk_comm_info(const pk_ctx *ctx, int *rank, int *world, int *kind);
+/* which RCCL the library resolved (dlopen at first use; the environment variable PK_RCCL_LIB names one outright, otherwise
+ * the copy already in the process, then librccl.so.1): ncclGetVersion's code (e.g. 22703; 0 if the library lacks the call)
+ * and the name it was opened by.  PK_ERR_RCCL: none could be loaded. */
+int pk_comm_rccl_version(int *version, char *path, size_t cap);
 int pk_comm_destroy(pk_ctx *ctx);
 /* the two collectives, on the context's stream (exposed for tests and for callers that shard their own steps):
  * d_recv[r*bytes_per_rank ...] = rank r's d_send;  d_buf[i] = sum over ranks of d_buf[i] (wrapping u64) */

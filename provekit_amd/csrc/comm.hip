@@ -36,23 +36,36 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
+    ncclResult_t (*GetVersion)(int*) = nullptr;       // optional
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    std::string error;
+    std::string error, path;
 };
 
 RcclApi* rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
-        // a copy already in the process (e.g. the one a PyTorch wheel bundles) is preferred: one RCCL per process
-        const char* names[] = {"librccl.so.1", "librccl.so"};
-        for (int pass = 0; pass < 2 && !api.handle; pass++)
-            for (const char* n : names) {
-                api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
-                if (api.handle) break;
-            }
+        // PK_RCCL_LIB names the library outright (a site build of RCCL; the test-suite's in-process stand-in,
+        // tests/stub_rccl).  Otherwise a copy already in the process (e.g. the one a PyTorch wheel bundles) is preferred: one
+        // RCCL per process
+        const char* forced = getenv("PK_RCCL_LIB");
+        if (forced && *forced) {
+            api.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) api.path = forced;
+        } else {
+            const char* names[] = {"librccl.so.1", "librccl.so"};
+            for (int pass = 0; pass < 2 && !api.handle; pass++)
+                for (const char* n : names) {
+                    api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                    if (api.handle) {
+                        api.path = n;
+                        break;
+                    }
+                }
+        }
         if (!api.handle) {
             const char* e = dlerror();  // one call: dlerror() clears the message it returns
             api.error = std::string("librccl not found: ") + (e ? e : "dlopen failed");
@@ -69,6 +82,8 @@ RcclApi* rccl() {
         PK_SYM(AllReduce, "ncclAllReduce");
         PK_SYM(GetErrorString, "ncclGetErrorString");
 #undef PK_SYM
+        api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.handle, "ncclCommAbort"));
+        api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(api.handle, "ncclGetVersion"));
     });
     return &api;
 }
@@ -195,6 +210,7 @@ int comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes)
     }
     ProfScope prof(ctx, "comm_all_gather");
     if (c->kind == PK_COMM_RCCL) {
+        if (c->failed || !c->nccl) return set_err(ctx, PK_ERR_RCCL, "the communicator was aborted by an earlier failure of this rank");
         PK_RCCL(ctx, rccl()->AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, ctx->stream));
         return PK_OK;
     }
@@ -252,8 +268,12 @@ int comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes)
     return PK_OK;
 }
 
-// A rank that fails BEFORE reaching a collective (e.g. its encode ran out of memory) calls this so that the ranks already
-// waiting in the collective return an error instead of blocking forever.  RCCL: nothing to do here (its own abort / timeout).
+// A rank that fails BEFORE reaching a collective (e.g. its encode ran out of memory) calls comm_abort so that the ranks already
+// waiting in the collective return an error instead of blocking forever.  LOCAL: the group's sticky flag wakes them.  RCCL:
+// ncclCommAbort tears this rank's communicator down, which makes the peers' pending and later collectives on it fail
+// (asynchronous error) instead of waiting for a rank that will not come; the communicator is unusable afterwards on every
+// rank (pk_comm_destroy + a fresh pk_comm_init_rank to continue).  HOST: this rank fails fast, its peers are the caller's
+// transport's to time out.
 // pk_prove brackets itself with these; no-ops unless the context's in-process group was created with the turnstile on
 void comm_turn_begin(pk_ctx* ctx) {
     pk_comm* c = ctx->comm;
@@ -275,6 +295,13 @@ void comm_abort(pk_ctx* ctx) {
     if (!c) return;
     if (c->kind == PK_COMM_LOCAL && c->grp) c->grp->abort();
     if (c->kind == PK_COMM_HOST) c->failed = true;  // this rank's later collectives fail fast; its peers are the caller's transport's to time out
+    if (c->kind == PK_COMM_RCCL && !c->failed) {
+        c->failed = true;
+        if (c->nccl && rccl()->CommAbort) {
+            (void)rccl()->CommAbort(c->nccl);  // frees the communicator
+            c->nccl = nullptr;
+        }
+    }
 }
 
 int comm_all_reduce_sum_u64(pk_ctx* ctx, uint64_t* d_buf, size_t count) {
@@ -282,6 +309,7 @@ int comm_all_reduce_sum_u64(pk_ctx* ctx, uint64_t* d_buf, size_t count) {
     if (!c || !count) return PK_OK;
     ProfScope prof(ctx, "comm_all_reduce");
     if (c->kind == PK_COMM_RCCL) {
+        if (c->failed || !c->nccl) return set_err(ctx, PK_ERR_RCCL, "the communicator was aborted by an earlier failure of this rank");
         PK_RCCL(ctx, rccl()->AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, c->nccl, ctx->stream));
         return PK_OK;
     }
@@ -453,7 +481,10 @@ int pk_ctx_create_set(const int* devices, int n, pk_ctx** out) {
         for (int j = 0; j < i; j++) distinct = distinct && devices[i] != devices[j];
     }
     if (!rc && n > 1) {
-        if (!distinct) {
+        // PK_RCCL_SAME_DEVICE=1 (test-suite, together with PK_RCCL_LIB = the in-process stand-in): take the RCCL branch even
+        // for a repeated device -- real RCCL refuses two ranks on one GPU
+        const char* same_ok = getenv("PK_RCCL_SAME_DEVICE");
+        if (!distinct && !(same_ok && same_ok[0] == '1')) {
             rc = pk_comm_init_local(out, n);  // several ranks on one device: RCCL cannot, the in-process transport can
         } else {
             RcclApi* a = rccl();
@@ -491,6 +522,17 @@ int pk_ctx_create_set(const int* devices, int n, pk_ctx** out) {
             }
     }
     return rc;
+}
+
+int pk_comm_rccl_version(int* version, char* path, size_t cap) {
+    RcclApi* a = rccl();
+    if (!a->error.empty()) return PK_ERR_RCCL;
+    if (version) {
+        *version = 0;
+        if (a->GetVersion && a->GetVersion(version) != ncclSuccess) return PK_ERR_RCCL;
+    }
+    if (path && cap) snprintf(path, cap, "%s", a->path.c_str());
+    return PK_OK;
 }
 
 int pk_comm_info(const pk_ctx* ctx, int* rank, int* world, int* kind) {

@@ -100,6 +100,15 @@ class Context:
     def comm_destroy(self):
         self._check(lib.pk_comm_destroy(self.handle))
 
+    @staticmethod
+    def rccl_version():
+        """(ncclGetVersion code, name the library was opened by) of the RCCL behind the "rccl" transport (pk_comm_rccl_version)"""
+        v, path = C.c_int(), C.create_string_buffer(512)
+        rc = lib.pk_comm_rccl_version(C.byref(v), path, 512)
+        if rc != 0:
+            raise ProveKitHipError(rc, "pk_comm_rccl_version failed (librccl not loadable?)")
+        return v.value, path.value.decode()
+
     def __del__(self):
         try:
             self.close()

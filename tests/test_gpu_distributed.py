@@ -100,6 +100,11 @@ def _check_multirank_bench(ctx, one_gpu):
     ref = commit_batch(ctx, [int(t.data_ptr()) for t in polys], m2)
     assert cp["root"] == ref.root.hex()
     ref.close()
+    # ... and the same invocation carries the whole curve (G = 1 and 2 of the 2 ranks) and the library's own communicator's evidence
+    assert sorted(cp["curve"]) == ["1", "2"] and cp["roots_agree"] and cp["curve"]["1"]["root"] == cp["root"]
+    assert cp["curve"]["1"]["transport"] == "none" and cp["curve"]["2"]["transport"] == ("host" if one_gpu else "rccl")
+    assert q["rccl"]["world"] == 2 and q["rccl"]["ranks_seen"] == [0, 1] and q["rccl"]["transport"] == ("host" if one_gpu else "rccl")
+    assert q["rccl"]["allgather_32MiB_us"] > 0
     # latency mode: one proof at a time sharded over the two ranks (commits of >= 64 rows per rank split by leaf index)
     sh = launch(["--workload", "prove", "--sharded", "--log2-size", "15", "--no-cpu-baseline"])
     assert sh["n_gpus"] == 2 and sh["scaling"] == "strong" and sh["config"]["proofs_per_step"] == 1 and sh["value"] > 0
@@ -109,6 +114,55 @@ def test_bench_multirank_on_one_gpu_host_transport(ctx, oracle):
     """PK_BENCH_ONE_GPU=1: both ranks on GPU 0 (RCCL refuses that), joined by the library's host transport over the launcher's
     gloo group -- the same pk_commit_into / pk_prove sharding code as under RCCL, two real processes"""
     _check_multirank_bench(ctx, one_gpu=True)
+
+
+def test_bench_gpus_2_without_a_launcher():
+    """plain `python bench.py --gpus 2 --steps 2` -- no torchrun around it, WORLD_SIZE unset -- starts its own
+    two ranks (here both on GPU 0: PK_BENCH_ONE_GPU=1, host transport), reads --gpus, and the one line says so: n_gpus 2, the
+    library's communicator saw 2 ranks, and the 2^26 commit ran sharded over them next to the one-rank figure"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+    env["PK_BENCH_ONE_GPU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(root_dir, "bench.py"), "--gpus", "2", "--steps", "2", "--size-classes", "", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["proofs_per_step"] == 2 * 16 and "started its own ranks" in d["config"]["launcher"]
+    assert d["rccl"]["world"] == 2 and d["rccl"]["transport"] == "host" and d["rccl"]["ranks_seen"] == [0, 1]
+    c = d["commit_2p26"]
+    assert c["n_gpus"] == 2 and c["scaling"] == "strong" and sorted(c["curve"]) == ["1", "2"] and c["roots_agree"]
+    assert c["root"].startswith("592836a1")  # the 2^26 root every round has reported
+
+
+def test_bench_gpus_more_than_present_is_clamped():
+    """--gpus 8 on a box with fewer GPUs runs on what is there (and says so) instead of failing or claiming 8"""
+    import ctypes as C
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from provekit_amd._lib import lib
+
+    n = C.c_int(0)
+    lib.pk_device_count(C.byref(n))
+    if n.value != 1:
+        pytest.skip("written for the one-GPU box")
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID", "PK_BENCH_ONE_GPU")}
+    out = subprocess.run([sys.executable, os.path.join(root_dir, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--log2-size", "13", "--concurrency", "2",
+                          "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.strip()][-1])
+    assert d["n_gpus"] == 1 and d["rccl"]["world"] == 1
 
 
 def test_bench_multirank_over_rccl_needs_two_gpus(ctx, oracle):
