@@ -522,20 +522,18 @@ def emit_commit_line(args, world, m, dt, prof, root_hex, how):
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: start N ranks of this file under torch.distributed.run on this
     node (one process per GPU, rendezvous on 127.0.0.1 at a free port) and pass rank 0's JSON line through.  N is clamped to
-    the GPUs the library sees (pk_device_count) unless PK_BENCH_ONE_GPU=1 (development aid: every rank on GPU 0 over gloo)."""
-    import ctypes as C
+    the GPUs present unless PK_BENCH_ONE_GPU=1 (development aid: every rank on GPU 0 over gloo)."""
     import socket
     import subprocess
 
     n = args.gpus
     if os.environ.get("PK_BENCH_ONE_GPU") != "1":
-        from provekit_amd._lib import lib
+        import torch  # (torch's HIP runtime must be the first to initialise in a process that uses both: not pk_device_count here)
 
-        have = C.c_int(0)
-        lib.pk_device_count(C.byref(have))
-        if have.value < n:
-            print(f"[bench] --gpus {n} asked for, {have.value} GPU(s) visible: running on {max(have.value, 1)}", file=sys.stderr)
-            n = max(have.value, 1)
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"[bench] --gpus {n} asked for, {have} GPU(s) visible: running on {max(have, 1)}", file=sys.stderr)
+            n = max(have, 1)
     argv = [a for a in sys.argv[1:]]
     for i, a in enumerate(argv):  # rewrite --gpus to what will really run
         if a == "--gpus":

@@ -130,6 +130,11 @@ int pk_comm_info(const pk_ctx *ctx, int *rank, int *world, int *kind);
  * and the name it was opened by.  PK_ERR_RCCL: none could be loaded. */
 int pk_comm_rccl_version(int *version, char *path, size_t cap);
 int pk_comm_destroy(pk_ctx *ctx);
+/* After a sharded call failed on some rank the communicator is poisoned on purpose (nobody may wait for a rank that left).
+ * pk_comm_reset makes it usable again once EVERY rank is back from the failed call: the in-process and host transports clear
+ * their sticky flag (call it on every rank; harmless on a healthy communicator); an RCCL communicator that was aborted is gone --
+ * PK_ERR_RCCL: pk_comm_destroy + pk_comm_init_rank again. */
+int pk_comm_reset(pk_ctx *ctx);
 /* the two collectives, on the context's stream (exposed for tests and for callers that shard their own steps):
  * d_recv[r*bytes_per_rank ...] = rank r's d_send;  d_buf[i] = sum over ranks of d_buf[i] (wrapping u64) */
 int pk_comm_all_gather(pk_ctx *ctx, const void *d_send, void *d_recv, size_t bytes_per_rank);
@@ -334,7 +339,14 @@ int pk_gather_leaves(pk_ctx *ctx, const uint64_t *d_leaves, size_t n_leaves, siz
 int pk_commit(pk_ctx *ctx, const uint64_t *const *d_coeffs, unsigned batch, unsigned n_vars, unsigned log_inv_rate,
               unsigned fold, uint8_t root_out[32], pk_tree **out);
 /* pk_commit into caller-owned device buffers (no allocation; sizes in FEs from pk_commit_sizes, which account for the
- * context's device set: a rank of G keeps 1/G of the codeword rows).  d_nodes is the full heap on every rank.
+ * context's device set: a rank of G keeps 1/G of the codeword rows).
+ * WHICH SLOTS OF d_nodes ARE VALID.  d_nodes has room for the full heap (2 * rows digests, root at [1], leaf digests at
+ * [rows, 2 rows)) on every rank.  Outside a device set, and in a device set with fewer than 2^13 rows per rank, every rank
+ * holds the whole heap.  From 2^13 rows per rank up the inner tree is sharded by contiguous subtree: rank g of G holds the
+ * leaf layer [rows, 2 rows) and the top levels [1, 2G) like everyone else, and of every level c in [2G, rows) only its own
+ * slots [c + g c/G, c + (g+1) c/G) -- the other ranks' inner nodes are ZERO here, never computed.  (pk_tree_info's d_nodes
+ * is the same buffer under the same rule.)  Do not walk d_nodes yourself in a device set: pk_commit_open / pk_tree_open
+ * collect authentication paths from the ranks that own them; pk_shard_* below state the map.
  * ENCODING OF d_leaves.  The codeword a commit leaves behind is the library's own working form, described by the
  * pk_commit_layout it reports (layout_out, or pk_tree_layout for a pk_tree):
  *   n_shards / shard   rows i = shard (mod n_shards) are present, local row t = i / n_shards (1 / 0 outside a device set)

@@ -67,6 +67,7 @@ SIGNATURES = {
     "pk_comm_init_local": (C.c_int, [C.POINTER(vp), C.c_int]),
     "pk_comm_info": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pk_comm_rccl_version": (C.c_int, [C.POINTER(C.c_int), C.c_char_p, sz]),
+    "pk_comm_reset": (C.c_int, [vp]),
     "pk_comm_destroy": (C.c_int, [vp]),
     "pk_comm_all_gather": (C.c_int, [vp, vp, vp, sz]),
     "pk_comm_all_reduce_sum_u64": (C.c_int, [vp, vp, sz]),

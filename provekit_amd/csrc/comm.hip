@@ -543,6 +543,25 @@ int pk_comm_info(const pk_ctx* ctx, int* rank, int* world, int* kind) {
     return PK_OK;
 }
 
+int pk_comm_reset(pk_ctx* ctx) {
+    PK_ENTER(ctx);
+    pk_comm* c = ctx->comm;
+    if (!c) return PK_OK;
+    if (c->kind == PK_COMM_RCCL) {
+        if (c->failed || !c->nccl) return set_err(ctx, PK_ERR_RCCL, "an aborted RCCL communicator cannot be reset: pk_comm_destroy, then join again");
+        return PK_OK;
+    }
+    if (c->kind == PK_COMM_HOST) c->failed = false;
+    if (c->kind == PK_COMM_LOCAL && c->grp) {
+        std::lock_guard<std::mutex> lk(c->grp->mu);
+        c->grp->aborted = false;
+        c->grp->arrived = 0;  // ranks that were woken out of a barrier by the abort never completed it
+        c->grp->token_busy = false;
+    }
+    c->holds_token = false;
+    return PK_OK;
+}
+
 int pk_comm_destroy(pk_ctx* ctx) {
     PK_ENTER(ctx);
     (void)hipStreamSynchronize(ctx->stream);

@@ -71,6 +71,7 @@ struct pk_ctx {
 #define PK_PIN_ROOT 2048 /* 32 B: the root of the last Merkle tree built on this context (hash.hip) */
 #define PK_PIN_POW 2112  /* 8 B: the nonce found by the last proof-of-work launch (pow.hip) */
 #define PK_PIN_GATE 2304 /* 48 B, 64-byte aligned: the gate through which the host publishes a round's challenge (reduce.hpp) */
+#define PK_PIN_GATE_TIMEOUT 2368 /* 4 B: sequence number of a gate whose kernel gave up waiting (reduce.hpp); 0 = none */
 
 // A launch too small to fill the chip is latency-bound, and it sits on some prover's Fiat-Shamir critical path while the
 // chip-filling kernels of the other provers share its SIMDs: let its wavefronts issue ahead of theirs (s_setprio 3).  The

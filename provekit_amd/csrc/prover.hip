@@ -11,6 +11,7 @@
 //    +- external rows, weighted sums, claimed_evaluations hint (whir_r1cs.rs:81-91)
 //    +- whir_prove (whir::Prover::prove; structure pinned by recursive-verifier/app/circuit/whir.go:51-220)
 #include <sys/random.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cerrno>
@@ -46,6 +47,7 @@ int sumcheck_quadratic_launch(pk_ctx* ctx, const uint64_t* d_f, const uint64_t* 
                               uint64_t* d_f_out, uint64_t* d_w_out, unsigned* red_seq_out);
 int sumcheck_collect_spin(pk_ctx* ctx, unsigned red_seq, uint64_t out[12]);
 unsigned sumcheck_gate_next(pk_ctx* ctx);
+int sumcheck_gate_check(pk_ctx* ctx);
 void sumcheck_gate_publish(pk_ctx* ctx, unsigned gate_seq, const uint64_t challenge[4]);
 int witness_bounds_strided(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, unsigned m0, unsigned stride, unsigned offset, uint64_t* d_a,
                            uint64_t* d_b, uint64_t* d_c);
@@ -146,6 +148,11 @@ struct PendingGate {
     void arm(unsigned s) { seq = s; }
     void publish(const fe& challenge) {
         if (!seq) return;
+        static const long stall_us = [] {  // PK_TEST_GATE_STALL_US: the test-suite's stand-in for a host thread that was stopped
+            const char* e = getenv("PK_TEST_GATE_STALL_US");
+            return e ? strtol(e, nullptr, 10) : 0L;
+        }();
+        if (stall_us > 0) usleep((useconds_t)stall_us);
         uint64_t w[4];
         h_store(w, challenge);
         sumcheck_gate_publish(c, seq, w);
@@ -1009,6 +1016,8 @@ int pk_scheme_create(pk_ctx* ctx, const pk_r1cs* r1cs, size_t num_constraints, s
     PK_REQUIRE(ctx, num_witnesses <= ((size_t)1 << (m - 1)), "R1CS witness length exceeds scheme capacity");
     PK_REQUIRE(ctx, num_constraints <= ((size_t)1 << m_0), "R1CS constraints exceed scheme capacity");
     PK_REQUIRE(ctx, whir_witness->n_vars == m && whir_witness->batch_size == 2, "whir_witness config does not match m / batch 2");
+    // pk_prove commits the blinding polynomial next to its mask exactly as the witness (whir_r1cs.rs:212-226): batch 2, nothing else
+    PK_REQUIRE(ctx, whir_for_hiding_spartan->batch_size == 2, "whir_for_hiding_spartan must have batch_size 2");
     for (const pk_whir_config* c : {whir_witness, whir_for_hiding_spartan}) {
         PK_REQUIRE(ctx, c->folding_factor >= 1 && c->folding_factor <= 8 && c->n_rounds <= PK_MAX_WHIR_ROUNDS, "bad WHIR config");
         PK_REQUIRE(ctx, c->n_vars >= c->folding_factor * (c->n_rounds + 1), "WHIR rounds exceed the number of variables");
@@ -1070,6 +1079,7 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     } turn(ctx);
     Arena A{s->arena, s->arena_bytes};
     Transcript T(s->domain_separator);
+    (void)sumcheck_gate_check(ctx);  // a word left by an earlier, abandoned proof is not this proof's
     const bool timing = getenv("PK_PROVE_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto t_start = now();
@@ -1367,6 +1377,8 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     CK(whir_prove(ctx, A, s->whir_witness, W.com, wts, wlen, 3, T));
     CK(pk_ctx_sync(ctx));
     lap("witness WHIR proof");
+    // latency mode: every gated kernel of this proof has completed by now; one that gave up on its challenge computed with zero
+    CK(sumcheck_gate_check(ctx));
     // the proof performed exactly the operations its IO pattern declares (what spongefish enforces on the reference's side)
     if (!T.finished())
         return set_err(ctx, PK_ERR_IO_PATTERN, "%s", T.violation().empty() ? "the proof ended before its IO pattern did" : T.violation().c_str());

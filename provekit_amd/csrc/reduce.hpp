@@ -223,7 +223,16 @@ struct gate_args {
     const unsigned* host;  // pinned page + PK_PIN_GATE, or nullptr: no gate, the challenge is in the kernel arguments
     unsigned* dev;         // device mirror, same layout
     unsigned seq;
+    unsigned leader_spins;  // polls of the pinned page before workgroup (0,0) gives up (PK_GATE_SPINS_LEADER; the test-suite shortens it)
 };
+// A gate that gives up (the host did not publish within the device-side bound: stopped in a debugger, SIGSTOP, a core shared with
+// too many provers) lets its kernel run on with a ZERO challenge so that the queue drains -- and says so: workgroup (0,0) stores the
+// gate's sequence number into the word PK_PIN_GATE_TIMEOUT of the pinned page (system scope, sticky until the host clears it).
+// The host looks at that word wherever it takes a gated kernel's result (collect_reduction_spin) and once more before pk_prove
+// returns (gate_timed_out: the closing fold has no result of its own), and abandons the proof with PK_ERR_HIP.  The device bound
+// (2^24 polls of >= 1 us) is well above the host's own 10 s tolerance, so the host normally notices first and releases the gate itself.
+#define PK_GATE_SPINS_LEADER (1u << 24)
+#define PK_GATE_SPINS_FOLLOWER (1u << 27)
 // Layout of the gate (48 bytes, 64-byte aligned, the same in the pinned page and in the device mirror): three 16-byte chunks
 // [c0 c1 c2 seq] [c3 c4 c5 seq] [c6 c7 seq seq] -- every chunk carries the sequence number in its LAST word, which the writer stores last,
 // so a reader that finds the expected number in all three chunks of ONE set of 16-byte loads holds the whole challenge: a poll is a single
@@ -252,7 +261,12 @@ __device__ __forceinline__ fe gate_wait(const gate_args& g) {
         fe c = fe_zero();
         unsigned spins = 0;
         if (blockIdx.x == 0 && blockIdx.y == 0) {
-            while (!gate_try(reinterpret_cast<const gate_v4*>(g.host), g.seq, c) && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
+            bool got = false;
+            while (!(got = gate_try(reinterpret_cast<const gate_v4*>(g.host), g.seq, c)) && ++spins < g.leader_spins) __builtin_amdgcn_s_sleep(1);
+            if (!got) {  // report, then release the grid with a zero challenge (c is still zero: gate_try writes it only on success)
+                unsigned* pin_err = const_cast<unsigned*>(g.host) + (PK_PIN_GATE_TIMEOUT - PK_PIN_GATE) / 4;
+                __hip_atomic_store(pin_err, g.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             // mirror: the eight data words, then ONE release store of the sequence number (agent scope: the other workgroups' L2)
 #pragma unroll
             for (int i = 0; i < 8; i++) __hip_atomic_store(g.dev + i, c.v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -260,7 +274,7 @@ __device__ __forceinline__ fe gate_wait(const gate_args& g) {
         } else {
             // thousands of wavefronts wait here on one L2 line: one word per poll and a real pause between polls, or the channel that
             // holds the line is saturated and workgroup (0,0)'s own stores queue behind the readers (measured: +10 us per round)
-            while (__hip_atomic_load(g.dev + 11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.seq && ++spins < (1u << 24)) __builtin_amdgcn_s_sleep(8);
+            while (__hip_atomic_load(g.dev + 11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.seq && ++spins < PK_GATE_SPINS_FOLLOWER) __builtin_amdgcn_s_sleep(8);
             __atomic_thread_fence(__ATOMIC_ACQUIRE);  // once, after the word arrived (an acquire per poll invalidates caches thousands of times)
 #pragma unroll
             for (int i = 0; i < 8; i++) c.v[i] = __hip_atomic_load(g.dev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -278,9 +292,14 @@ inline unsigned gate_next(pk_ctx* ctx) {
     if (++ctx->gate_seq == 0) ctx->gate_seq = 1;
     return ctx->gate_seq;
 }
-inline gate_args gate_none() { return gate_args{nullptr, nullptr, 0}; }
+inline gate_args gate_none() { return gate_args{nullptr, nullptr, 0, 0}; }
 inline gate_args gate_for(pk_ctx* ctx, unsigned seq) {  // after reduction_scratch(ctx)
-    return gate_args{(const unsigned*)((char*)ctx->h_pinned + PK_PIN_GATE), red_ticket(ctx) + 16, seq};  // both 64-byte aligned
+    static const unsigned spins = [] {  // PK_TEST_GATE_SPINS: the test-suite's way to reach the give-up path in milliseconds
+        const char* e = getenv("PK_TEST_GATE_SPINS");
+        const unsigned long v = e ? strtoul(e, nullptr, 10) : 0;
+        return v ? (unsigned)v : PK_GATE_SPINS_LEADER;
+    }();
+    return gate_args{(const unsigned*)((char*)ctx->h_pinned + PK_PIN_GATE), red_ticket(ctx) + 16, seq, spins};  // both 64-byte aligned
 }
 // the host's half: the challenge first, the sequence number last
 inline void gate_publish(pk_ctx* ctx, unsigned seq, const fe& c) {
@@ -293,6 +312,13 @@ inline void gate_publish(pk_ctx* ctx, unsigned seq, const fe& c) {
     __atomic_store_n(g + 10, seq, __ATOMIC_RELEASE);
     __atomic_store_n(g + 11, seq, __ATOMIC_RELEASE);
 }
+// did a gated kernel of this context give up on its challenge since the last call?  (clears the word)
+inline bool gate_timed_out(pk_ctx* ctx) {
+    if (!ctx->h_pinned) return false;
+    unsigned* w = (unsigned*)((char*)ctx->h_pinned + PK_PIN_GATE_TIMEOUT);
+    return __atomic_exchange_n(w, 0u, __ATOMIC_ACQ_REL) != 0;
+}
+#define PK_GATE_TIMEOUT_MSG "a gated sumcheck kernel gave up waiting for its challenge (the host thread was stalled for tens of seconds) and ran with a zero challenge: the proof is abandoned"
 // wait for the reduction launched with sequence number `seq` WITHOUT draining the stream (a gated kernel may already sit behind it):
 // spin on the completion word its finishing workgroup publishes after the K results
 template <int K>
@@ -304,6 +330,7 @@ inline int collect_reduction_spin(pk_ctx* ctx, unsigned seq, uint64_t* host_out)
         if ((++polls & 0xfffff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0)
             return set_err(ctx, PK_ERR_HIP, "a gated reduction did not complete within 10 s");
     }
+    if (gate_timed_out(ctx)) return set_err(ctx, PK_ERR_HIP, "%s", PK_GATE_TIMEOUT_MSG);
     memcpy(host_out, ctx->h_pinned, 32 * K);
     return PK_OK;
 }

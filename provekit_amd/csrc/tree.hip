@@ -207,6 +207,9 @@ int commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, un
     // top log2 G levels hashed everywhere.  Inner nodes of the other ranks' subtrees are never formed here: openings collect
     // them from their owners (pk_tree_open).
     const unsigned g = (unsigned)comm_rank(ctx);
+    // heap slots [2G, rows) are the inner nodes below the subtree roots: this rank fills only its own 1/G of them -- the rest is
+    // zeroed, so that a caller who walks d_nodes himself reads zeros there, not whatever the buffer held (include/provekit_hip.h)
+    PK_HIP(ctx, hipMemsetAsync((fe*)d_nodes + 2 * (size_t)G, 0, 32 * (rows - 2 * (size_t)G), ctx->stream));
     fe* H = gathered;  // 2 * loc <= rows entries
     PK_HIP(ctx, hipMemcpyAsync(H + loc, (fe*)d_nodes + rows + (size_t)g * loc, 32 * loc, hipMemcpyDeviceToDevice, ctx->stream));
     rc = pk_merkle_inner(ctx, (uint64_t*)H, loc);

@@ -488,3 +488,47 @@ def test_latency_mode_gives_the_same_transcript(oracle, m, m_0, nc, n_in, pow_bi
     scheme.close()
     r1cs.close()
     ctx.close()
+
+
+def test_a_gate_that_gives_up_fails_the_proof_instead_of_proving_with_zero():
+    """in latency mode a gated sumcheck kernel whose host stalled past the device-side bound used to run on with a
+    ZERO challenge and pk_prove returned PK_OK with a transcript that does not verify.  Now the giving-up workgroup leaves a word in
+    the pinned page and the host abandons the proof with PK_ERR_HIP.  A fresh process: the two test hooks (a short device bound, a host
+    that sleeps before publishing each challenge) are read once per process."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = r'''
+import sys
+sys.path[:0] = [%r, %r]
+import torch; torch.cuda.is_available()
+import oracle_lib as oracle
+import provekit_amd
+from provekit_amd._lib import ProveKitHipError
+from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+from provekit_amd.sparse_matrix import R1CS
+from test_gpu_prove import satisfiable_r1cs, to_sparse
+m, m_0, nc, n_in = 12, 9, 500, 700
+ctx = provekit_amd.Context(0)
+nw, z, coeffs, trips = satisfiable_r1cs(nc, n_in, 31)
+r1cs = R1CS(ctx, *(to_sparse(nc, nw, t) for t in trips), oracle.to_mont(oracle.ints_to_limbs(coeffs)))
+scheme = WhirR1CSScheme(ctx, r1cs, m, m_0, WhirConfig.for_size(m, 4.0), blinding_config_for(m_0, 4.0))
+d_z = ctx.upload(oracle.to_mont(oracle.ints_to_limbs(z)))
+plain = scheme.prove(d_z, seed=1)          # no gates in the plain mode: unaffected by the hooks
+ctx.set_latency_mode(True)
+for attempt in range(2):
+    try:
+        scheme.prove(d_z, seed=1)
+        print("SILENT")                     # the old behaviour: PK_OK
+    except ProveKitHipError as e:
+        print("REFUSED", e.code, "gave up waiting" in str(e))
+ctx.set_latency_mode(False)
+print("PLAIN_AGAIN", scheme.prove(d_z, seed=1) == plain)
+''' % (os.path.dirname(here), here)
+    env = dict(os.environ, PK_TEST_GATE_SPINS="64", PK_TEST_GATE_STALL_US="30000")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.split(" ")[0] in ("SILENT", "REFUSED", "PLAIN_AGAIN")]
+    assert lines == ["REFUSED -3 True", "REFUSED -3 True", "PLAIN_AGAIN True"], (lines, out.stderr[-1500:])

@@ -333,6 +333,22 @@ def test_a_failing_rank_wakes_its_peers_instead_of_hanging_them(rank_sets):
     assert res[0][0] == -4  # PK_ERR_RCCL on the rank that was waiting for it
     assert res[0][1] == -4 and res[1][1] == -4  # the communicator stays unusable: nobody waits for anybody
 
+    # ... until every rank, back from the failed call, resets it (a recoverable caller error must not cost the device set)
+    def again(r, c):
+        c._check(lib.pk_comm_reset(c.handle))
+        return r
+
+    run_ranks(ctxs, again)
+
+    def gather(r, c):
+        x = c.upload(np.arange(8, dtype=np.uint64) + 10 * r)
+        y = c.alloc(128)
+        c._check(lib.pk_comm_all_gather(c.handle, x.ptr, y.ptr, 64))
+        return c.download(y, (2, 8))
+
+    for got in run_ranks(ctxs, gather):
+        assert np.array_equal(got, np.stack([np.arange(8, dtype=np.uint64), np.arange(8, dtype=np.uint64) + 10]))
+
 
 def test_a_rank_that_fails_inside_a_sharded_proof_wakes_its_peers(oracle, rank_sets):
     """only the commit path aborted the group; every other early return inside pk_prove left the peers at a barrier
