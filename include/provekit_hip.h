@@ -536,45 +536,8 @@ int pk_selftest_arith(int op, const uint64_t *a, const uint64_t *b, uint64_t *ou
  * attempt}), attempt = 0, 1, ... until the candidate is < p */
 int pk_selftest_chacha(const uint8_t key[32], uint64_t counter, uint32_t n0, uint32_t n1, int rounds, uint8_t out[64]);
 int pk_selftest_random_fe(pk_ctx *ctx, const uint8_t seed32[32], uint32_t stream, uint64_t *d_out, size_t n);
-/* the same ops run by a kernel on device buffers (device-vs-host codegen diff in the GPU suite) */
-int pk_selftest_arith_device(pk_ctx *ctx, int op, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out, size_t n);
-/* measurement aid (SURVEY 8d "measured_peak_modmul_per_s"): rate of register-resident 9x29-bit Montgomery squarings,
- * ilp (1|2|4) independent chains per lane, waves_per_simd (1..8) resident waves, iters squarings per chain */
-int pk_selftest_modmul_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double *modmul_per_s);
-/* PROTOTYPE, not on the product path (csrc/fe52.hpp): the reference's f64-FMA Montgomery square on 5 x 52-bit limbs
- * (skyscraper/block-multiplier/src/portable_simd.rs:17-196, utils.rs:66-147, constants.rs:100-133; round-toward-zero as
- * fp-rounding/src/lib.rs:57-78).  a: n values < 2^256 (4 x u64 each) -> out5: n x 5 limbs of x^2 * 2^-260 mod p, lazily
- * reduced (< 2^257).  Host: under fesetround(FE_TOWARDZERO); device: MODE.FP_ROUND set by the kernel; _rate_fp52: the same
- * probe as pk_selftest_modmul_rate for this multiplier, so the two can be compared on one box. */
-int pk_selftest_fp52_sqr(const uint64_t *a, uint64_t *out5, size_t n);
-/* PROTOTYPE probe, not on the product path: the wavefront-cooperative Skyscraper square round (limbs in lanes 0..8, v_readlane
- * broadcasts, DPP window shift) next to the lone lane's round (skyscraper29s.hpp sky_sq_round_s), `iters` rounds each on one
- * wavefront of an idle GPU: out[36] = coop l, coop r, lane l, lane r (9 x 29-bit limbs each); cycles[0..1] = s_memtime ticks of the
- * two loops inside one launch, cycles[2..3] = nanoseconds of each loop in a launch of its own (hipEvents).  north_star's
- * "one-wavefront-per-node Skyscraper rounds", measured. */
-int pk_selftest_coop_round(pk_ctx *ctx, const uint32_t l[9], const uint32_t r[9], unsigned iters, uint32_t out[36],
-                           uint64_t cycles[4]);
-int pk_selftest_fp52_sqr_device(pk_ctx *ctx, const uint64_t *d_a, uint64_t *d_out5, size_t n);
-int pk_selftest_modmul_rate_fp52(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double *modmul_per_s);
-/* modular reduction as a constant-matrix product on the matrix core (v_mfma_i32_16x16x64_i8 over the
- * 8/8/8/5-bit digits a 29-bit limb already holds; csrc/selftest.hip "Reduction on the matrix core") -- measured and
- * NOT adopted.  pk_selftest_mfma_reduce: the product itself, exact (d_t_limbs: n x 18 limbs of 29 bits, d_out: n x 36 column sums
- * with sum_i out[i] 2^(29 (i/4) + 8 (i%4)) == t 2^-256 mod p, non-negative, < 2^270).  The two rate probes return squarings per
- * second: the matrix pipe fed for free, and the vector work that remains with the matrix products and lane movement free. */
-/* one Fiat-Shamir round trip as pk_prove makes it (launch + stream synchronisation) against the same round trip
- * through a persistent kernel's pinned mailbox, `host_work_permutes` sponge permutations of host work in between; microseconds per
- * round over `rounds` dependent round trips (tools/roundtrip.py, profiles/r04_roundtrip.json). */
-/* products by a constant per second, register-resident chains: the Montgomery product (mont261_29, shoup = 0) against the Shoup form
- * with a precomputed quotient (shoup261_29, shoup = 1: 143 multiply-adds instead of 162 + 9); csrc/fe29.hpp */
-int pk_selftest_constmul_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, int shoup, double *modmul_per_s);
-int pk_selftest_roundtrip(pk_ctx *ctx, unsigned rounds, unsigned host_work_permutes, double *us_per_round_launch,
-                          double *us_per_round_mailbox);
-/* `launches` dependent one-wavefront kernels back to back on the context's stream, one synchronisation at the end: microseconds per
- * kernel boundary with no host in the loop */
-int pk_selftest_launch_chain(pk_ctx *ctx, unsigned launches, unsigned threads_per_launch, double *us_per_launch);
-int pk_selftest_mfma_reduce(pk_ctx *ctx, const uint32_t *d_t_limbs, int32_t *d_out, size_t n);
-int pk_selftest_mfma_reduce_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned iters, double *squarings_per_s);
-int pk_selftest_mfma_valu_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double *squarings_per_s);
+/* Measurement probes (multiplier peak rates, round-trip costs), the device-side run of the op table above and the prototypes that
+ * were measured and rejected are NOT part of this library: tools/probes builds them into libpk_probes.so (tools/probes/pk_probes.h). */
 
 #ifdef __cplusplus
 }

@@ -159,18 +159,6 @@ SIGNATURES = {
     "pk_selftest_arith": (C.c_int, [C.c_int, vp, vp, vp, sz]),
     "pk_selftest_chacha": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, vp]),
     "pk_selftest_random_fe": (C.c_int, [vp, vp, C.c_uint32, vp, sz]),
-    "pk_selftest_arith_device": (C.c_int, [vp, C.c_int, vp, vp, vp, sz]),
-    "pk_selftest_modmul_rate": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),
-    "pk_selftest_coop_round": (C.c_int, [vp, vp, vp, C.c_uint, vp, vp]),
-    "pk_selftest_fp52_sqr": (C.c_int, [vp, vp, sz]),
-    "pk_selftest_fp52_sqr_device": (C.c_int, [vp, vp, vp, sz]),
-    "pk_selftest_modmul_rate_fp52": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),
-    "pk_selftest_constmul_rate": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.c_int, C.POINTER(C.c_double)]),
-    "pk_selftest_launch_chain": (C.c_int, [vp, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),
-    "pk_selftest_roundtrip": (C.c_int, [vp, C.c_uint, C.c_uint, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
-    "pk_selftest_mfma_reduce": (C.c_int, [vp, vp, vp, sz]),
-    "pk_selftest_mfma_reduce_rate": (C.c_int, [vp, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),
-    "pk_selftest_mfma_valu_rate": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),
 }
 
 

@@ -1,5 +1,5 @@
 """The f64-FMA Montgomery square prototype (csrc/fe52.hpp; the reference's block-multiplier portable_simd.rs:17-196 under
-round-toward-zero) executed on the host through pk_selftest_fp52_sqr, against its definition x^2 * 2^-260 mod p.
+round-toward-zero) executed on the host through pk_probe_fp52_sqr, against its definition x^2 * 2^-260 mod p.
 Inputs follow the reference's own multiplier tests: the 100k seeded loop of scalar.rs:163-206 (here 100k seeded values) and the
 proptest regression inputs."""
 import random
@@ -45,22 +45,24 @@ def check_fp52(vals, out):
 
 def test_fp52_square_host_matches_definition():
     from provekit_amd._lib import lib
+    from tools.pk_probes import lib as probes
 
     vals = fp52_inputs(100_000, 52)
     a = limbs4(vals)
     out = np.zeros((len(vals), 5), dtype=np.uint64)
-    assert lib.pk_selftest_fp52_sqr(a.ctypes.data, out.ctypes.data, len(vals)) == 0
+    assert probes.pk_probe_fp52_sqr(a.ctypes.data, out.ctypes.data, len(vals)) == 0
     check_fp52(vals, out)
 
 
 def test_fp52_square_chain_stays_in_its_lazy_domain():
     """the bound the rate probe relies on: outputs (< 2^257, limbs < 2^52) are valid inputs again"""
     from provekit_amd._lib import lib
+    from tools.pk_probes import lib as probes
 
     rnd = random.Random(7)
     vals = [rnd.randrange(2**256) for _ in range(2000)] + [2**256 - 1]
     a = limbs4(vals)
     out = np.zeros((len(vals), 5), dtype=np.uint64)
-    assert lib.pk_selftest_fp52_sqr(a.ctypes.data, out.ctypes.data, len(vals)) == 0
+    assert probes.pk_probe_fp52_sqr(a.ctypes.data, out.ctypes.data, len(vals)) == 0
     worst = max(sum(int(out[i, k]) << (52 * k) for k in range(5)) for i in range(len(vals)))
     assert worst < 2**256  # x < 2^256 -> x^2/2^260 + (4 * 2^52 + 1) p / 2^52 ... < 2^256

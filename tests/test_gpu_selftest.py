@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("op", list(range(15)) + [21, 22, 23])  # 21-23: the safegcd inverse (feinv.hpp), both step forms
 def test_device_equals_host(ctx, oracle, op):
     from provekit_amd._lib import lib
+    from tools.pk_probes import lib as probes
     from provekit_amd.field import random_field
 
     n = 4096
@@ -23,7 +24,7 @@ def test_device_equals_host(ctx, oracle, op):
     host = np.empty_like(a)
     assert lib.pk_selftest_arith(op, a.ctypes.data, b.ctypes.data, host.ctypes.data, n) == 0
     da, db, do = ctx.upload(a), ctx.upload(b), ctx.alloc_fe(n)
-    ctx._check(lib.pk_selftest_arith_device(ctx.handle, op, da.ptr, db.ptr, do.ptr, n))
+    ctx._check(probes.pk_probe_arith_device(ctx.handle, op, da.ptr, db.ptr, do.ptr, n))
     assert np.array_equal(ctx.download_fe(do, n), host)
 
 
@@ -33,15 +34,16 @@ def test_fp52_prototype_device_equals_host_and_definition(ctx):
     import ctypes as C
 
     from provekit_amd._lib import lib
+    from tools.pk_probes import lib as probes
     from test_fp52_host import check_fp52, fp52_inputs, limbs4
 
     vals = fp52_inputs(100_000, 53)
     a = limbs4(vals)
     n = len(vals)
     host = np.zeros((n, 5), dtype=np.uint64)
-    assert lib.pk_selftest_fp52_sqr(a.ctypes.data, host.ctypes.data, n) == 0
+    assert probes.pk_probe_fp52_sqr(a.ctypes.data, host.ctypes.data, n) == 0
     da, do = ctx.upload(a), ctx.alloc_fe(2 * n)
-    ctx._check(lib.pk_selftest_fp52_sqr_device(ctx.handle, da.ptr, do.ptr, n))
+    ctx._check(probes.pk_probe_fp52_sqr_device(ctx.handle, da.ptr, do.ptr, n))
     dev = np.zeros((n, 5), dtype=np.uint64)
     ctx._check(lib.pk_memcpy_d2h(ctx.handle, dev.ctypes.data, do.ptr, dev.nbytes))
     assert np.array_equal(dev, host)
@@ -57,6 +59,7 @@ def test_cooperative_square_round_prototype_matches_the_lane(ctx):
     import random
 
     from provekit_amd._lib import lib
+    from tools.pk_probes import lib as probes
 
     P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
     limbs = lambda v: [(v >> (29 * k)) & ((1 << 29) - 1) if k < 8 else v >> 232 for k in range(9)]
@@ -66,7 +69,7 @@ def test_cooperative_square_round_prototype_matches_the_lane(ctx):
         L, R = (C.c_uint32 * 9)(*limbs(v[0])), (C.c_uint32 * 9)(*limbs(v[1]))
         out, cyc = (C.c_uint32 * 36)(), (C.c_uint64 * 4)()
         for n in (1, 2, 3, 6):
-            ctx._check(lib.pk_selftest_coop_round(ctx.handle, L, R, n, out, cyc))
+            ctx._check(probes.pk_probe_coop_round(ctx.handle, L, R, n, out, cyc))
             o = list(out)
             assert value(o[0:9]) % P == value(o[18:27]) % P and value(o[9:18]) % P == value(o[27:36]) % P, (v, n)
             assert max(o[0:8]) <= 1 << 29

@@ -11,6 +11,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import provekit_amd
 from provekit_amd._lib import lib
+from tools.pk_probes import lib as probes
 
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
@@ -35,12 +36,12 @@ for case in range(8):
     # a compression runs at most 6 square rounds between two reductions (the state grows by ~2p per round and the limbs hold it);
     # parity is checked over up to 17 rounds, the timing loop runs longer and its (overflowed) values are not compared
     for n in (1, 2, 3, 6, 12, 17):
-        ctx._check(lib.pk_selftest_coop_round(ctx.handle, L, R, n, out, cyc))
+        ctx._check(probes.pk_probe_coop_round(ctx.handle, L, R, n, out, cyc))
         o = list(out)
         cl, cr, sl, sr = value(o[0:9]), value(o[9:18]), value(o[18:27]), value(o[27:36])
         assert cl % P == sl % P and cr % P == sr % P, (case, n)
         assert max(o[0:8]) <= (1 << 29) and o[8] < (1 << 30), o[:9]
-    ctx._check(lib.pk_selftest_coop_round(ctx.handle, L, R, iters, out, cyc))
+    ctx._check(probes.pk_probe_coop_round(ctx.handle, L, R, iters, out, cyc))
     res["cases"] += 1
     if best is None or cyc[2] < best[2]:
         best = (cyc[0], cyc[1], cyc[2], cyc[3])

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import provekit_amd  # noqa: E402
 from provekit_amd._lib import lib  # noqa: E402
+from tools.pk_probes import lib as probes
 
 P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
@@ -30,7 +31,7 @@ def check_parity(ctx, n=4096, seed=3):
             limbs[i, q] = (t >> (29 * q)) & ((1 << 29) - 1)
     d_in = ctx.upload(limbs)
     d_out = ctx.upload(np.zeros((n, 36), dtype=np.int32))
-    ctx._check(lib.pk_selftest_mfma_reduce(ctx.handle, d_in.ptr, d_out.ptr, n))
+    ctx._check(probes.pk_probe_mfma_reduce(ctx.handle, d_in.ptr, d_out.ptr, n))
     out = ctx.download(d_out, (n, 36), np.int32)
     rinv = pow(1 << 256, -1, P)
     worst = 0
@@ -57,9 +58,9 @@ if __name__ == "__main__":
     res = {"experiment": "modular reduction as a constant-matrix product on the matrix core (v_mfma_i32_16x16x64_i8 over the 8/8/8/5-bit digits of "
                          "29-bit limbs, Montgomery factor folded into the constants); csrc/selftest.hip",
            "parity_of_the_matrix_product": check_parity(ctx)}
-    int29, a0 = best(lib.pk_selftest_modmul_rate, [(w, i, 2000) for w in (2, 4, 8) for i in (1, 2)])
-    pipe, a1 = best(lib.pk_selftest_mfma_reduce_rate, [(w, 400) for w in (1, 2, 4, 8)])
-    valu, a2 = best(lib.pk_selftest_mfma_valu_rate, [(w, i, 1000) for w in (2, 4, 8) for i in (1, 2)])
+    int29, a0 = best(probes.pk_probe_modmul_rate, [(w, i, 2000) for w in (2, 4, 8) for i in (1, 2)])
+    pipe, a1 = best(probes.pk_probe_mfma_reduce_rate, [(w, 400) for w in (1, 2, 4, 8)])
+    valu, a2 = best(probes.pk_probe_mfma_valu_rate, [(w, i, 1000) for w in (2, 4, 8) for i in (1, 2)])
     res.update({
         "int29_squaring_T_per_s": int29 / 1e12, "int29_best_waves_ilp": list(a0[:2]),
         "matrix_pipe_only_T_squarings_per_s": pipe / 1e12, "matrix_pipe_best_waves": a1[0],

@@ -10,10 +10,11 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import provekit_amd
 from provekit_amd._lib import lib
+from tools.pk_probes import lib as probes
 
 ctx = provekit_amd.Context(0)
 res = {"unit": "T squarings/s", "iters": 4096, "int29": {}, "fp52": {}}
-for name, fn in (("int29", lib.pk_selftest_modmul_rate), ("fp52", lib.pk_selftest_modmul_rate_fp52)):
+for name, fn in (("int29", probes.pk_probe_modmul_rate), ("fp52", probes.pk_probe_modmul_rate_fp52)):
     for waves in (1, 2, 4, 6, 8):
         for ilp in (1, 2, 4):
             best = 0.0

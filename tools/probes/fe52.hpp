@@ -17,7 +17,7 @@
 // and v_lshl_add_u64 at 5.1, v_mad_u64_u32 at 5.5 -- a 52x52-bit product costs 2 FMA + 1 subtract + 2 wide adds = 23 cycles
 // where the 29-bit limbs get the same 2704 bit^2 from 3.2 multiply-adds = 18 cycles with the accumulation included.  On NEON
 // the FMA pipes are 2-4x wider than the 64-bit integer multiplier; on CDNA4 both are quarter-rate VALU operations.
-// Nothing in the product path uses this header; it is reachable only through pk_selftest_fp52_* (selftest.hip).
+// Nothing in the product path uses this header; it is reachable only through pk_probe_fp52_* (tools/probes/probes.hip).
 #pragma once
 #include "fe29.hpp"
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Does sustained load lower the clocks?  The register-resident squaring rate (pk_selftest_modmul_rate) and rocm-smi's sclk / power before
+"""Does sustained load lower the clocks?  The register-resident squaring rate (pk_probe_modmul_rate) and rocm-smi's sclk / power before
 and after N seconds of chip-filling work (2^26 commits).  GPU box."""
 import ctypes as C, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,12 +7,13 @@ sys.path.insert(0, ROOT)
 import torch
 import provekit_amd
 from provekit_amd._lib import lib
+from tools.pk_probes import lib as probes
 
 ctx = provekit_amd.Context(0)
 
 def rate():
     v = C.c_double()
-    ctx._check(lib.pk_selftest_modmul_rate(ctx.handle, 8, 2, 3000, C.byref(v)))
+    ctx._check(probes.pk_probe_modmul_rate(ctx.handle, 8, 2, 3000, C.byref(v)))
     return round(v.value / 1e12, 4)
 
 def smi():
