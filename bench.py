@@ -161,83 +161,44 @@ def ntt_roofline(prof, steps, m, cfg_w, cfg_b, peak_modmul=None):
     return out
 
 
-def cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg):
-    """The same step through the CPU oracle (oracle/pk_oracle.c, OpenMP over the host cores) -- a reported
-    baseline only.  The 2^8 blinding WHIR (microseconds of work) is left out; everything else is the full size."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as o
-    from provekit_amd.field import random_field
+def cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg_w, cfg_b, domain_separator, z_host, seed, gpu_proof, budget_s=75.0):
+    """The SAME step on the host cores: one whole proof of the bench's statement through oracle/prover_ref.py -- the reference's
+    WhirR1CSProver::prove (provekit/prover/src/whir_r1cs.rs:42-100) restated on the C oracle's kernels (oracle/pk_oracle.c, OpenMP
+    wherever the reference uses rayon; the sparse products serial as in the reference), transcript and blinding algebra included --
+    with the key the GPU proof was made with, so the two proof strings can be compared byte for byte.  A reported baseline only.
+    Run at all threads, then at 16 and at 1 while the time budget lasts (the serial fraction shows in the ratio)."""
+    sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+    import prover_ref as PR
+    import verifier as V
 
-    half = 1 << (m - 1)
-    z = random_field(n_wit, 1)
-    mask, g = random_field(half, 2), random_field(2 * half, 3)  # input / RNG generation stays outside the timed region
-    t0 = time.perf_counter()
-    f = np.zeros((2 * half, 4), np.uint64)
-    f[:n_wit] = z
-    f[half:] = mask
-    fc, gc = o.to_coeffs(f, m), o.to_coeffs(g, m)
-    leaves = o.rs_encode(np.concatenate([fc, gc]), 2, m, 1, 4)
-    o.merkle_commit(leaves)
-    zpt = random_field(1, 4)[0]
-    o.eval_univariate(fc, zpt), o.eval_univariate(gc, zpt)
-    a = o.spmv(nc, n_wit, mats[0].new_row_indices, mats[0].col_indices, mats[0].values, interner, z)
-    b = o.spmv(nc, n_wit, mats[1].new_row_indices, mats[1].col_indices, mats[1].values, interner, z)
-    pad = np.zeros(((1 << m_0) - nc, 4), np.uint64)
-    a, b = np.concatenate([a, pad]), np.concatenate([b, pad])
-    c = o.hadamard(a, b)
-    eq = o.eq_table(random_field(m_0, 5))
-    fold, length = None, 1 << m_0
-    al = random_field(m_0, 6)
-    for r in range(m_0):
-        _, a, b, c, eq = o.sumcheck_cubic_round(a[:length], b[:length], c[:length], eq[:length], fold)
-        if fold is not None:
-            length //= 2
-        fold = al[r]
-    eqa = o.eq_table(al)
-    ws = []
-    for k in range(3):
-        row = o.spmv(nc, n_wit, mats[k].new_row_indices, mats[k].col_indices, mats[k].values, interner, eqa[:nc], transpose=True)
-        w = np.zeros((2 * half, 4), np.uint64)
-        w[:n_wit] = row
-        ws.append(w)
-        o.dot(w, f), o.dot(w, g)
-    # WHIR opening
-    beta = random_field(1, 7)[0]
-    cw = o.vec_axpy(fc, beta, gc)
-    p = o.to_evals(cw, m)
-    one = o.to_mont(o.ints_to_limbs([1]))[0]
-    w = o.eq_accumulate_univariate(np.zeros((2 * half, 4), np.uint64), m, zpt, one)
-    for x in ws:
-        w = o.vec_add(w, x)
+    def vcfg(c):
+        return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, list(c.num_queries), list(c.ood_samples), list(c.pow_bits),
+                            c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
 
-    def rounds(p, w, k):
-        rs, fold = [], None
-        for i in range(k):
-            _, p, w = o.sumcheck_quadratic_round(p[: len(p)], w[: len(w)], fold)
-            if fold is not None:
-                p, w = p[: len(p) // 2], w[: len(w) // 2]
-            fold = random_field(1, 100 + i)[0]
-            rs.append(fold)
-        pp, ww = p.copy(), w.copy()
-        o.L.pko_fold_pairs(o._p(pp), len(pp), o._p(fold))
-        o.L.pko_fold_pairs(o._p(ww), len(ww), o._p(fold))
-        return pp[: len(pp) // 2], ww[: len(ww) // 2], np.stack(rs)
-
-    p, w, rs = rounds(p, w, 4)
-    nv, rate = m, 1
-    for r in range(cfg.n_rounds):
-        cw = o.fold_coeffs(cw, nv, rs)
-        nv -= 4
-        rate += 3
-        lv = o.rs_encode(cw, 1, nv, rate, 4)
-        o.merkle_commit(lv)
-        o.eval_univariate(cw, zpt)
-        o.pow_solve(np.frombuffer(bytes(range(32)), dtype=np.uint64), cfg.pow_bits[r])
-        for q in range(cfg.num_queries[r] + 1):
-            w = o.eq_accumulate_univariate(w, nv, random_field(1, 200 + q)[0], one)
-        p, w, rs = rounds(p, w, 4)
-    dt = time.perf_counter() - t0
-    return dt, o.L.pko_num_threads()
+    r1cs = (nc, n_wit, [(mt.new_row_indices, mt.col_indices, mt.values) for mt in mats], interner)
+    all_threads = PR.L.pko_num_threads()
+    out = {"threads": {}}
+    spent = 0.0
+    for threads in (all_threads, 16, 1):
+        if threads > all_threads or str(threads) in out["threads"]:
+            continue
+        # a run at fewer threads takes about all_threads / threads times the parallel part: skip what cannot fit the budget
+        est = out["threads"][str(all_threads)]["s_per_proof"] * min(all_threads / threads, 40.0) * 0.6 if out["threads"] else 0.0
+        if spent + est > budget_s:
+            out["threads"][str(threads)] = {"skipped": f"estimated {est:.0f} s: over the {budget_s:.0f} s budget of this leg (run bench.py --cpu-baseline-budget to raise it)"}
+            continue
+        PR.L.pko_set_num_threads(threads)
+        stage = {}
+        t0 = time.perf_counter()
+        proof = PR.prove(domain_separator, m, m_0, vcfg(cfg_w), vcfg(cfg_b), r1cs, z_host, seed, stage)
+        dt = time.perf_counter() - t0
+        spent += dt
+        out["threads"][str(threads)] = {"s_per_proof": dt, "proofs_per_s": 1.0 / dt, "stage_s": stage}
+        if threads == all_threads:
+            out.update(seconds=dt, cores=threads, stage_s=stage, proof_bytes=len(proof),
+                       matches_gpu_transcript=(proof == gpu_proof) if gpu_proof is not None else None)
+    PR.L.pko_set_num_threads(all_threads)
+    return out
 
 
 def commit_probe(ctx, torch, local_rank, n_vars=26, reps=3, world=1, dist=None, one_gpu=False, takes_part=True, transport=None):
@@ -580,6 +541,7 @@ def main():
                     help="log2 of the committed polynomial size (poseidon-rounds: 21).  Under torch.distributed.run spell it "
                          "--log2-size: the launcher's own parser rejects --m as an ambiguous abbreviation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=75.0, help="seconds the CPU-baseline leg may spend on its runs at fewer threads (all threads always runs)")
     ap.add_argument("--no-commit-probe", action="store_true", help="skip the secondary 2^26 commit figure (configs[4]) of the default line")
     ap.add_argument("--commit-log2-size", type=int, default=26, help="log2 coefficients of the secondary commit figure (26 = BASELINE configs[4])")
     ap.add_argument("--size-classes", default="23,25",
@@ -679,6 +641,7 @@ def main():
             c.set_latency_mode(True)
         workers.append((c, WhirR1CSScheme(c, r1cs_w, m, m_0, cfg_w, cfg_b), d_z, r1cs_w, z_host))
     ctx = workers[0][0]
+    mats0, interner0 = mats, interner  # every prover of a rank proves the same statement (one seed), each with its own witness
 
     def run_proofs(first_seed, count):
         """`count` proofs through the `conc` provers of this GPU.  Work is handed out dynamically (each prover thread takes the
@@ -1015,15 +978,23 @@ def main():
         if size_figs:
             line["size_classes"] = size_figs
         if not args.no_cpu_baseline and world == 1:
-            cdt, threads = cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg_w)
+            seed = (4242).to_bytes(32, "little")
+            gpu_proof = workers[0][1].prove(workers[0][2], seed=seed)
+            cb = cpu_baseline(m, m_0, mats0, interner0, nc, n_wit, cfg_w, cfg_b, workers[0][1].domain_separator, workers[0][4], seed, gpu_proof,
+                              budget_s=args.cpu_baseline_budget)
             line["cpu_baseline"] = {
-                "value": 1.0 / cdt,
+                "value": 1.0 / cb["seconds"],
                 "unit": "proofs/s",
-                "cores": threads,
+                "cores": cb["cores"],
                 "kind": "port",
-                "sample": f"1 proof (a step is {conc} of them) of the same workload (m={m}) through oracle/pk_oracle.c, OpenMP on {threads} threads wherever the reference "
-                          "uses rayon (commit, sumcheck, eq, sums); SpMV serial as in the reference; NOT the whole step: the 2^8 blinding WHIR, the STIR "
-                          "openings (Merkle paths + leaf gathers) and the transcript are omitted, so the real CPU figure is lower still",
+                "sample": f"1 whole proof (a step is {conc} of them) of the same statement (m={m}) through oracle/prover_ref.py + oracle/pk_oracle.c: both commitments, the "
+                          f"zk sumcheck with its blinding algebra, the blinding WHIR, external rows and sums, the {cfg_w.n_rounds}-round witness WHIR with proof of work and "
+                          "STIR openings, and the Skyscraper-sponge transcript -- the reference's prove end to end (whir_r1cs.rs:42-100); OpenMP wherever the reference uses "
+                          "rayon, sparse products serial as in the reference; same 32-byte key as a GPU proof of this run",
+                "matches_gpu_transcript": cb["matches_gpu_transcript"],
+                "proof_bytes": cb["proof_bytes"],
+                "stage_s": cb["stage_s"],
+                "by_threads": {k: ({"proofs_per_s": v["proofs_per_s"], "s_per_proof": v["s_per_proof"]} if "s_per_proof" in v else v) for k, v in cb["threads"].items()},
             }
         emit(line)
     if hung_any:

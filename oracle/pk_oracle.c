@@ -144,10 +144,12 @@ void pko_fe_from_mont(const u64 mont[4], u64 out[4]) {
     pko_fe_mul(mont, one, out);
 }
 void pko_fe_to_mont_many(const u64 *canon, u64 *out, size_t n) {
-    for (size_t i = 0; i < n; i++) pko_fe_to_mont(canon + 4 * i, out + 4 * i);
+#pragma omp parallel for schedule(static) if (n >= 4096)
+    for (long i = 0; i < (long)n; i++) pko_fe_to_mont(canon + 4 * i, out + 4 * i);
 }
 void pko_fe_from_mont_many(const u64 *mont, u64 *out, size_t n) {
-    for (size_t i = 0; i < n; i++) pko_fe_from_mont(mont + 4 * i, out + 4 * i);
+#pragma omp parallel for schedule(static) if (n >= 4096)
+    for (long i = 0; i < (long)n; i++) pko_fe_from_mont(mont + 4 * i, out + 4 * i);
 }
 void pko_fe_pow(const u64 base[4], u64 e, u64 out[4]) {
     u64 acc[4], b[4];
@@ -428,13 +430,33 @@ int pko_rs_encode(const u64 *coeffs, unsigned batch, unsigned n_vars, unsigned l
 /* ------------------------------------------------------------------ */
 /* E1: univariate Horner                                                */
 /* ------------------------------------------------------------------ */
-void pko_eval_univariate(const u64 *c, size_t n, const u64 z[4], u64 out[4]) {
+static void horner(const u64 *c, size_t n, const u64 z[4], u64 out[4]) {
     u64 acc[4] = {0, 0, 0, 0};
     for (size_t i = n; i-- > 0;) {
         pko_fe_mul(acc, z, acc);
         pko_fe_add(acc, c + 4 * i, acc);
     }
     memcpy(out, acc, 32);
+}
+/* Horner's rule; long polynomials in blocks of 2^14 coefficients evaluated independently (all cores, as every other linear-size
+ * step of the path) and combined by Horner in z^(2^14): the same field value, exact arithmetic */
+void pko_eval_univariate(const u64 *c, size_t n, const u64 z[4], u64 out[4]) {
+    const size_t B = (size_t)1 << 14;
+    if (n <= 2 * B) {
+        horner(c, n, z, out);
+        return;
+    }
+    const size_t nb = (n + B - 1) / B;
+    u64 *part = (u64 *)malloc(32 * nb);
+#pragma omp parallel for schedule(static)
+    for (long b = 0; b < (long)nb; b++) {
+        size_t lo = (size_t)b * B, len = n - lo < B ? n - lo : B;
+        horner(c + 4 * lo, len, z, part + 4 * b);
+    }
+    u64 zB[4];
+    pko_fe_pow(z, (u64)B, zB);
+    horner(part, nb, zB, out);
+    free(part);
 }
 
 /* ------------------------------------------------------------------ */
@@ -771,6 +793,69 @@ u64 pko_pow_solve(const u64 challenge[4], double difficulty) { /* pow.rs:33-41; 
         }
         if (best != ~(u64)0) return best;
     }
+}
+
+/* ------------------------------------------------------------------ */
+/* The proof's random draws.  The reference takes the ZK mask, the random polynomial g and the blinding univariates from
+ * rand's thread_rng (provekit/common/src/utils/zk_utils.rs:13-22, provekit/prover/src/whir_r1cs.rs:197,212-221): ChaCha12 under
+ * an OS-seeded key -- nothing to be bit-exact with.  The HIP library expands ONE 256-bit key per proof with the same cipher
+ * (csrc/prover.hip random_fe_kernel); with an injected key its draws are reproducible, and this is their restatement: elements
+ * 2j and 2j+1 of draw `stream` come from the ChaCha12 blocks (counter = j, nonce = {stream, attempt}), attempt = 0, 1, ...:
+ * words 0..7 / 8..15 masked to 254 bits, accepted iff < p (ark-ff Fp::rand's rejection), stored as they are (a uniform
+ * Montgomery image is a uniform element). */
+/* ------------------------------------------------------------------ */
+#define PKO_QR(a, b, c, d)                          \
+    a += b; d ^= a; d = (d << 16) | (d >> 16);      \
+    c += d; b ^= c; b = (b << 12) | (b >> 20);      \
+    a += b; d ^= a; d = (d << 8) | (d >> 24);       \
+    c += d; b ^= c; b = (b << 7) | (b >> 25)
+void pko_chacha_block(const uint8_t key[32], u64 counter, uint32_t n0, uint32_t n1, int rounds, uint32_t out[16]) { /* RFC 8439 2.3 */
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+    memcpy(s + 4, key, 32);
+    s[12] = (uint32_t)counter;
+    s[13] = (uint32_t)(counter >> 32);
+    s[14] = n0;
+    s[15] = n1;
+    uint32_t x[16];
+    memcpy(x, s, 64);
+    for (int r = 0; r < rounds / 2; r++) {
+        PKO_QR(x[0], x[4], x[8], x[12]);
+        PKO_QR(x[1], x[5], x[9], x[13]);
+        PKO_QR(x[2], x[6], x[10], x[14]);
+        PKO_QR(x[3], x[7], x[11], x[15]);
+        PKO_QR(x[0], x[5], x[10], x[15]);
+        PKO_QR(x[1], x[6], x[11], x[12]);
+        PKO_QR(x[2], x[7], x[8], x[13]);
+        PKO_QR(x[3], x[4], x[9], x[14]);
+    }
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+void pko_random_fe(const uint8_t key[32], uint32_t stream, u64 *out, size_t n) {
+    const size_t pairs = (n + 1) / 2;
+#pragma omp parallel for schedule(static) if (pairs >= 1024)
+    for (long jj = 0; jj < (long)pairs; jj++) {
+        const size_t j = (size_t)jj;
+        int done[2] = {0, 2 * j + 1 >= n};
+        for (uint32_t attempt = 0; !(done[0] && done[1]); attempt++) {
+            uint32_t blk[16];
+            pko_chacha_block(key, (u64)j, stream, attempt, 12, blk);
+            for (int half = 0; half < 2; half++) {
+                if (done[half]) continue;
+                u64 x[4];
+                for (int w = 0; w < 4; w++) x[w] = (u64)blk[8 * half + 2 * w] | ((u64)blk[8 * half + 2 * w + 1] << 32);
+                x[3] &= 0x3fffffffffffffffULL; /* < 2^254 */
+                if (lt(x, P)) {
+                    memcpy(out + 4 * (2 * j + half), x, 32);
+                    done[half] = 1;
+                }
+            }
+        }
+    }
+}
+
+/* opened leaves of a leaf-major codeword as ark-serialize writes them: rows idx[0..k) of leaves (width FEs each), canonical */
+void pko_gather_rows_canonical(const u64 *leaves_mont, size_t width, const u64 *idx, size_t k, u64 *out_canon) {
+    for (size_t q = 0; q < k; q++) pko_fe_from_mont_many(leaves_mont + 4 * width * idx[q], out_canon + 4 * width * q, width);
 }
 
 int pko_num_threads(void) {

@@ -137,6 +137,12 @@ int pko_pow_threshold(double difficulty, uint64_t out[4]);                 /* po
 int pko_pow_verify(const uint64_t challenge[4], double difficulty, uint64_t nonce); /* pow.rs:24-26 */
 uint64_t pko_pow_solve(const uint64_t challenge[4], double difficulty);   /* smallest valid nonce, bias 0.01 */
 
+/* ---- the proof's random draws (restatement of the HIP library's keyed expansion, csrc/prover.hip random_fe_kernel; the reference
+ * draws from thread_rng, zk_utils.rs:13-22) and the opened rows of a codeword, canonical ---- */
+void pko_chacha_block(const uint8_t key[32], uint64_t counter, uint32_t n0, uint32_t n1, int rounds, uint32_t out[16]);
+void pko_random_fe(const uint8_t key[32], uint32_t stream, uint64_t *out, size_t n);
+void pko_gather_rows_canonical(const uint64_t *leaves_mont, size_t width, const uint64_t *idx, size_t k, uint64_t *out_canon);
+
 /* misc */
 int pko_num_threads(void);
 void pko_set_num_threads(int n);

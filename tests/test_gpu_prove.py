@@ -532,3 +532,67 @@ print("PLAIN_AGAIN", scheme.prove(d_z, seed=1) == plain)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.split(" ")[0] in ("SILENT", "REFUSED", "PLAIN_AGAIN")]
     assert lines == ["REFUSED -3 True", "REFUSED -3 True", "PLAIN_AGAIN True"], (lines, out.stderr[-1500:])
+
+
+def _vcfg(c):
+    import verifier as V
+
+    return V.WhirConfig(c.n_vars, c.batch_size, c.folding_factor, c.starting_log_inv_rate, list(c.num_queries), list(c.ood_samples), list(c.pow_bits),
+                        c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
+
+
+@pytest.mark.parametrize("m,m_0,nc,n_in,pow_bits", [(9, 7, 100, 60, 5.0), (12, 9, 500, 700, 4.0), (17, 16, 60000, 5000, 8.0)])
+def test_transcript_equals_the_oracle_provers(ctx, oracle, m, m_0, nc, n_in, pow_bits):
+    """WHOLE-PROOF parity: for the same statement, witness and 32-byte key, pk_prove (HIP kernels + the C++ host driver) and the
+    oracle's prover (oracle/prover_ref.py: the reference's prove restated on the C oracle's kernels, transcript and scalar algebra in
+    Python) must write the same bytes -- every commitment root, OOD answer, sumcheck message, proof-of-work nonce, opened leaf and
+    authentication path, in order.  Also in latency mode."""
+    import prover_ref as PR
+    from test_prover_ref import small_instance
+
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS
+
+    nw, z, coeffs, trips, mats = small_instance(nc, n_in, 31)
+    interner = oracle.to_mont(oracle.ints_to_limbs(coeffs))
+    zm = oracle.to_mont(oracle.ints_to_limbs(z))
+    cfg_w, cfg_b = WhirConfig.for_size(m, pow_bits), blinding_config_for(m_0, pow_bits)
+    r1cs = R1CS(ctx, *(to_sparse(nc, nw, t) for t in trips), interner)
+    scheme = WhirR1CSScheme(ctx, r1cs, m, m_0, cfg_w, cfg_b)
+    d_z = ctx.upload(zm)
+    for seed in (3, 4):
+        want = PR.prove(scheme.domain_separator, m, m_0, _vcfg(cfg_w), _vcfg(cfg_b), (nc, nw, mats, interner), zm, seed.to_bytes(32, "little"))
+        got = scheme.prove(d_z, seed=seed)
+        assert len(got) == len(want)
+        if got != want:
+            first = next(i for i in range(len(got)) if got[i] != want[i])
+            raise AssertionError(f"pk_prove's transcript differs from the oracle prover's from byte {first} of {len(got)}")
+    ctx.set_latency_mode(True)
+    try:
+        assert scheme.prove(d_z, seed=4) == want
+    finally:
+        ctx.set_latency_mode(False)
+    scheme.close()
+    r1cs.close()
+
+
+def test_transcript_equals_the_oracle_provers_at_the_bench_size(ctx, oracle):
+    """the same equality at BASELINE configs[1]'s size (m = 21, m_0 = 20) under the reference's own derived schedule (109 / 28 / 16 / 11
+    queries, grinding up to 19 bits): 260 KB of proof, byte for byte"""
+    import prover_ref as PR
+
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS, SparseMatrix
+
+    m, m_0 = 21, 20
+    nc, nw, mats, interner, z = size_class_instance(oracle, m)
+    cfg_w, cfg_b = WhirConfig.derive(m), blinding_config_for(m_0)
+    r1cs = R1CS(ctx, *(SparseMatrix(nc, nw, *t) for t in mats), interner)
+    scheme = WhirR1CSScheme(ctx, r1cs, m, m_0, cfg_w, cfg_b)
+    stage = {}
+    want = PR.prove(scheme.domain_separator, m, m_0, _vcfg(cfg_w), _vcfg(cfg_b), (nc, nw, mats, interner), z, (11).to_bytes(32, "little"), stage)
+    print("oracle prover stage_s", stage)
+    got = scheme.prove(ctx.upload(z), seed=11)
+    assert len(got) == len(want) and got == want
+    scheme.close()
+    r1cs.close()
