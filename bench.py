@@ -176,14 +176,15 @@ def cpu_baseline(m, m_0, mats, interner, nc, n_wit, cfg_w, cfg_b, domain_separat
                             c.final_queries, c.final_pow_bits, c.commitment_ood_samples, c.final_folding_pow_bits)
 
     r1cs = (nc, n_wit, [(mt.new_row_indices, mt.col_indices, mt.values) for mt in mats], interner)
-    all_threads = PR.L.pko_num_threads()
-    out = {"threads": {}}
+    host = PR.usable_cores()  # the cgroup quota counts, not the CPUs the container can see
+    all_threads = host["usable"]
+    out = {"threads": {}, "host": host}
     spent = 0.0
-    for threads in (all_threads, 16, 1):
+    for threads in (all_threads, 4, 1):
         if threads > all_threads or str(threads) in out["threads"]:
             continue
         # a run at fewer threads takes about all_threads / threads times the parallel part: skip what cannot fit the budget
-        est = out["threads"][str(all_threads)]["s_per_proof"] * min(all_threads / threads, 40.0) * 0.6 if out["threads"] else 0.0
+        est = out["threads"][str(all_threads)]["s_per_proof"] * (all_threads / threads) * 0.8 if out["threads"] else 0.0
         if spent + est > budget_s:
             out["threads"][str(threads)] = {"skipped": f"estimated {est:.0f} s: over the {budget_s:.0f} s budget of this leg (run bench.py --cpu-baseline-budget to raise it)"}
             continue
@@ -541,7 +542,7 @@ def main():
                     help="log2 of the committed polynomial size (poseidon-rounds: 21).  Under torch.distributed.run spell it "
                          "--log2-size: the launcher's own parser rejects --m as an ambiguous abbreviation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-budget", type=float, default=75.0, help="seconds the CPU-baseline leg may spend on its runs at fewer threads (all threads always runs)")
+    ap.add_argument("--cpu-baseline-budget", type=float, default=75.0, help="seconds the CPU-baseline leg may spend on its runs at fewer threads (the run at all usable cores always happens)")
     ap.add_argument("--no-commit-probe", action="store_true", help="skip the secondary 2^26 commit figure (configs[4]) of the default line")
     ap.add_argument("--commit-log2-size", type=int, default=26, help="log2 coefficients of the secondary commit figure (26 = BASELINE configs[4])")
     ap.add_argument("--size-classes", default="23,25",
@@ -995,6 +996,9 @@ def main():
                 "proof_bytes": cb["proof_bytes"],
                 "stage_s": cb["stage_s"],
                 "by_threads": {k: ({"proofs_per_s": v["proofs_per_s"], "s_per_proof": v["s_per_proof"]} if "s_per_proof" in v else v) for k, v in cb["threads"].items()},
+                "host": cb["host"],
+                "cores_note": "cores = what this process may use: min(logical CPUs, affinity, cgroup CPU quota) -- OpenMP threads beyond the quota are throttled and "
+                              "make the run slower (tools/cpu_scaling.py, profiles/r05_cpu_scaling.json)",
             }
         emit(line)
     if hung_any:

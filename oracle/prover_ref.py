@@ -44,6 +44,11 @@ L.pko_gather_rows_canonical.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_
 RNG_MASK, RNG_G, RNG_BLIND, RNG_MASK_B, RNG_G_B = 1, 2, 3, 4, 5  # the `stream` word of a draw (csrc/prover.hip)
 
 
+from hostcores import usable_cores  # noqa: E402
+
+L.pko_set_num_threads(usable_cores()["usable"])  # OpenMP's default is every CPU the container can SEE
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 

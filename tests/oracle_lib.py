@@ -18,6 +18,12 @@ def build():
 
 
 L = C.CDLL(build())
+import sys  # noqa: E402
+
+sys.path.insert(0, ODIR)
+from hostcores import usable_cores  # noqa: E402
+
+L.pko_set_num_threads(usable_cores()["usable"])  # OpenMP's default is every CPU the container can SEE, cgroup quota or not
 L.pko_pow_solve.restype = C.c_uint64
 L.pko_pow_solve.argtypes = [C.c_void_p, C.c_double]
 L.pko_pow_verify.argtypes = [C.c_void_p, C.c_double, C.c_uint64]

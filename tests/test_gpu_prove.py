@@ -594,5 +594,10 @@ def test_transcript_equals_the_oracle_provers_at_the_bench_size(ctx, oracle):
     print("oracle prover stage_s", stage)
     got = scheme.prove(ctx.upload(z), seed=11)
     assert len(got) == len(want) and got == want
+    # ... and the oracle prover's proof is one the oracle verifier accepts, matrix evaluation of the deferred weights included
+    import verifier as V
+
+    assert V.verify(want, scheme.domain_separator, m, m_0, _vcfg(cfg_w), _vcfg(cfg_b), r1cs=oracle.matrix_evaluator(nc, nw, mats, interner))
+    assert abs(sum(v for k, v in stage.items() if k != "total") - stage["total"]) < 0.02 * stage["total"]
     scheme.close()
     r1cs.close()
