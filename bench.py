@@ -372,12 +372,15 @@ def size_class_probe(provekit_amd, torch, local_rank, m, proofs_per_prover=3):
         for t in ths:
             t.join()
 
+    if conc > 1:
+        provekit_amd.Context.set_host_wait(local_rank, True)  # many provers in flight: their host threads sleep while they wait
     wave(900000, 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     wave(1, proofs_per_prover)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    provekit_amd.Context.set_host_wait(local_rank, False)
     singles = []
     for i in range(3):
         t1 = time.perf_counter()
@@ -703,6 +706,10 @@ def main():
 
     # one step = one wave of `conc` proofs (a batch of synthetic statements through the hot path), so any --steps the driver
     # passes measures the steady state of a full chip rather than a ragged tail
+    # throughput mode: the provers' host threads sleep while they wait (pk_device_set_host_wait); the one-at-a-time passes below spin
+    block_wait = conc > 1 and os.environ.get("PK_BENCH_SPIN") != "1"
+    if block_wait:
+        provekit_amd.Context.set_host_wait(local_rank, True)
     run_proofs(100000, args.warmup * conc)
     # hipEvent pairs around the launches of ONE of the `conc` provers (worker 0) during the timed region: the source of the
     # *_under_load figures.  PK_BENCH_NO_TIMED_PROFILE=1 turns it off for an A/B (profiles/r05_timed_profile_ab.json: no
@@ -716,6 +723,8 @@ def main():
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, dist, None if one_gpu else f"cuda:{local_rank}")
     prof = ctx.profile_read()
+    if block_wait:
+        provekit_amd.Context.set_host_wait(local_rank, False)
     # untimed extra pass, one proof at a time on worker 0: isolated kernel durations for the roofline
     # (with several provers in flight the per-launch times above include interference from the other streams)
     ctx.profile(True)
@@ -809,6 +818,8 @@ def main():
             return None
         try:
             args.h2d = True
+            if block_wait:
+                provekit_amd.Context.set_host_wait(local_rank, True)
             run_proofs(200000, 2 * conc)
             barrier()
             t1 = time.perf_counter()
@@ -820,6 +831,8 @@ def main():
             return None
         finally:
             args.h2d = False
+            if block_wait:
+                provekit_amd.Context.set_host_wait(local_rank, False)
 
     # Order.  One GPU: the commit probe first (before anything else allocates and releases large buffers in this process), the h2d probe last.
     # Several ranks: every figure that needs only torch's collectives first, then the sharded commit -- the one step of this file that goes
@@ -914,6 +927,7 @@ def main():
                             f"queries {cfg_w.num_queries}/{cfg_w.final_queries}, pow_bits {cfg_w.pow_bits}/{cfg_w.final_pow_bits} (WhirConfig::new derivation, security 128, "
                             f"ConjectureList), blinding WHIR n={cfg_b.n_vars} queries {cfg_b.num_queries}/{cfg_b.final_queries}, Skyscraper-sponge transcript, ChaCha12 masks",
                 "proofs_per_step": conc * (1 if args.sharded else world),
+                "host_wait": "blocking (pk_device_set_host_wait: the provers' host threads sleep on the completion interrupt)" if block_wait else "spinning (HIP default)",
                 "profiling_in_timed_region": (f"hipEvent pairs around the launches of 1 of the {conc} provers per GPU" if timed_profile else False),
                 "launcher": ("bench.py --gpus N started its own ranks (torch.distributed.run, 127.0.0.1)" if os.environ.get("PK_BENCH_SELF_LAUNCHED") else
                              ("torch.distributed.run" if dist is not None else "single process")),

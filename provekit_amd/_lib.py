@@ -55,6 +55,7 @@ LEAVES_MONTGOMERY, LEAVES_SCALED32 = 0, 1
 SIGNATURES = {
     "pk_abi_version": (C.c_int, []),
     "pk_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pk_device_set_host_wait": (C.c_int, [C.c_int, C.c_int]),
     "pk_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "pk_ctx_destroy": (C.c_int, [vp]),
     "pk_last_error": (C.c_char_p, [vp]),

@@ -21,6 +21,16 @@ int pk_device_count(int* n) {
     return PK_OK;
 }
 
+int pk_device_set_host_wait(int device, int mode) {
+    if (mode != PK_WAIT_SPIN && mode != PK_WAIT_BLOCK) return PK_ERR_BAD_ARG;
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    if (hipSetDevice(device) != hipSuccess) return PK_ERR_BAD_ARG;
+    const hipError_t e = hipSetDeviceFlags(mode == PK_WAIT_BLOCK ? hipDeviceScheduleBlockingSync : hipDeviceScheduleSpin);
+    if (have) (void)hipSetDevice(cur);
+    return e == hipSuccess ? PK_OK : PK_ERR_HIP;
+}
+
 int pk_ctx_create(int device, pk_ctx** out) {
     if (!out) return PK_ERR_BAD_ARG;
     *out = nullptr;
@@ -36,6 +46,10 @@ int pk_ctx_create(int device, pk_ctx** out) {
         return PK_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    {   // PK_HOST_WAIT=block|spin: pk_device_set_host_wait for callers that cannot reach the API (A/B runs, tools/cpuuse.py)
+        const char* w = getenv("PK_HOST_WAIT");
+        if (w && *w) (void)pk_device_set_host_wait(device, w[0] == 'b' ? PK_WAIT_BLOCK : PK_WAIT_SPIN);
+    }
     pk::ntt_retain_ctx(ctx);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)

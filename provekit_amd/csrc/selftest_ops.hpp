@@ -17,7 +17,7 @@ inline fe load_host(const uint64_t* p) {
 }
 inline void store_host(uint64_t* p, const fe& x) { memcpy(p, x.v, 32); }
 
-PK_HD inline fe selftest_op(int op, const fe& x, const fe& y) {
+PK_HD fe selftest_op(int op, const fe& x, const fe& y) {
     fe r = x;
     switch (op) {
         case 0: r = fe_mul29(x, y); break;

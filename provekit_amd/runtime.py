@@ -101,6 +101,14 @@ class Context:
         self._check(lib.pk_comm_destroy(self.handle))
 
     @staticmethod
+    def set_host_wait(device: int, block: bool):
+        """pk_device_set_host_wait: how host threads wait for `device` -- block=True sleeps on the completion interrupt (many provers per
+        GPU, few host cores), False spins (HIP's default; one proof at a time)"""
+        rc = lib.pk_device_set_host_wait(device, 1 if block else 0)
+        if rc != 0:
+            raise ProveKitHipError(rc, "pk_device_set_host_wait failed")
+
+    @staticmethod
     def rccl_version():
         """(ncclGetVersion code, name the library was opened by) of the RCCL behind the "rccl" transport (pk_comm_rccl_version)"""
         v, path = C.c_int(), C.create_string_buffer(512)
