@@ -142,6 +142,34 @@ pub fn whir_config_to_c(c: &WhirConfig) -> Result<sys::pk_whir_config> {
     Ok(out)
 }
 
+/// `HipProver::new` refused the scheme's `create_io_pattern()`: the whole-proof entry point (`pk_prove`) performs another sequence
+/// of transcript operations than this build of whir / spongefish declares.  The library's schedule of whir's part was restated from
+/// the Go verifier, not from whir itself, so a skew is a possibility a caller must be able to survive:
+/// `prover_for` catches exactly this error and falls back to the step-wise prover, which lets whir's own prover drive the
+/// transcript and so cannot disagree with it.
+#[derive(Debug)]
+pub struct IoPatternMismatch(pub String);
+impl std::fmt::Display for IoPatternMismatch {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        write!(f, "the scheme's IO pattern does not match the HIP prover's operation schedule: {}", self.0)
+    }
+}
+impl std::error::Error for IoPatternMismatch {}
+
+/// The prover to use for `scheme`: the whole-proof backend (`HipProver`: one FFI call per proof) when the reference's IO pattern
+/// matches its schedule op by op, otherwise -- with a warning that names the first differing operation -- the step-wise backend
+/// (`stepwise::StepProver`: whir's own prover over the device kernels).  Any other construction error is returned as it is.
+pub fn prover_for<'a>(ctx: &'a HipContext, scheme: &'a WhirR1CSScheme, r1cs: &R1CS) -> Result<Box<dyn WhirR1CSProver + 'a>> {
+    match HipProver::new(ctx, scheme, r1cs) {
+        Ok(p) => Ok(Box::new(p)),
+        Err(e) if e.downcast_ref::<IoPatternMismatch>().is_some() => {
+            tracing::warn!("{e}; falling back to the step-wise HIP prover");
+            Ok(Box::new(stepwise::StepProver::new(ctx, scheme, r1cs)?))
+        }
+        Err(e) => Err(e),
+    }
+}
+
 /// `WhirR1CSProver` for a scheme bound to one device context and one uploaded R1CS.
 pub struct HipProver<'a> {
     ctx: &'a HipContext,
@@ -165,8 +193,12 @@ impl<'a> HipProver<'a> {
         // the reference's own IO pattern: its bytes fix the sponge IV, its operations are checked against pk_prove's
         let io = scheme.create_io_pattern();
         let bytes = io.as_bytes();
-        ctx.check(unsafe { sys::pk_scheme_set_io_pattern(ctx.raw, raw, bytes.as_ptr(), bytes.len()) })
-            .context("the scheme's IO pattern does not match the HIP prover's operation schedule")?;
+        let rc = unsafe { sys::pk_scheme_set_io_pattern(ctx.raw, raw, bytes.as_ptr(), bytes.len()) };
+        if rc != sys::PK_OK {
+            // pk_last_error names the first operation that differs ("operation #k is ..., the prover performs ...")
+            let why = unsafe { CStr::from_ptr(sys::pk_last_error(ctx.raw)) }.to_string_lossy().into_owned();
+            return Err(anyhow::Error::new(IoPatternMismatch(why)));
+        }
         Ok(this)
     }
 

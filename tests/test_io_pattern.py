@@ -90,3 +90,33 @@ def test_verifier_enforces_the_pattern():
     assert not A.done()
     A.next_scalars(1)
     assert A.done()
+
+
+def test_reference_pattern_bytes():
+    """Closes DESIGN 6's open item the day somebody with a Rust toolchain runs tools/print_io_pattern.rs in the reference checkout and
+    drops its output into tests/golden/reference_io_pattern.hex: line 1 = WhirR1CSScheme::create_io_pattern().as_bytes() for
+    poseidon-1000.nps (provekit/common/src/whir_r1cs.rs:28-39), lines 2-4 = the first three challenges the reference's verifier
+    state squeezes after absorbing the proof's first scalar.  Until then: skipped (this image has no cargo)."""
+    path = os.path.join(ROOT, "tests", "golden", "reference_io_pattern.hex")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/reference_io_pattern.hex not present: run tools/print_io_pattern.rs where cargo exists")
+    import json
+
+    import verifier as V
+
+    lines = [l.strip() for l in open(path) if l.strip()]
+    pattern, want = bytes.fromhex(lines[0]), [int.from_bytes(bytes.fromhex(h), "little") for h in lines[1:4]]
+    m, m_0 = 21, 20  # poseidon-1000 (SURVEY Appendix A)
+    cw, cb = WhirConfig.for_size(m), blinding_config_for(m_0)
+    # (a) the library takes the reference's pattern: same operations, whatever the labels
+    assert io_pattern_check(pattern, m_0, cw, cb) == ""
+    # (b) is the library's own restatement the same bytes?  (a difference in labels only is reported, not failed: (a) and (c) decide)
+    ours = create_io_pattern(m_0, cw, cb)
+    if ours != pattern:
+        print("library restatement differs from the reference pattern (labels):", ours[:200], pattern[:200])
+    # (c) IV derivation + permutation: the reference's first three challenges from its own proof's first 32 bytes
+    fixture = json.load(open(os.path.join(ROOT, "tests", "golden", "fixture_whir.json")))
+    root = bytes.fromhex(fixture["blinding_whir"]["transcript_prefix_hex"][:64])  # the reference proof's first 32 bytes: the witness root
+    A = V.Arthur(pattern, root)
+    A.next_scalars(1)
+    assert A.challenge_scalars(3) == want, "the sponge (IV from the pattern bytes, Skyscraper permutation) disagrees with the reference's"
