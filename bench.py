@@ -339,6 +339,65 @@ def rccl_probe(provekit_amd, torch, rank, local_rank, world, dist, one_gpu, grou
     return out
 
 
+def sharded_proof_probe(provekit_amd, torch, rank, local_rank, world, dist, one_gpu, groups, mm, reps=3):
+    """BASELINE configs[3] under several ranks: ONE proof of the m = `mm` size class (the p256 class: 25) sharded over ALL ranks of the
+    run behind the C ABI -- every commit split by leaf index with an all-gather of leaf digests, inner trees by contiguous subtree,
+    sumcheck tables / weights / OOD evaluations by blocks, opened rows collected from their owners -- strong scaling, the launcher
+    contract's clock (barrier, wall time, max over ranks).  Rank 0 also proves the same statement alone with the same key: the two
+    proof strings must be the same bytes."""
+    import hashlib
+
+    from provekit_amd.device_set import max_over_ranks
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+
+    m_0, n_wit = mm - 1, (1 << (mm - 1)) - 5
+    cfg_w, cfg_b = WhirConfig.derive(mm), blinding_config_for(m_0)
+    dev = None if one_gpu else f"cuda:{local_rank}"
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx = provekit_amd.Context(local_rank)
+    r1cs, _, _, nc, n_in = synth_r1cs(ctx, m_0, n_wit, seed=4321 + mm)  # the same statement and witness on every rank
+    d_z, z_host = satisfying_witness(ctx, r1cs, n_wit, nc, n_in, 7 + mm)
+    lone_ms, lone_proof = None, None
+    if rank == 0:  # the lone prover first, on a context without a communicator
+        lone = WhirR1CSScheme(ctx, r1cs, mm, m_0, cfg_w, cfg_b)
+        lone.prove_nocopy(d_z, seed=1)
+        ts = []
+        for i in range(reps):
+            t0 = time.perf_counter()
+            lone_proof = lone.prove(d_z, seed=2 + i)
+            ts.append(time.perf_counter() - t0)
+        lone_ms = 1e3 * sorted(ts)[len(ts) // 2]
+        lone.close()
+    keep = join_subgroup(ctx, rank, world, dist, one_gpu, groups)  # noqa: F841 (kept alive); from here on this context shards
+    prover = WhirR1CSScheme(ctx, r1cs, mm, m_0, cfg_w, cfg_b)
+    prover.prove_nocopy(d_z, seed=1)
+    ts, proof = [], None
+    for i in range(reps):
+        barrier()
+        t0 = time.perf_counter()
+        proof = prover.prove(d_z, seed=2 + i)
+        barrier()
+        ts.append(max_over_ranks(time.perf_counter() - t0, dist, dev))
+    ms = 1e3 * sorted(ts)[len(ts) // 2]
+    out = {"workload": f"one proof of the m={mm} size class ({nc} constraints, {n_wit} witnesses, derived schedule) sharded over {world} ranks "
+                       f"({'host-transport, single-GPU development mode' if one_gpu else 'RCCL over xGMI'}); wall clock, max over ranks, median of {reps}",
+           "m": mm, "n_gpus": world, "scaling": "strong", "ms_per_proof": ms, "proofs_per_s": 1e3 / ms, "one_gpu_ms_per_proof": lone_ms,
+           "speedup_vs_one_gpu": (lone_ms / ms) if lone_ms else None, "proof_bytes": len(proof), "proof_sha256_16": hashlib.sha256(proof).hexdigest()[:16],
+           "equals_the_lone_provers_transcript": (proof == lone_proof) if rank == 0 else None}
+    prover.close()
+    ctx.comm_destroy()
+    d_z.free()
+    r1cs.close()
+    ctx.close()
+    torch.cuda.empty_cache()
+    return out
+
+
 def size_class_probe(provekit_amd, torch, local_rank, m, proofs_per_prover=3):
     """Secondary figure of the default line: another BASELINE size class (configs[2]: m = 23, configs[3]: m = 25) on this GPU --
     the reference's own derived WHIR schedule for that size, a satisfiable synthetic R1CS of the same construction as the bench's
@@ -544,6 +603,8 @@ def main():
     ap.add_argument("--m", "--log2-size", dest="m", type=int, default=21,
                     help="log2 of the committed polynomial size (poseidon-rounds: 21).  Under torch.distributed.run spell it "
                          "--log2-size: the launcher's own parser rejects --m as an ambiguous abbreviation")
+    ap.add_argument("--no-sharded-proof", action="store_true", help="under several ranks: skip the secondary figure 'one proof of the p256 size class sharded over all ranks'")
+    ap.add_argument("--sharded-proof-log2-size", type=int, default=25, help="size class of that figure (25 = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-budget", type=float, default=75.0, help="seconds the CPU-baseline leg may spend on its runs at fewer threads (the run at all usable cores always happens)")
     ap.add_argument("--no-commit-probe", action="store_true", help="skip the secondary 2^26 commit figure (configs[4]) of the default line")
@@ -838,7 +899,7 @@ def main():
     # Several ranks: every figure that needs only torch's collectives first, then the sharded commit -- the one step of this file that goes
     # through the library's own RCCL communicator -- under a watchdog: if it does not come back, the line is printed without it and the
     # process leaves without another collective, so a stuck communicator can cost the run that one figure and nothing else.
-    h2d_rate = None
+    h2d_rate, sharded_fig = None, None
     if world > 1 and not comm_ok:
         h2d_rate = run_h2d_probe()  # torch's collectives only
         commit_fig = {"error": "skipped: the library's communicator did not pass its probe on every rank (see `rccl`)"}
@@ -849,13 +910,19 @@ def main():
         def guarded():
             torch.cuda.set_device(local_rank)  # the current device is per thread
             box.update(fig=run_commit_probe())
+            if m == 21 and not args.no_sharded_proof and (world & (world - 1)) == 0 and world <= 16 and not (box.get("fig") or {}).get("error"):
+                try:  # configs[3]: one proof of the p256 size class sharded over all ranks (every rank takes the same branch: the commit figure is rank-independent)
+                    box.update(sharded=sharded_proof_probe(provekit_amd, torch, rank, local_rank, world, dist, one_gpu, groups, args.sharded_proof_log2_size))
+                except Exception as e:  # noqa: BLE001
+                    box.update(sharded={"error": str(e)[:300]})
 
         th = threading.Thread(target=guarded, daemon=True)
         th.start()
-        th.join(float(os.environ.get("PK_BENCH_COMMIT_LIMIT_S", "240")))
+        th.join(float(os.environ.get("PK_BENCH_COMMIT_LIMIT_S", "420")))
         hung = th.is_alive()
         hung_any = max_over_ranks(1.0 if hung else 0.0, dist, dev_for_flags) > 0
-        commit_fig = {"error": "the sharded commit did not return within its limit on some rank; skipped"} if hung_any else box.get("fig")
+        commit_fig = {"error": "the sharded commit / proof did not return within its limit on some rank; skipped"} if hung_any else box.get("fig")
+        sharded_fig = None if hung_any else box.get("sharded")
     else:
         commit_fig = run_commit_probe()
     # (c) the other BASELINE size classes (configs[2] m = 23, configs[3] m = 25), rank 0's GPU only
@@ -990,6 +1057,8 @@ def main():
             line["rccl"] = rccl_fig
         if commit_fig is not None:
             line["commit_2p26" if args.commit_log2_size == 26 else f"commit_2p{args.commit_log2_size}"] = commit_fig
+        if sharded_fig is not None:
+            line[f"sharded_proof_m{args.sharded_proof_log2_size}"] = sharded_fig
         if size_figs:
             line["size_classes"] = size_figs
         if not args.no_cpu_baseline and world == 1:

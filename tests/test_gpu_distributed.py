@@ -87,7 +87,7 @@ def _check_multirank_bench(ctx, one_gpu):
     # proofs/s): the commit probe runs SHARDED over the ranks (north_star's strong-scaling curve; here 2^17 instead of 2^26 to
     # keep the test short) and gives the unsharded root; the PCIe-inclusive rate is a second timed pass
     m2 = 17
-    q = launch(["--workload", "prove", "--concurrency", "2", "--no-cpu-baseline", "--commit-log2-size", str(m2), "--size-classes", ""])
+    q = launch(["--workload", "prove", "--concurrency", "2", "--no-cpu-baseline", "--commit-log2-size", str(m2), "--size-classes", "", "--sharded-proof-log2-size", "16"])
     assert q["n_gpus"] == 2 and q["scaling"] == "weak" and q["h2d_inclusive_proofs_per_s"] > 0
     cp = q[f"commit_2p{m2}"]
     assert cp["n_gpus"] == 2 and cp["scaling"] == "strong" and cp["ms_per_commit"] > 0 and "sharded by leaf index over 2 ranks" in cp["workload"]
@@ -105,6 +105,9 @@ def _check_multirank_bench(ctx, one_gpu):
     assert cp["curve"]["1"]["transport"] == "none" and cp["curve"]["2"]["transport"] == ("host" if one_gpu else "rccl")
     assert q["rccl"]["world"] == 2 and q["rccl"]["ranks_seen"] == [0, 1] and q["rccl"]["transport"] == ("host" if one_gpu else "rccl")
     assert q["rccl"]["allgather_32MiB_us"] > 0
+    # ... and configs[3]'s shape: one proof sharded over the two ranks, the same bytes as the lone prover's
+    sp = q["sharded_proof_m16"]
+    assert sp["n_gpus"] == 2 and sp["scaling"] == "strong" and sp["ms_per_proof"] > 0 and sp["equals_the_lone_provers_transcript"] is True
     # latency mode: one proof at a time sharded over the two ranks (commits of >= 64 rows per rank split by leaf index)
     sh = launch(["--workload", "prove", "--sharded", "--log2-size", "15", "--no-cpu-baseline"])
     assert sh["n_gpus"] == 2 and sh["scaling"] == "strong" and sh["config"]["proofs_per_step"] == 1 and sh["value"] > 0
@@ -128,7 +131,7 @@ def test_bench_gpus_2_without_a_launcher():
     root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
     env["PK_BENCH_ONE_GPU"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(root_dir, "bench.py"), "--gpus", "2", "--steps", "2", "--size-classes", "", "--no-cpu-baseline"],
+    out = subprocess.run([sys.executable, os.path.join(root_dir, "bench.py"), "--gpus", "2", "--steps", "2", "--size-classes", "", "--no-cpu-baseline", "--sharded-proof-log2-size", "19"],
                          env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -140,6 +143,7 @@ def test_bench_gpus_2_without_a_launcher():
     c = d["commit_2p26"]
     assert c["n_gpus"] == 2 and c["scaling"] == "strong" and sorted(c["curve"]) == ["1", "2"] and c["roots_agree"]
     assert c["root"].startswith("592836a1")  # the 2^26 root every round has reported
+    assert d["sharded_proof_m19"]["n_gpus"] == 2 and d["sharded_proof_m19"]["equals_the_lone_provers_transcript"] is True
 
 
 def test_bench_gpus_more_than_present_is_clamped():
