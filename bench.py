@@ -431,15 +431,12 @@ def size_class_probe(provekit_amd, torch, local_rank, m, proofs_per_prover=3):
         for t in ths:
             t.join()
 
-    if conc > 1:
-        provekit_amd.Context.set_host_wait(local_rank, True)  # many provers in flight: their host threads sleep while they wait
     wave(900000, 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     wave(1, proofs_per_prover)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    provekit_amd.Context.set_host_wait(local_rank, False)
     singles = []
     for i in range(3):
         t1 = time.perf_counter()
@@ -603,6 +600,9 @@ def main():
     ap.add_argument("--m", "--log2-size", dest="m", type=int, default=21,
                     help="log2 of the committed polynomial size (poseidon-rounds: 21).  Under torch.distributed.run spell it "
                          "--log2-size: the launcher's own parser rejects --m as an ambiguous abbreviation")
+    ap.add_argument("--host-wait", choices=["auto", "spin", "block"], default="auto",
+                    help="how the provers' host threads wait for the GPU: spin (HIP default), block (sleep on the interrupt), auto = block only when this "
+                         "rank's share of the usable host cores is smaller than its number of provers")
     ap.add_argument("--no-sharded-proof", action="store_true", help="under several ranks: skip the secondary figure 'one proof of the p256 size class sharded over all ranks'")
     ap.add_argument("--sharded-proof-log2-size", type=int, default=25, help="size class of that figure (25 = BASELINE configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -637,6 +637,11 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return self_launch(args)
 
+    if os.environ.get("PK_BENCH_DUMP_AFTER_S"):  # debugging aid: every thread's Python stack on stderr after N seconds (a hang shows where)
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["PK_BENCH_DUMP_AFTER_S"]), repeat=False, file=sys.stderr)
+
     # stdout carries exactly one JSON line: libraries that print banners there (RCCL's version block at communicator
     # creation) are sent to stderr for the duration of the run
     global _STDOUT_FD
@@ -659,6 +664,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
 
+    if not torch.cuda.is_available():  # (also: torch's HIP runtime initialises before this library's first call)
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    import provekit_amd
+
+    # How the provers' host threads wait for the device, decided ONCE, before torch or this library creates a stream on the device (the mode must not change while
+    # work is in flight: a wait that blocks on a signal created for polling never wakes -- measured as a hang).  Spinning is
+    # HIP's default and the fastest for one proof at a time; it costs a busy core per waiting thread, so when the cores this process may use
+    # (cgroup quota / ranks on this node) are fewer than the provers it runs, the threads sleep on the completion interrupt instead.
+    from provekit_amd.hostinfo import usable_cores
+
+    cores = usable_cores()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    cores_per_rank = cores["usable"] / max(local_world, 1)
+    block_wait = args.host_wait == "block" or (args.host_wait == "auto" and cores_per_rank < (1 if args.sharded else args.concurrency))
+    if block_wait:
+        provekit_amd.Context.set_host_wait(local_rank, True)
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("PK_BENCH_FORCE_DIST"):
         # launched by torch.distributed.run: one rank per GPU over RCCL ("nccl" is RCCL on ROCm)
@@ -669,6 +690,17 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # a process group of its own for the watchdogs' verdicts ("did a guarded step hang on some rank?"): the stuck thread may sit inside a
+    # collective of the default group, where a second collective from the main thread would pair with the wrong operation on the peers
+    flags_group = dist.new_group(backend="gloo") if dist is not None else None
+
+    def any_rank(flag):
+        if dist is None:
+            return bool(flag)
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=flags_group)
+        return t.item() > 0
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
 
@@ -762,15 +794,11 @@ def main():
     dev_for_flags = None if one_gpu else f"cuda:{local_rank}"
     # the ranks must agree on what happens next (a rank that skips a collective the others enter would hang them): flags travel over the
     # launcher's process group, which is torch's own communicator, not the library's
-    hung_any = max_over_ranks(1.0 if hung else 0.0, dist, dev_for_flags) > 0
-    comm_ok = not hung_any and not max_over_ranks(1.0 if (rccl_fig or {}).get("error") else 0.0, dist, dev_for_flags) > 0
+    hung_any = any_rank(hung)
+    comm_ok = not hung_any and not any_rank((rccl_fig or {}).get("error"))
 
     # one step = one wave of `conc` proofs (a batch of synthetic statements through the hot path), so any --steps the driver
     # passes measures the steady state of a full chip rather than a ragged tail
-    # throughput mode: the provers' host threads sleep while they wait (pk_device_set_host_wait); the one-at-a-time passes below spin
-    block_wait = conc > 1 and os.environ.get("PK_BENCH_SPIN") != "1"
-    if block_wait:
-        provekit_amd.Context.set_host_wait(local_rank, True)
     run_proofs(100000, args.warmup * conc)
     # hipEvent pairs around the launches of ONE of the `conc` provers (worker 0) during the timed region: the source of the
     # *_under_load figures.  PK_BENCH_NO_TIMED_PROFILE=1 turns it off for an A/B (profiles/r05_timed_profile_ab.json: no
@@ -784,8 +812,6 @@ def main():
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, dist, None if one_gpu else f"cuda:{local_rank}")
     prof = ctx.profile_read()
-    if block_wait:
-        provekit_amd.Context.set_host_wait(local_rank, False)
     # untimed extra pass, one proof at a time on worker 0: isolated kernel durations for the roofline
     # (with several provers in flight the per-launch times above include interference from the other streams)
     ctx.profile(True)
@@ -879,8 +905,6 @@ def main():
             return None
         try:
             args.h2d = True
-            if block_wait:
-                provekit_amd.Context.set_host_wait(local_rank, True)
             run_proofs(200000, 2 * conc)
             barrier()
             t1 = time.perf_counter()
@@ -892,8 +916,6 @@ def main():
             return None
         finally:
             args.h2d = False
-            if block_wait:
-                provekit_amd.Context.set_host_wait(local_rank, False)
 
     # Order.  One GPU: the commit probe first (before anything else allocates and releases large buffers in this process), the h2d probe last.
     # Several ranks: every figure that needs only torch's collectives first, then the sharded commit -- the one step of this file that goes
@@ -920,7 +942,7 @@ def main():
         th.start()
         th.join(float(os.environ.get("PK_BENCH_COMMIT_LIMIT_S", "420")))
         hung = th.is_alive()
-        hung_any = max_over_ranks(1.0 if hung else 0.0, dist, dev_for_flags) > 0
+        hung_any = any_rank(hung)
         commit_fig = {"error": "the sharded commit / proof did not return within its limit on some rank; skipped"} if hung_any else box.get("fig")
         sharded_fig = None if hung_any else box.get("sharded")
     else:
@@ -994,7 +1016,8 @@ def main():
                             f"queries {cfg_w.num_queries}/{cfg_w.final_queries}, pow_bits {cfg_w.pow_bits}/{cfg_w.final_pow_bits} (WhirConfig::new derivation, security 128, "
                             f"ConjectureList), blinding WHIR n={cfg_b.n_vars} queries {cfg_b.num_queries}/{cfg_b.final_queries}, Skyscraper-sponge transcript, ChaCha12 masks",
                 "proofs_per_step": conc * (1 if args.sharded else world),
-                "host_wait": "blocking (pk_device_set_host_wait: the provers' host threads sleep on the completion interrupt)" if block_wait else "spinning (HIP default)",
+                "host_wait": ("blocking (pk_device_set_host_wait: the provers' host threads sleep on the completion interrupt)" if block_wait else "spinning (HIP default)")
+                             + f"; {cores['usable']} usable host cores (logical {cores['logical_cpus']}, cgroup quota {cores['cgroup_cpu_quota']}) for {local_world} rank(s) on this node",
                 "profiling_in_timed_region": (f"hipEvent pairs around the launches of 1 of the {conc} provers per GPU" if timed_profile else False),
                 "launcher": ("bench.py --gpus N started its own ranks (torch.distributed.run, 127.0.0.1)" if os.environ.get("PK_BENCH_SELF_LAUNCHED") else
                              ("torch.distributed.run" if dist is not None else "single process")),

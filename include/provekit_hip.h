@@ -68,7 +68,9 @@ int pk_device_count(int *n);
  * proof at a time.  PK_WAIT_BLOCK: the thread sleeps until the completion interrupt -- right for many provers per GPU: with 16
  * provers in flight spinning burns 16 cores for nothing, and on a host that grants fewer (a container CPU quota) the throttling
  * stalls every prover (measured: 24 provers under a 16-CPU quota, 186 proofs/s spinning, 257 blocking).
- * Process-wide for the device (hipSetDeviceFlags), may be changed at any time; affects waits that start afterwards. */
+ * Process-wide for the device (hipSetDeviceFlags).  Choose it BEFORE creating contexts on the device and leave it: the runtime builds
+ * its completion signals for the mode in force, and a wait that blocks on a signal made for polling never wakes (measured: switching
+ * to blocking while provers were running hung one of them in its next synchronisation). */
 #define PK_WAIT_SPIN 0
 #define PK_WAIT_BLOCK 1
 int pk_device_set_host_wait(int device, int mode);

@@ -103,7 +103,8 @@ class Context:
     @staticmethod
     def set_host_wait(device: int, block: bool):
         """pk_device_set_host_wait: how host threads wait for `device` -- block=True sleeps on the completion interrupt (many provers per
-        GPU, few host cores), False spins (HIP's default; one proof at a time)"""
+        GPU, few host cores), False spins (HIP's default; one proof at a time).  Call it before creating contexts on the device and do
+        not change it while work is in flight."""
         rc = lib.pk_device_set_host_wait(device, 1 if block else 0)
         if rc != 0:
             raise ProveKitHipError(rc, "pk_device_set_host_wait failed")
