@@ -576,15 +576,17 @@ def test_transcript_equals_the_oracle_provers(ctx, oracle, m, m_0, nc, n_in, pow
     r1cs.close()
 
 
-def test_transcript_equals_the_oracle_provers_at_the_bench_size(ctx, oracle):
+@pytest.mark.parametrize("m", [21, 23])
+def test_transcript_equals_the_oracle_provers_at_the_bench_size(ctx, oracle, m):
     """the same equality at BASELINE configs[1]'s size (m = 21, m_0 = 20) under the reference's own derived schedule (109 / 28 / 16 / 11
-    queries, grinding up to 19 bits): 260 KB of proof, byte for byte"""
+    queries, grinding up to 19 bits): 260 KB of proof, byte for byte -- and at configs[2]'s size class (m = 23: 2^20-leaf trees, three-pass
+    NTTs, five WHIR rounds)"""
     import prover_ref as PR
 
     from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
     from provekit_amd.sparse_matrix import R1CS, SparseMatrix
 
-    m, m_0 = 21, 20
+    m_0 = m - 1
     nc, nw, mats, interner, z = size_class_instance(oracle, m)
     cfg_w, cfg_b = WhirConfig.derive(m), blinding_config_for(m_0)
     r1cs = R1CS(ctx, *(SparseMatrix(nc, nw, *t) for t in mats), interner)
