@@ -686,17 +686,26 @@ def main():
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: gloo need not resolve the container's hostname to find an interface
         if one_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     # a process group of its own for the watchdogs' verdicts ("did a guarded step hang on some rank?"): the stuck thread may sit inside a
     # collective of the default group, where a second collective from the main thread would pair with the wrong operation on the peers
-    flags_group = dist.new_group(backend="gloo") if dist is not None else None
+    flags_group = None
+    if dist is not None:
+        try:
+            flags_group = dist.new_group(backend="gloo")
+        except Exception as e:  # noqa: BLE001 -- e.g. no interface gloo can bind: the verdicts then travel over the default group
+            print(f"[bench] no gloo group for the watchdogs' verdicts ({str(e)[:120]}): using the default group", file=sys.stderr)
 
     def any_rank(flag):
         if dist is None:
             return bool(flag)
+        if flags_group is None:
+            return max_over_ranks(1.0 if flag else 0.0, dist, None if one_gpu else f"cuda:{local_rank}") > 0
         t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=flags_group)
         return t.item() > 0
