@@ -603,3 +603,51 @@ def test_transcript_equals_the_oracle_provers_at_the_bench_size(ctx, oracle, m):
     assert abs(sum(v for k, v in stage.items() if k != "total") - stage["total"]) < 0.02 * stage["total"]
     scheme.close()
     r1cs.close()
+
+
+def test_blocking_host_wait_gives_the_same_proofs(ctx, oracle):
+    """pk_device_set_host_wait(PK_WAIT_BLOCK) -- prover threads sleep on the completion interrupt instead of spinning -- chosen before any
+    context exists (a fresh process): four provers in flight write the transcripts this process's spinning prover writes"""
+    import hashlib
+    import subprocess
+
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.sparse_matrix import R1CS
+
+    m, m_0, nc, n_in = 12, 9, 500, 700
+    nw, z, coeffs, trips = satisfiable_r1cs(nc, n_in, 31)
+    r1cs = R1CS(ctx, *(to_sparse(nc, nw, t) for t in trips), oracle.to_mont(oracle.ints_to_limbs(coeffs)))
+    scheme = WhirR1CSScheme(ctx, r1cs, m, m_0, WhirConfig.for_size(m, 4.0), blinding_config_for(m_0, 4.0))
+    d_z = ctx.upload(oracle.to_mont(oracle.ints_to_limbs(z)))
+    want = [hashlib.sha256(scheme.prove(d_z, seed=s)).hexdigest() for s in range(1, 9)]
+    scheme.close()
+    r1cs.close()
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = r'''
+import sys, threading, hashlib
+sys.path[:0] = [%r, %r]
+import torch; torch.cuda.is_available()
+import oracle_lib as oracle
+import provekit_amd
+provekit_amd.Context.set_host_wait(0, True)   # before the first context of this process
+from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+from provekit_amd.sparse_matrix import R1CS
+from test_gpu_prove import satisfiable_r1cs, to_sparse
+m, m_0, nc, n_in = 12, 9, 500, 700
+nw, z, coeffs, trips = satisfiable_r1cs(nc, n_in, 31)
+out = {}
+def work(w):
+    c = provekit_amd.Context(0)
+    r1cs = R1CS(c, *(to_sparse(nc, nw, t) for t in trips), oracle.to_mont(oracle.ints_to_limbs(coeffs)))
+    s = WhirR1CSScheme(c, r1cs, m, m_0, WhirConfig.for_size(m, 4.0), blinding_config_for(m_0, 4.0))
+    d = c.upload(oracle.to_mont(oracle.ints_to_limbs(z)))
+    for seed in (2 * w + 1, 2 * w + 2):
+        out[seed] = hashlib.sha256(s.prove(d, seed=seed)).hexdigest()
+ths = [threading.Thread(target=work, args=(w,)) for w in range(4)]
+[t.start() for t in ths]; [t.join() for t in ths]
+print("HASHES", " ".join(out[s] for s in range(1, 9)))
+''' % (os.path.dirname(here), here)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    got = [l for l in res.stdout.splitlines() if l.startswith("HASHES ")][-1].split()[1:]
+    assert got == want
