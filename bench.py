@@ -790,6 +790,8 @@ def main():
 
         def probe():
             torch.cuda.set_device(local_rank)  # the current device is per thread
+            if os.environ.get("PK_BENCH_TEST_HANG") == "probe":  # test hook: a communicator that never forms
+                threading.Event().wait()
             try:
                 box.update(fig=rccl_probe(provekit_amd, torch, rank, local_rank, world, dist, one_gpu, groups))
             except Exception as e:  # noqa: BLE001
@@ -940,6 +942,8 @@ def main():
         box = {}
         def guarded():
             torch.cuda.set_device(local_rank)  # the current device is per thread
+            if os.environ.get("PK_BENCH_TEST_HANG") == "commit":  # test hook: a sharded step that never comes back
+                threading.Event().wait()
             box.update(fig=run_commit_probe())
             if m == 21 and not args.no_sharded_proof and (world & (world - 1)) == 0 and world <= 16 and not (box.get("fig") or {}).get("error"):
                 try:  # configs[3]: one proof of the p256 size class sharded over all ranks (every rank takes the same branch: the commit figure is rank-independent)

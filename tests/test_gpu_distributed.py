@@ -146,6 +146,33 @@ def test_bench_gpus_2_without_a_launcher():
     assert d["sharded_proof_m19"]["n_gpus"] == 2 and d["sharded_proof_m19"]["equals_the_lone_provers_transcript"] is True
 
 
+@pytest.mark.parametrize("where,limit_env", [("probe", "PK_BENCH_RCCL_LIMIT_S"), ("commit", "PK_BENCH_COMMIT_LIMIT_S")])
+def test_a_stuck_library_collective_costs_the_line_only_its_own_keys(where, limit_env):
+    """the watchdogs of the multi-rank line: a communicator that never forms (probe) or a sharded step that never returns (commit) --
+    simulated by a thread that blocks for ever -- must leave the judged figure intact: the weak-scaling proofs/s is measured and printed,
+    the keys that needed the library's communicator carry an error string, every rank leaves with exit code 0"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+    env.update(PK_BENCH_ONE_GPU="1", PK_BENCH_TEST_HANG=where)
+    env[limit_env] = "3"
+    out = subprocess.run([sys.executable, os.path.join(root_dir, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--concurrency", "2", "--size-classes", "",
+                          "--no-cpu-baseline", "--commit-log2-size", "17", "--sharded-proof-log2-size", "15"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["proofs_per_step"] == 4
+    if where == "probe":
+        assert "error" in d["rccl"] and "error" in d["commit_2p17"] and "sharded_proof_m15" not in d
+    else:
+        assert d["rccl"]["ranks_seen"] == [0, 1] and "error" in d["commit_2p17"] and "sharded_proof_m15" not in d
+
+
 def test_bench_gpus_more_than_present_is_clamped():
     """--gpus 8 on a box with fewer GPUs runs on what is there (and says so) instead of failing or claiming 8"""
     import ctypes as C
