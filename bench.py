@@ -339,6 +339,74 @@ def rccl_probe(provekit_amd, torch, rank, local_rank, world, dist, one_gpu, grou
     return out
 
 
+def single_stream_figures(torch, ctx, prover, d_z, latency_pass, sharded, iso_steps=8):
+    """one proof at a time on `ctx` (the chip otherwise idle): per-kernel durations with event profiling on (the roofline's isolated figures),
+    then the single-stream latency proper without events, then the same in the library's latency mode, and the multiplier's peak rate"""
+    import ctypes as C
+
+    ctx.profile(True)
+    ctx.profile_reset()
+    iso_times = []
+    for i in range(iso_steps):
+        t1 = time.perf_counter()
+        prover.prove_nocopy(d_z, seed=5000 + i)  # returns with the proof on the host: the stream is drained
+        iso_times.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    iso_dt = sorted(iso_times)[iso_steps // 2]  # median: the first proofs after a many-prover phase still see its clocks / queues
+    prof_iso = ctx.profile_read()
+    ctx.profile(False)
+
+    def one_at_a_time(first_seed):
+        ts = []
+        for i in range(iso_steps + 2):
+            t1 = time.perf_counter()
+            prover.prove_nocopy(d_z, seed=first_seed + i)
+            ts.append(time.perf_counter() - t1)
+        return sorted(ts[2:])[iso_steps // 2]
+
+    if latency_pass:
+        iso_dt = one_at_a_time(5500)  # the single-stream figure proper: no event pairs around the launches
+    # the same in the library's latency mode (pk_ctx_set_latency_mode: sumcheck rounds enqueued one ahead behind a host-published gate)
+    lat_dt = None
+    if latency_pass and not sharded:
+        try:
+            ctx.set_latency_mode(True)
+            lat_dt = one_at_a_time(6000)
+        finally:
+            ctx.set_latency_mode(False)
+    # SURVEY 8d's second roofline: peak rate of the register-resident Montgomery squaring, best over occupancy / ILP
+    peak_modmul = 0.0
+    try:  # the probe lives in tools/libpk_probes.so (the lab), not in the product library
+        from tools.pk_probes import lib as probes
+
+        for waves in (2, 4, 8):
+            for ilp in (1, 2):
+                r = C.c_double()
+                ctx._check(probes.pk_probe_modmul_rate(ctx.handle, waves, ilp, 2000, C.byref(r)))
+                peak_modmul = max(peak_modmul, r.value)
+    except ImportError as e:
+        print(f"[bench] no multiplier-peak probe ({e}): roofline.alu.peak is null", file=sys.stderr)
+    return {"iso_dt": iso_dt, "lat_dt": lat_dt, "prof_iso": prof_iso, "iso_steps": iso_steps, "peak_modmul": peak_modmul}
+
+
+def single_stream_probe(provekit_amd, torch, local_rank, m, latency_pass):
+    """internal (--single-stream-probe): single_stream_figures on the bench's statement in a fresh process; prints one JSON object"""
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+
+    m_0, n_wit = m - 1, (1 << (m - 1)) - 5
+    ctx = provekit_amd.Context(local_rank)
+    r1cs, _, _, nc, n_in = synth_r1cs(ctx, m_0, n_wit, seed=1234)
+    d_z, _ = satisfying_witness(ctx, r1cs, n_wit, nc, n_in, 99)
+    prover = WhirR1CSScheme(ctx, r1cs, m, m_0, WhirConfig.derive(m), blinding_config_for(m_0))
+    for i in range(60):  # ~0.6 s of proofs first: a fresh process finds the chip at its idle clocks
+        prover.prove_nocopy(d_z, seed=100 + i)
+    out = single_stream_figures(torch, ctx, prover, d_z, latency_pass, False)
+    prover.close()
+    r1cs.close()
+    ctx.close()
+    return out
+
+
 def sharded_proof_probe(provekit_amd, torch, rank, local_rank, world, dist, one_gpu, groups, mm, reps=3):
     """BASELINE configs[3] under several ranks: ONE proof of the m = `mm` size class (the p256 class: 25) sharded over ALL ranks of the
     run behind the C ABI -- every commit split by leaf index with an all-gather of leaf digests, inner trees by contiguous subtree,
@@ -618,15 +686,17 @@ def main():
                          "reproduce it, tools/alloc_effect.py); most likely the package power limit: 16 provers draw ~1.28 kW and already run at 2.26 GHz "
                          "instead of 2.39 (tools/power_trace.sh), and seconds of that heat the package for whatever follows.  The idle seconds a fresh "
                          "process brings remove the effect; every figure then matches a dedicated run of that size")
+    ap.add_argument("--single-stream-probe", action="store_true", help="internal: the one-proof-at-a-time figures of the default line in this (fresh, spinning) process; prints their JSON object")
     ap.add_argument("--no-latency-pass", action="store_true", help="skip the untimed one-at-a-time passes after the isolated-kernel pass (rocprofv3 runs: keeps the trace to "
                                                                    "the timed region + 8 isolated proofs)")
     ap.add_argument("--no-h2d-probe", action="store_true", help="skip the secondary PCIe-inclusive rate (witness uploaded before every proof)")
     ap.add_argument("--workload", choices=["prove", "commit"], default="prove",
                     help="prove = BASELINE configs[1] (default, the judged line); commit = one batch-2 WHIR commit of 2^m coefficients "
                          "(configs[4] with --m 26), SHARDED over the ranks with an all-gather of leaf digests (strong scaling)")
-    ap.add_argument("--concurrency", type=int, default=16,
+    ap.add_argument("--concurrency", type=int, default=20,
                     help="provers per GPU, each with its own context/stream/arena (host transcript work of one proof overlaps "
-                         "the kernels of another); 1 = strictly one proof at a time")
+                         "the kernels of another); 1 = strictly one proof at a time.  20 with sleeping host threads is the measured optimum on one "
+                         "MI355X (profiles/r05_wait_ab.jsonl: 16 spinning 260.7, 16 blocking 262.6, 20 blocking 266.8 proofs/s on one box)")
     ap.add_argument("--sharded", action="store_true",
                     help="prove workload, latency mode (BASELINE configs[3]): ONE proof at a time sharded over all ranks -- every large "
                          "commit split by leaf index with an RCCL all-gather of leaf digests behind the C ABI; strong scaling")
@@ -721,6 +791,31 @@ def main():
         return commit_workload(args, rank, local_rank, world, dist, torch)
     if args.size_class_probe:
         return emit(size_class_probe(provekit_amd, torch, local_rank, args.size_class_probe))
+    if args.single_stream_probe:
+        return emit(single_stream_probe(provekit_amd, torch, local_rank, args.m, not args.no_latency_pass))
+
+    m = args.m
+    # The one-proof-at-a-time figures of a process that will run its provers' threads in blocking-wait mode are taken by a FRESH process in
+    # the default spinning mode, and FIRST, before this process creates a prover (a second process on a GPU where another holds two dozen idle
+    # hardware queues runs ~3.5 % slower -- measured: 9.9 against 9.6 ms per proof)
+    ss = None
+    if block_wait and rank == 0 and not args.sharded:
+        try:
+            import subprocess
+
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "PK_BENCH_FORCE_DIST", "PK_BENCH_TEST_HANG")}
+            env["LOCAL_RANK"] = str(local_rank)
+            cmd = [sys.executable, os.path.abspath(__file__), "--single-stream-probe", "--log2-size", str(m), "--host-wait", "spin"] + (["--no-latency-pass"] if args.no_latency_pass else [])
+            out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+            if out.returncode == 0 and lines:
+                ss = json.loads(lines[-1])
+                ss["prof_iso"] = {k: tuple(v) for k, v in ss["prof_iso"].items()}
+                ss["how"] = "a fresh process in spinning-wait mode (this one runs its provers' threads blocking)"
+            else:
+                print(f"[bench] single-stream probe failed ({(out.stderr or 'no output')[-200:]}): measuring in this process", file=sys.stderr)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] single-stream probe failed ({e}): measuring in this process", file=sys.stderr)
 
     import threading
 
@@ -823,53 +918,16 @@ def main():
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0, dist, None if one_gpu else f"cuda:{local_rank}")
     prof = ctx.profile_read()
-    # untimed extra pass, one proof at a time on worker 0: isolated kernel durations for the roofline
-    # (with several provers in flight the per-launch times above include interference from the other streams)
-    ctx.profile(True)
-    ctx.profile_reset()
-    iso_steps = 8
-    iso_times = []
-    for i in range(iso_steps):
-        t1 = time.perf_counter()
-        workers[0][1].prove_nocopy(workers[0][2], seed=5000 + i)  # returns with the proof on the host: the stream is drained
-        iso_times.append(time.perf_counter() - t1)
-    torch.cuda.synchronize()
-    iso_dt = sorted(iso_times)[iso_steps // 2]  # median: the first proofs after the 16-prover phase still see its clocks / queues
-    # the same one-proof-at-a-time pass in the library's latency mode (pk_ctx_set_latency_mode: sumcheck rounds enqueued one ahead behind a
-    # host-published gate) -- profiling off, so that no event pairs sit between the gated launches
-    prof_iso = ctx.profile_read()
-    ctx.profile(False)
-    def one_at_a_time(first_seed):
-        ts = []
-        for i in range(iso_steps + 2):
-            t1 = time.perf_counter()
-            workers[0][1].prove_nocopy(workers[0][2], seed=first_seed + i)
-            ts.append(time.perf_counter() - t1)
-        return sorted(ts[2:])[iso_steps // 2]
-
-    if not args.no_latency_pass:
-        iso_dt = one_at_a_time(5500)  # the single-stream figure proper: no event pairs around the launches
-    lat_dt = None
-    if not args.sharded and not args.no_latency_pass:
-        try:
-            ctx.set_latency_mode(True)
-            lat_dt = one_at_a_time(6000)
-        finally:
-            ctx.set_latency_mode(False)
-    # SURVEY 8d's second roofline: peak rate of the register-resident Montgomery squaring, best over occupancy / ILP
-    import ctypes as C
-    from provekit_amd._lib import lib
-    peak_modmul = 0.0
-    try:  # the probe lives in tools/libpk_probes.so (the lab), not in the product library
-        from tools.pk_probes import lib as probes
-
-        for waves in (2, 4, 8):
-            for ilp in (1, 2):
-                r = C.c_double()
-                ctx._check(probes.pk_probe_modmul_rate(ctx.handle, waves, ilp, 2000, C.byref(r)))
-                peak_modmul = max(peak_modmul, r.value)
-    except ImportError as e:
-        print(f"[bench] no multiplier-peak probe ({e}): roofline.alu.peak is null", file=sys.stderr)
+    # One proof at a time on an otherwise idle chip: isolated kernel durations for the roofline, the single-stream figures, the multiplier peak.
+    # When this process runs its provers' threads in blocking-wait mode, those figures were taken at the start by a FRESH process in the
+    # default spinning mode (`ss` above) -- a blocked thread wakes ~20 us after its kernel, 65 times per proof, which is no part of a single
+    # prover's latency; one process has one wait mode: it cannot be switched under running provers.
+    if ss is None and (rank == 0 or not block_wait):
+        ss = single_stream_figures(torch, ctx, workers[0][1], workers[0][2], not args.no_latency_pass, args.sharded)
+        ss["how"] = "this process, after the timed region" + (" (blocking-wait mode: a single prover pays ~20 us per synchronisation for it)" if block_wait else "")
+    if ss is None:
+        ss = {"iso_dt": float("nan"), "lat_dt": None, "prof_iso": {}, "iso_steps": 8, "peak_modmul": 0.0, "how": "rank 0 only"}
+    iso_dt, lat_dt, prof_iso, iso_steps, peak_modmul = ss["iso_dt"], ss["lat_dt"], ss["prof_iso"], ss["iso_steps"], ss["peak_modmul"]
 
     # ---- secondary figures of the default line (each guarded: none may break the line) -----------------------------------
     # (b) BASELINE configs[4]: the 2^26 commit -- on one GPU, and under several ranks SHARDED over the first G = 1, 2, 4, 8 <= N of them
@@ -960,13 +1018,27 @@ def main():
         sharded_fig = None if hung_any else box.get("sharded")
     else:
         commit_fig = run_commit_probe()
+    if world == 1:
+        h2d_rate = run_h2d_probe()
+    # Everything that needs this process's provers is done.  The CPU leg will want a GPU proof to compare bytes with: take it now, then release
+    # the provers -- a fresh process on a GPU where another holds two dozen idle hardware queues measures ~3.5 % low (9.9 against 9.6 ms per proof)
+    cpu_seed, gpu_proof, ds0, z0 = (4242).to_bytes(32, "little"), None, workers[0][1].domain_separator, workers[0][4]
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        gpu_proof = workers[0][1].prove(workers[0][2], seed=cpu_seed)
     # (c) the other BASELINE size classes (configs[2] m = 23, configs[3] m = 25), rank 0's GPU only
     size_figs = {}
     if rank == 0 and m == 21 and not args.sharded and args.size_classes:
         import subprocess
 
+        for c_, prover_, d_z_, r1cs_, _ in workers:
+            prover_.close()
+            d_z_.free()
+            r1cs_.close()
+            c_.close()
+        workers.clear()
+        torch.cuda.empty_cache()
         for mm in [int(x) for x in args.size_classes.split(",") if x.strip()]:
-            try:  # a fresh process per class on this GPU (see --size-class-probe); this one keeps its provers, idle, meanwhile
+            try:  # a fresh process per class on this GPU (see --size-class-probe)
                 env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "TORCHELASTIC_RUN_ID", "PK_BENCH_FORCE_DIST")}
                 env["LOCAL_RANK"] = str(local_rank)  # the same device; no process group in the child
                 out = subprocess.run([sys.executable, os.path.abspath(__file__), "--size-class-probe", str(mm)], env=env, capture_output=True, text=True,
@@ -975,8 +1047,6 @@ def main():
                 size_figs[str(mm)] = json.loads(lines[-1]) if out.returncode == 0 and lines else {"error": (out.stderr or "no output")[-200:]}
             except Exception as e:  # noqa: BLE001
                 size_figs[str(mm)] = {"error": str(e)[:200]}
-    if world == 1:
-        h2d_rate = run_h2d_probe()
     if dist is not None and not hung_any:
         dist.barrier()
 
@@ -1081,8 +1151,8 @@ def main():
             "roofline_ntt": ntt_roofline(prof_iso, iso_steps, m, cfg_w, cfg_b, peak_modmul),
             "single_stream": {"ms_per_proof": 1e3 * iso_dt, "proofs_per_s": 1.0 / iso_dt,
                               "latency_mode_ms_per_proof": None if lat_dt is None else 1e3 * lat_dt,
-                              "note": "one proof at a time on worker 0; latency_mode = pk_ctx_set_latency_mode (sumcheck rounds enqueued one ahead "
-                                      "behind a host-published gate; same transcript)"},
+                              "note": "one proof at a time; latency_mode = pk_ctx_set_latency_mode (sumcheck rounds enqueued one ahead "
+                                      "behind a host-published gate; same transcript); measured in " + ss["how"]},
             "stage_ms_per_proof_isolated": stage_ms,
         }
         if h2d_rate is not None:
@@ -1098,10 +1168,7 @@ def main():
         if size_figs:
             line["size_classes"] = size_figs
         if not args.no_cpu_baseline and world == 1:
-            seed = (4242).to_bytes(32, "little")
-            gpu_proof = workers[0][1].prove(workers[0][2], seed=seed)
-            cb = cpu_baseline(m, m_0, mats0, interner0, nc, n_wit, cfg_w, cfg_b, workers[0][1].domain_separator, workers[0][4], seed, gpu_proof,
-                              budget_s=args.cpu_baseline_budget)
+            cb = cpu_baseline(m, m_0, mats0, interner0, nc, n_wit, cfg_w, cfg_b, ds0, z0, cpu_seed, gpu_proof, budget_s=args.cpu_baseline_budget)
             line["cpu_baseline"] = {
                 "value": 1.0 / cb["seconds"],
                 "unit": "proofs/s",

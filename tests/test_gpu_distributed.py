@@ -138,7 +138,7 @@ def test_bench_gpus_2_without_a_launcher():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["config"]["proofs_per_step"] == 2 * 16 and "started its own ranks" in d["config"]["launcher"]
+    assert d["config"]["proofs_per_step"] == 2 * 20 and "started its own ranks" in d["config"]["launcher"]
     assert d["rccl"]["world"] == 2 and d["rccl"]["transport"] == "host" and d["rccl"]["ranks_seen"] == [0, 1]
     c = d["commit_2p26"]
     assert c["n_gpus"] == 2 and c["scaling"] == "strong" and sorted(c["curve"]) == ["1", "2"] and c["roots_agree"]

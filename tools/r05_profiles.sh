@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 Q='--no-commit-probe --no-h2d-probe --no-latency-pass --size-classes='
 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench.json 2> gpurun_out/r05_bench.err
-bash tools/profile.sh r05_conc16 --steps 20 --warmup 5 $Q > gpurun_out/r05_conc16.log 2>&1
+bash tools/profile.sh r05_conc20 --steps 20 --warmup 5 $Q > gpurun_out/r05_conc20.log 2>&1
 KEEP_TRACE=1 bash tools/profile.sh r05_conc1 --concurrency 1 --steps 64 $Q > gpurun_out/r05_conc1.log 2>&1
 bash tools/pmc.sh r05_pmc_prove --concurrency 1 --steps 6 $Q > gpurun_out/r05_pmc_prove.log 2>&1
 bash tools/pmc.sh r05_pmc_prove23 --log2-size 23 --concurrency 1 --steps 4 $Q > gpurun_out/r05_pmc_prove23.log 2>&1
