@@ -913,10 +913,14 @@ def main():
     ctx.profile(timed_profile)
     ctx.profile_reset()
     barrier()
+    cpu0 = time.process_time()  # CPU seconds of every thread of this process: what the provers' host side costs (transcript, launches, waiting)
     t0 = time.perf_counter()
     run_proofs(1, args.steps * conc)
     barrier()
-    dt = max_over_ranks(time.perf_counter() - t0, dist, None if one_gpu else f"cuda:{local_rank}")
+    own_dt = time.perf_counter() - t0
+    host_cpu_ms_per_proof = 1e3 * (time.process_time() - cpu0) / (args.steps * conc)
+    host_cores_busy = (time.process_time() - cpu0) / own_dt
+    dt = max_over_ranks(own_dt, dist, None if one_gpu else f"cuda:{local_rank}")
     prof = ctx.profile_read()
     # One proof at a time on an otherwise idle chip: isolated kernel durations for the roofline, the single-stream figures, the multiplier peak.
     # When this process runs its provers' threads in blocking-wait mode, those figures were taken at the start by a FRESH process in the
@@ -1101,6 +1105,8 @@ def main():
                 "proofs_per_step": conc * (1 if args.sharded else world),
                 "host_wait": ("blocking (pk_device_set_host_wait: the provers' host threads sleep on the completion interrupt)" if block_wait else "spinning (HIP default)")
                              + f"; {cores['usable']} usable host cores (logical {cores['logical_cpus']}, cgroup quota {cores['cgroup_cpu_quota']}) for {local_world} rank(s) on this node",
+                "host_cpu_ms_per_proof": round(host_cpu_ms_per_proof, 2),
+                "host_cores_busy_in_timed_region": round(host_cores_busy, 2),
                 "profiling_in_timed_region": (f"hipEvent pairs around the launches of 1 of the {conc} provers per GPU" if timed_profile else False),
                 "launcher": ("bench.py --gpus N started its own ranks (torch.distributed.run, 127.0.0.1)" if os.environ.get("PK_BENCH_SELF_LAUNCHED") else
                              ("torch.distributed.run" if dist is not None else "single process")),
