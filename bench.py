@@ -499,12 +499,15 @@ def size_class_probe(provekit_amd, torch, local_rank, m, proofs_per_prover=3):
         for t in ths:
             t.join()
 
+    if conc > 1:
+        provekit_amd.Context.set_host_wait(local_rank, "poll")  # many provers in flight: the library's own query-and-sleep wait (switchable)
     wave(900000, 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     wave(1, proofs_per_prover)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    provekit_amd.Context.set_host_wait(local_rank, "spin")
     singles = []
     for i in range(3):
         t1 = time.perf_counter()
@@ -668,7 +671,7 @@ def main():
     ap.add_argument("--m", "--log2-size", dest="m", type=int, default=21,
                     help="log2 of the committed polynomial size (poseidon-rounds: 21).  Under torch.distributed.run spell it "
                          "--log2-size: the launcher's own parser rejects --m as an ambiguous abbreviation")
-    ap.add_argument("--host-wait", choices=["auto", "spin", "block"], default="auto",
+    ap.add_argument("--host-wait", choices=["auto", "spin", "block", "poll"], default="auto",
                     help="how the provers' host threads wait for the GPU: spin (HIP default), block (sleep on the interrupt), auto = block only when this "
                          "rank's share of the usable host cores is smaller than its number of provers")
     ap.add_argument("--no-sharded-proof", action="store_true", help="under several ranks: skip the secondary figure 'one proof of the p256 size class sharded over all ranks'")
@@ -696,7 +699,7 @@ def main():
     ap.add_argument("--concurrency", type=int, default=20,
                     help="provers per GPU, each with its own context/stream/arena (host transcript work of one proof overlaps "
                          "the kernels of another); 1 = strictly one proof at a time.  20 with sleeping host threads is the measured optimum on one "
-                         "MI355X (profiles/r05_wait_ab.jsonl: 16 spinning 260.7, 16 blocking 262.6, 20 blocking 266.8 proofs/s on one box)")
+                         "MI355X (profiles/r05_wait_ab.jsonl: 16 spinning 260.7, 16 blocking 262.6, 20 blocking 266.8 proofs/s on one box; polling = blocking + 1 %)")
     ap.add_argument("--sharded", action="store_true",
                     help="prove workload, latency mode (BASELINE configs[3]): ONE proof at a time sharded over all ranks -- every large "
                          "commit split by leaf index with an RCCL all-gather of leaf digests behind the C ABI; strong scaling")
@@ -747,9 +750,17 @@ def main():
     cores = usable_cores()
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     cores_per_rank = cores["usable"] / max(local_world, 1)
-    block_wait = args.host_wait == "block" or (args.host_wait == "auto" and cores_per_rank < (1 if args.sharded else args.concurrency))
+    # auto: many provers in flight -> PK_WAIT_POLL, the library's own query-and-sleep loop (as fast as blocking or faster, a third of its host CPU,
+    # and -- being the library's own -- safe to switch: it is on for the many-prover phases and off for the one-at-a-time passes); one prover -> spin.
+    wait_mode = args.host_wait if args.host_wait != "auto" else ("poll" if args.concurrency > 1 and not args.sharded else "spin")
+    block_wait = wait_mode == "block"  # a mode of the RUNTIME: fixed for the life of the process, one-at-a-time figures from a fresh process
     if block_wait:
-        provekit_amd.Context.set_host_wait(local_rank, True)
+        provekit_amd.Context.set_host_wait(local_rank, "block")
+
+    def throughput_wait(on):
+        if wait_mode == "poll":
+            provekit_amd.Context.set_host_wait(local_rank, "poll" if on else "spin")
+
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("PK_BENCH_FORCE_DIST"):
         # launched by torch.distributed.run: one rank per GPU over RCCL ("nccl" is RCCL on ROCm)
@@ -905,6 +916,7 @@ def main():
 
     # one step = one wave of `conc` proofs (a batch of synthetic statements through the hot path), so any --steps the driver
     # passes measures the steady state of a full chip rather than a ragged tail
+    throughput_wait(True)
     run_proofs(100000, args.warmup * conc)
     # hipEvent pairs around the launches of ONE of the `conc` provers (worker 0) during the timed region: the source of the
     # *_under_load figures.  PK_BENCH_NO_TIMED_PROFILE=1 turns it off for an A/B (profiles/r05_timed_profile_ab.json: no
@@ -922,13 +934,14 @@ def main():
     host_cores_busy = (time.process_time() - cpu0) / own_dt
     dt = max_over_ranks(own_dt, dist, None if one_gpu else f"cuda:{local_rank}")
     prof = ctx.profile_read()
+    throughput_wait(False)
     # One proof at a time on an otherwise idle chip: isolated kernel durations for the roofline, the single-stream figures, the multiplier peak.
-    # When this process runs its provers' threads in blocking-wait mode, those figures were taken at the start by a FRESH process in the
-    # default spinning mode (`ss` above) -- a blocked thread wakes ~20 us after its kernel, 65 times per proof, which is no part of a single
-    # prover's latency; one process has one wait mode: it cannot be switched under running provers.
+    # Spinning waits here: the polling mode of the many-prover phases is the library's own loop and was switched off above.  (With
+    # --host-wait block -- a mode of the runtime, fixed for the life of the process -- these figures were taken at the start by a FRESH process in
+    # spinning mode, `ss` above: a blocked thread wakes ~20 us after its kernel, 65 times per proof, no part of a single prover's latency.)
     if ss is None and (rank == 0 or not block_wait):
         ss = single_stream_figures(torch, ctx, workers[0][1], workers[0][2], not args.no_latency_pass, args.sharded)
-        ss["how"] = "this process, after the timed region" + (" (blocking-wait mode: a single prover pays ~20 us per synchronisation for it)" if block_wait else "")
+        ss["how"] = "this process, after the timed region, spinning waits" + (" -- NO: blocking-wait mode, a single prover pays ~20 us per synchronisation for it" if block_wait else "")
     if ss is None:
         ss = {"iso_dt": float("nan"), "lat_dt": None, "prof_iso": {}, "iso_steps": 8, "peak_modmul": 0.0, "how": "rank 0 only"}
     iso_dt, lat_dt, prof_iso, iso_steps, peak_modmul = ss["iso_dt"], ss["lat_dt"], ss["prof_iso"], ss["iso_steps"], ss["peak_modmul"]
@@ -978,6 +991,7 @@ def main():
             return None
         try:
             args.h2d = True
+            throughput_wait(True)
             run_proofs(200000, 2 * conc)
             barrier()
             t1 = time.perf_counter()
@@ -989,6 +1003,7 @@ def main():
             return None
         finally:
             args.h2d = False
+            throughput_wait(False)
 
     # Order.  One GPU: the commit probe first (before anything else allocates and releases large buffers in this process), the h2d probe last.
     # Several ranks: every figure that needs only torch's collectives first, then the sharded commit -- the one step of this file that goes
@@ -1103,7 +1118,8 @@ def main():
                             f"queries {cfg_w.num_queries}/{cfg_w.final_queries}, pow_bits {cfg_w.pow_bits}/{cfg_w.final_pow_bits} (WhirConfig::new derivation, security 128, "
                             f"ConjectureList), blinding WHIR n={cfg_b.n_vars} queries {cfg_b.num_queries}/{cfg_b.final_queries}, Skyscraper-sponge transcript, ChaCha12 masks",
                 "proofs_per_step": conc * (1 if args.sharded else world),
-                "host_wait": ("blocking (pk_device_set_host_wait: the provers' host threads sleep on the completion interrupt)" if block_wait else "spinning (HIP default)")
+                "host_wait": ({"block": "blocking (pk_device_set_host_wait: the provers' host threads sleep on the completion interrupt)",
+                               "poll": "polling (pk_device_set_host_wait PK_WAIT_POLL: the library's own query-and-sleep loop)", "spin": "spinning (HIP default)"}[wait_mode])
                              + f"; {cores['usable']} usable host cores (logical {cores['logical_cpus']}, cgroup quota {cores['cgroup_cpu_quota']}) for {local_world} rank(s) on this node",
                 "host_cpu_ms_per_proof": round(host_cpu_ms_per_proof, 2),
                 "host_cores_busy_in_timed_region": round(host_cores_busy, 2),

@@ -73,6 +73,9 @@ int pk_device_count(int *n);
  * to blocking while provers were running hung one of them in its next synchronisation). */
 #define PK_WAIT_SPIN 0
 #define PK_WAIT_BLOCK 1
+#define PK_WAIT_POLL 2 /* the library's own wait: hipStreamQuery with sleeps of 20 .. 100 us in between -- the cheapest for the host (no core per
+                        * waiting thread, none of the runtime's spinning before it blocks), completion noticed up to one interval late.  Unlike the
+                        * two runtime modes it may be chosen and left at any time. */
 int pk_device_set_host_wait(int device, int mode);
 int pk_ctx_create(int device, pk_ctx **out);
 int pk_ctx_destroy(pk_ctx *ctx);

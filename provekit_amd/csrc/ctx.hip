@@ -3,7 +3,38 @@
 #include "ctx.hpp"
 #include "fe29.hpp"
 
+#include <sys/prctl.h>
+#include <time.h>
+
+#include <atomic>
+
 using namespace pk;
+
+#define PK_MAX_DEVICES 64
+static std::atomic<int> g_poll_wait[PK_MAX_DEVICES];
+
+namespace pk {
+// PK_WAIT_POLL: a few immediate queries (work that ends within microseconds), then sleeps that lengthen from 20 us to 100 us.  A waiting
+// thread costs a query and a timer wake-up per interval instead of a core (spinning) or the runtime's spin-then-block (~0.2 ms of spinning
+// per wait: 65 waits per proof); it learns of completion up to one interval late, which a prover that shares the chip with others does not
+// notice and a lone prover does (keep PK_WAIT_SPIN for latency).
+hipError_t wait_stream(int device, hipStream_t stream) {
+    if (device < 0 || device >= PK_MAX_DEVICES || !g_poll_wait[device].load(std::memory_order_relaxed)) return hipStreamSynchronize(stream);
+    static thread_local bool slack_set = false;
+    if (!slack_set) {  // the default timer slack (50 us) would round every short sleep up
+        (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0);
+        slack_set = true;
+    }
+    for (unsigned polls = 0;; polls++) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e != hipErrorNotReady) return e;
+        if (polls < 4) continue;
+        const long ns = polls < 12 ? 20000 : (polls < 40 ? 50000 : 100000);
+        struct timespec ts = {0, ns};
+        (void)nanosleep(&ts, nullptr);
+    }
+}
+}  // namespace pk
 
 extern "C" {
 
@@ -22,7 +53,13 @@ int pk_device_count(int* n) {
 }
 
 int pk_device_set_host_wait(int device, int mode) {
-    if (mode != PK_WAIT_SPIN && mode != PK_WAIT_BLOCK) return PK_ERR_BAD_ARG;
+    if (mode != PK_WAIT_SPIN && mode != PK_WAIT_BLOCK && mode != PK_WAIT_POLL) return PK_ERR_BAD_ARG;
+    if (device < 0 || device >= PK_MAX_DEVICES) return PK_ERR_BAD_ARG;
+    if (mode == PK_WAIT_POLL) {  // the library's own loop: nothing of the runtime changes, so this one may be switched at any time
+        g_poll_wait[device].store(1, std::memory_order_relaxed);
+        return PK_OK;
+    }
+    g_poll_wait[device].store(0, std::memory_order_relaxed);
     int cur = 0;
     const bool have = hipGetDevice(&cur) == hipSuccess;
     if (hipSetDevice(device) != hipSuccess) return PK_ERR_BAD_ARG;
@@ -48,7 +85,7 @@ int pk_ctx_create(int device, pk_ctx** out) {
     ctx->stream = ctx->own_stream;
     {   // PK_HOST_WAIT=block|spin: pk_device_set_host_wait for callers that cannot reach the API (A/B runs, tools/cpuuse.py)
         const char* w = getenv("PK_HOST_WAIT");
-        if (w && *w) (void)pk_device_set_host_wait(device, w[0] == 'b' ? PK_WAIT_BLOCK : PK_WAIT_SPIN);
+        if (w && *w) (void)pk_device_set_host_wait(device, w[0] == 'b' ? PK_WAIT_BLOCK : (w[0] == 'p' ? PK_WAIT_POLL : PK_WAIT_SPIN));
     }
     pk::ntt_retain_ctx(ctx);
     hipDeviceProp_t prop;
@@ -61,7 +98,7 @@ int pk_ctx_create(int device, pk_ctx** out) {
 int pk_ctx_destroy(pk_ctx* ctx) {
     PK_ENTER(ctx);
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)wait_stream(ctx->device, ctx->stream);
     pk::comm_release(ctx);
     pk::ntt_release_ctx(ctx);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -111,7 +148,7 @@ int pk_malloc(pk_ctx* ctx, size_t bytes, void** d_ptr) {
 int pk_free(pk_ctx* ctx, void* d_ptr) {
     PK_ENTER(ctx);
     if (!d_ptr) return PK_OK;
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
     PK_HIP(ctx, hipFree(d_ptr));
     return PK_OK;
 }
@@ -120,7 +157,7 @@ int pk_memcpy_h2d(pk_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
     PK_REQUIRE(ctx, bytes == 0 || (d_dst && src), "null pointer");
     if (!bytes) return PK_OK;
     PK_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
     return PK_OK;
 }
 int pk_memcpy_d2h(pk_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
@@ -128,7 +165,7 @@ int pk_memcpy_d2h(pk_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
     PK_REQUIRE(ctx, bytes == 0 || (dst && d_src), "null pointer");
     if (!bytes) return PK_OK;
     PK_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
     return PK_OK;
 }
 int pk_memcpy_d2d(pk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
@@ -166,7 +203,7 @@ int pk_profile_enable(pk_ctx* ctx, int on) {
 }
 int pk_profile_reset(pk_ctx* ctx) {
     PK_ENTER(ctx);
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
     for (auto& r : ctx->prof) {
         ctx->ev_pool.push_back(r.e0);
         ctx->ev_pool.push_back(r.e1);
@@ -176,7 +213,7 @@ int pk_profile_reset(pk_ctx* ctx) {
 }
 int pk_profile_read(pk_ctx* ctx, const char* name, uint64_t* launches, double* total_ms) {
     if (!ctx || !name || !launches || !total_ms) return PK_ERR_BAD_ARG;
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
     *launches = 0;
     *total_ms = 0.0;
     for (auto& r : ctx->prof) {
@@ -216,7 +253,7 @@ namespace pk {
 int ensure_scratch(pk_ctx* ctx, size_t bytes) {
     if (ctx->scratch_bytes >= bytes) return PK_OK;
     if (ctx->d_scratch) {
-        PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
         PK_HIP(ctx, hipFree(ctx->d_scratch));
         ctx->d_scratch = nullptr;
         ctx->scratch_bytes = 0;
@@ -235,7 +272,7 @@ int ensure_pinned(pk_ctx* ctx) {
     return PK_OK;
 }
 int sync_stream(pk_ctx* ctx) {
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
     ctx->mail_off = 0;  // nothing in flight reads or writes the mailbox any more
     return PK_OK;
 }
@@ -261,7 +298,7 @@ int mail_alloc(pk_ctx* ctx, size_t bytes, void** out) {
 int ensure_ws(pk_ctx* ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return PK_OK;
     if (ctx->d_ws) {
-        PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
         PK_HIP(ctx, hipFree(ctx->d_ws));
         ctx->d_ws = nullptr;
         ctx->ws_bytes = 0;

@@ -166,7 +166,10 @@ struct ProfScope {
 
 int ensure_scratch(pk_ctx* ctx, size_t bytes);
 int ensure_pinned(pk_ctx* ctx);                               // the 4 KiB result page
-int sync_stream(pk_ctx* ctx);                                 // hipStreamSynchronize + rewind the mailbox
+// Every wait of the library for a stream goes through here (pk_device_set_host_wait): the runtime's hipStreamSynchronize -- spinning or
+// blocking, whichever the device's scheduling flag says -- or, in PK_WAIT_POLL, the library's own loop: hipStreamQuery with short sleeps.
+hipError_t wait_stream(int device, hipStream_t stream);
+int sync_stream(pk_ctx* ctx);                                 // wait_stream + rewind the mailbox
 int mail_alloc(pk_ctx* ctx, size_t bytes, void** out);        // 64-B aligned; valid until the next sync_stream
 int read_root(pk_ctx* ctx, const uint64_t* d_nodes, size_t n_leaves, uint64_t root[4]);  // hash.hip: after pk_merkle_*
 int ensure_ws(pk_ctx* ctx, size_t bytes);

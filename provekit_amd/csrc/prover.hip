@@ -820,7 +820,7 @@ int proof_key(pk_ctx* ctx, const uint8_t* rng_seed32, RngKey& key) {
         rc = comm_all_gather(ctx, d_key, d_key + 32, 32);
         if (rc) return rc;
         PK_HIP(ctx, hipMemcpyAsync(key.k, d_key + 32, 32, hipMemcpyDeviceToHost, ctx->stream));
-        PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
     }
     return PK_OK;
 }
@@ -997,7 +997,7 @@ extern "C" {
 int pk_scheme_destroy(pk_ctx* ctx, pk_scheme* s) {
     PK_ENTER(ctx);
     if (!s) return PK_OK;
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)wait_stream(ctx->device, ctx->stream);
     (void)hipFree(s->arena);
     (void)hipFree(s->noir_witness);
     if (s->side) (void)pk_ctx_destroy(s->side);
@@ -1085,7 +1085,7 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     auto t_start = now();
     auto lap = [&](const char* what) {
         if (!timing) return;
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)wait_stream(ctx->device, ctx->stream);
         auto t = now();
         fprintf(stderr, "[pk_prove] %-28s %8.3f ms (sponge: %u permutes, %.3f ms; hint serialisation so far %.3f ms)\n", what,
                 1e3 * std::chrono::duration<double>(t - t_start).count(), T.permutes, 1e3 * T.permute_seconds, 1e3 * T.hint_seconds);
@@ -1109,7 +1109,7 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
         bool used = false;
         ~SideDrain() {
             if (used && s->side) {
-                (void)hipStreamSynchronize(s->side->stream);
+                (void)wait_stream(s->side->device, s->side->stream);
                 s->side->mail_off = 0;
             }
         }
@@ -1170,7 +1170,7 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     std::vector<fe> g_univ(4 * (size_t)m_0);
     if (overlap_blinding) {  // the side stream finished long ago: take its root and the coefficients, then the transcript half here
         pk_ctx* sc = s->side;
-        if (hipStreamSynchronize(sc->stream) != hipSuccess) return set_err(ctx, PK_ERR_HIP, "side stream synchronisation failed");
+        if (wait_stream(sc->device, sc->stream) != hipSuccess) return set_err(ctx, PK_ERR_HIP, "side stream synchronisation failed");
         memcpy(g_univ.data(), side_univ, 32 * g_univ.size());
         sc->mail_off = 0;
         fe root_b;

@@ -248,7 +248,7 @@ extern "C" {
 int pk_tree_destroy(pk_ctx* ctx, pk_tree* t) {
     PK_ENTER(ctx);
     if (!t) return PK_OK;
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)wait_stream(ctx->device, ctx->stream);
     if (t->owns_leaves) (void)hipFree(t->d_leaves);
     (void)hipFree(t->d_nodes);
     delete t;
@@ -440,7 +440,7 @@ int pk_tree_open(pk_ctx* ctx, const pk_tree* t, const uint64_t* indices, size_t 
                                                                                           logn, m_idx, k, canonical_leaves, m_leaves, m_sib, m_path, t->scaled);
     }
     PK_LAUNCH_CHECK(ctx);
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // not sync_stream: the mailbox is read below
+    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));  // not sync_stream: the mailbox is read below
     memcpy(leaves_out, m_leaves, 32 * n1);
     if (logn) memcpy(sibling_digests, m_sib, 32 * k);
     if (plen) memcpy(auth_paths, m_path, 32 * k * plen);
@@ -472,7 +472,7 @@ int pk_gather_leaves_enc(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves,
     gather_opening_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, ctx->stream>>>((const fe*)d_leaves, nullptr, n_leaves, (unsigned)width, layout, 0, m_idx, k,
                                                                                 canonical_leaves, m_leaves, nullptr, nullptr, encoding == PK_LEAVES_SCALED32);
     PK_LAUNCH_CHECK(ctx);
-    PK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
     memcpy(leaves_out, m_leaves, 32 * n1);
     ctx->mail_off = 0;
     return PK_OK;

@@ -101,11 +101,13 @@ class Context:
         self._check(lib.pk_comm_destroy(self.handle))
 
     @staticmethod
-    def set_host_wait(device: int, block: bool):
-        """pk_device_set_host_wait: how host threads wait for `device` -- block=True sleeps on the completion interrupt (many provers per
-        GPU, few host cores), False spins (HIP's default; one proof at a time).  Call it before creating contexts on the device and do
-        not change it while work is in flight."""
-        rc = lib.pk_device_set_host_wait(device, 1 if block else 0)
+    def set_host_wait(device: int, mode):
+        """pk_device_set_host_wait: how host threads wait for `device` -- "spin" / False (HIP's default; one proof at a time), "block" / True
+        (sleep on the completion interrupt: many provers per GPU, few host cores) -- choose these two before creating contexts on the device
+        and do not change them while work is in flight -- or "poll" (the library's own query-and-sleep loop: the cheapest for the host,
+        switchable at any time)"""
+        code = {False: 0, True: 1, "spin": 0, "block": 1, "poll": 2}[mode]
+        rc = lib.pk_device_set_host_wait(device, code)
         if rc != 0:
             raise ProveKitHipError(rc, "pk_device_set_host_wait failed")
 

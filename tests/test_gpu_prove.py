@@ -605,9 +605,11 @@ def test_transcript_equals_the_oracle_provers_at_the_bench_size(ctx, oracle, m):
     r1cs.close()
 
 
-def test_blocking_host_wait_gives_the_same_proofs(ctx, oracle):
-    """pk_device_set_host_wait(PK_WAIT_BLOCK) -- prover threads sleep on the completion interrupt instead of spinning -- chosen before any
-    context exists (a fresh process): four provers in flight write the transcripts this process's spinning prover writes"""
+@pytest.mark.parametrize("mode", ["block", "poll"])
+def test_blocking_host_wait_gives_the_same_proofs(ctx, oracle, mode):
+    """pk_device_set_host_wait: PK_WAIT_BLOCK -- prover threads sleep on the completion interrupt instead of spinning -- and PK_WAIT_POLL -- the
+    library's own query-and-sleep loop -- chosen before any context exists (a fresh process): four provers in flight write the transcripts
+    this process's spinning prover writes"""
     import hashlib
     import subprocess
 
@@ -629,7 +631,7 @@ sys.path[:0] = [%r, %r]
 import torch; torch.cuda.is_available()
 import oracle_lib as oracle
 import provekit_amd
-provekit_amd.Context.set_host_wait(0, True)   # before the first context of this process
+provekit_amd.Context.set_host_wait(0, %r)   # before the first context of this process
 from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
 from provekit_amd.sparse_matrix import R1CS
 from test_gpu_prove import satisfiable_r1cs, to_sparse
@@ -646,7 +648,7 @@ def work(w):
 ths = [threading.Thread(target=work, args=(w,)) for w in range(4)]
 [t.start() for t in ths]; [t.join() for t in ths]
 print("HASHES", " ".join(out[s] for s in range(1, 9)))
-''' % (os.path.dirname(here), here)
+''' % (os.path.dirname(here), here, mode)
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     got = [l for l in res.stdout.splitlines() if l.startswith("HASHES ")][-1].split()[1:]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the host CPU of throughput mode goes: per-thread CPU seconds (/proc/self/task/*/stat) over a window of proofs by C provers,
-prover threads against everything else in the process (the HIP runtime's own threads).  usage: tools/host_threads.py [C=16] [block|spin] [proofs per prover=12]"""
+prover threads against everything else in the process (the HIP runtime's own threads).  usage: tools/host_threads.py [C=16] [block|spin|poll] [proofs per prover=12]"""
 import json
 import os
 import sys
@@ -20,8 +20,8 @@ import bench  # noqa: E402
 import provekit_amd  # noqa: E402
 from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for  # noqa: E402
 
-if mode == "block":
-    provekit_amd.Context.set_host_wait(0, True)
+if mode != "spin":
+    provekit_amd.Context.set_host_wait(0, mode)
 m, m_0 = 21, 20
 n_wit = (1 << (m - 1)) - 5
 cfg_w, cfg_b = WhirConfig.derive(m), blinding_config_for(m_0)
