@@ -499,8 +499,10 @@ def size_class_probe(provekit_amd, torch, local_rank, m, proofs_per_prover=3):
         for t in ths:
             t.join()
 
-    if conc > 1:
-        provekit_amd.Context.set_host_wait(local_rank, "poll")  # many provers in flight: the library's own query-and-sleep wait (switchable)
+    from provekit_amd.hostinfo import usable_cores
+
+    if conc > usable_cores()["usable"]:
+        provekit_amd.Context.set_host_wait(local_rank, "poll")  # more provers than cores: the library's own query-and-sleep wait (switchable)
     wave(900000, 1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -752,7 +754,9 @@ def main():
     cores_per_rank = cores["usable"] / max(local_world, 1)
     # auto: many provers in flight -> PK_WAIT_POLL, the library's own query-and-sleep loop (as fast as blocking or faster, a third of its host CPU,
     # and -- being the library's own -- safe to switch: it is on for the many-prover phases and off for the one-at-a-time passes); one prover -> spin.
-    wait_mode = args.host_wait if args.host_wait != "auto" else ("poll" if args.concurrency > 1 and not args.sharded else "spin")
+    # Provers that each have a core to themselves keep spinning: polling notices completion up to 0.1 ms late, 65 times per proof, which a
+    # chip full of other provers' work hides and a chip with three provers on it (the m = 25 class) does not (15.0 -> 14.3 proofs/s).
+    wait_mode = args.host_wait if args.host_wait != "auto" else ("poll" if args.concurrency > cores_per_rank and not args.sharded else "spin")
     block_wait = wait_mode == "block"  # a mode of the RUNTIME: fixed for the life of the process, one-at-a-time figures from a fresh process
     if block_wait:
         provekit_amd.Context.set_host_wait(local_rank, "block")
