@@ -104,6 +104,7 @@ int pk_ctx_destroy(pk_ctx* ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_xred) (void)hipFree(ctx->d_xred);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_ztab) (void)hipFree(ctx->d_ztab);
     if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
     if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
     for (auto& r : ctx->prof) {

@@ -49,6 +49,7 @@ struct pk_ctx {
     bool latency_mode = false;
     unsigned gate_seq = 0;  // sequence number of the last gate handed out (reduce.hpp)
     void* d_ws = nullptr;  // large reusable workspace (NTT scratch); grows, never shrinks
+    void* d_ztab = nullptr;  // 256 field elements: z^t for the point of the univariate evaluation in flight (mle.hip)
     size_t ws_bytes = 0;
     // "mailbox": device-visible pinned host memory the kernels read small inputs from and write small outputs to, so
     // the Fiat-Shamir round trips need no copy operations (each hipMemcpyAsync is a blit dispatch for the command processor).

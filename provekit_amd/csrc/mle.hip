@@ -480,44 +480,71 @@ __global__ __launch_bounds__(RED_THREADS) void dot_rows_kernel(const fe* __restr
 }
 
 // ---------------------------------------------------------------- E1: univariate evaluation
-// sum_i c[i] z^i with T = gridDim*blockDim lanes: lane g Horner-evaluates the stride-T subsequence c[g], c[g+T], ...
-// in z^T (so every load is coalesced across the wave), scales by z^g and the grid reduces.
+// sum_i c[i] z^i.  Workgroup b owns the contiguous segment [b S, (b + 1) S), S = 256 cnt; lane t Horner-evaluates its stride-256
+// subsequence c[b S + t], c[b S + t + 256], ... in z^256 (every load coalesced across the wave), scales by z^t -- one product with an
+// entry of a 256-entry table a tiny kernel builds once per point -- and by z^(b S), which lane 0 computes for the whole workgroup while the
+// others run their loops; the grid reduces.  cnt + 2 products per lane.  (Until round 5 the subsequences were strided over the whole grid
+// and every lane raised z to its own global index: 8 select-multiplications for the lane bits + up to 10 for the block bits on top of the
+// cnt = 8 of its loop -- most of the kernel's arithmetic was exponentiation.)
 struct pow2_args {
-    fe_arg p[18];  // z^(2^i)
+    fe_arg p[28];  // z^(2^i)
 };
+__global__ __launch_bounds__(RED_THREADS) void zpow_table_kernel(pow2_args zp, fe* __restrict__ ztab) {  // ztab[t] = z^t, t < 256
+    PK_LATENCY_PRIO();
+    fe h = fe_one();
+#pragma unroll 1
+    for (int i = 0; i < 8; i++)
+        if ((threadIdx.x >> i) & 1u) h = fe_mulx(h, from_arg(zp.p[i]));
+    fe_store(ztab + threadIdx.x, h);
+}
 // NP polynomials of the same length at the same point in one launch (a batch commitment's OOD answers, mtUtilities.go:51-76)
 template <int NP>
-__global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restrict__ c, const fe* __restrict__ c_second, size_t n, pow2_args zp, fe_arg zT_arg,
-                                                             fe* __restrict__ partials, unsigned* __restrict__ ticket,
+__global__ __launch_bounds__(RED_THREADS) void horner_kernel(const fe* __restrict__ c, const fe* __restrict__ c_second, size_t n, size_t cnt, pow2_args zp,
+                                                             const fe* __restrict__ ztab, fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                              fe* __restrict__ result, unsigned seq) {
     PK_LATENCY_PRIO();
     __shared__ uint4 smem[NP * 16];
-    const fe zT = from_arg(zT_arg);
-    const size_t T = (size_t)gridDim.x * blockDim.x;
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned s_zb[8];
+    static_assert(RED_THREADS == 256, "the lane table has 256 entries");
+    const size_t base = (size_t)blockIdx.x * cnt * RED_THREADS;
+    if (threadIdx.x == 0) {  // z^(b S) for the workgroup: the set bits of b S select entries of the host's z^(2^i) table
+        fe zb = fe_one();
+        bool any = false;
+        for (int i = 8; i < 28; i++)
+            if ((base >> i) & 1u) {
+                zb = any ? fe_mulx(zb, from_arg(zp.p[i])) : from_arg(zp.p[i]);
+                any = true;
+            }
+#pragma unroll
+        for (int k = 0; k < 8; k++) s_zb[k] = zb.v[k];
+    }
+    const fe z256 = from_arg(zp.p[8]);
+    const size_t first = base + threadIdx.x;
     fe acc[NP];
 #pragma unroll
     for (int q = 0; q < NP; q++) acc[q] = fe_zero();
-#pragma unroll
-    for (int q = 0; q < NP; q++) {
-    const fe* cq = q == 0 ? c : c_second;
-    if (g < n) {
-        size_t cnt = (n - g + T - 1) / T;  // elements g, g+T, ..., g+(cnt-1)T
-        fe h = fe_load(cq + g + (cnt - 1) * T);
-        for (size_t j = cnt - 1; j-- > 0;) h = fe_add(fe_mulx(h, zT), fe_load(cq + g + j * T));
-        // z^g from the host's table of z^(2^i): the 8 lane bits by select, the block bits under a uniform branch
-        // (g < 2^18: at most 1024 blocks of 256 lanes)
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            fe t = fe_mulx(h, from_arg(zp.p[i]));
-            const bool bit = (threadIdx.x >> i) & 1u;
-#pragma unroll
-            for (int k = 0; k < 8; k++) h.v[k] = bit ? t.v[k] : h.v[k];
-        }
-        for (int i = 8; i < 18; i++)
-            if ((blockIdx.x >> (i - 8)) & 1u) h = fe_mulx(h, from_arg(zp.p[i]));
-        acc[q] = h;
+    size_t mine = 0;  // how many of this lane's cnt elements exist
+    if (first < n) {
+        mine = (n - first + RED_THREADS - 1) / RED_THREADS;
+        if (mine > cnt) mine = cnt;
     }
+    if (mine) {
+        const fe zt = fe_load(ztab + threadIdx.x);
+#pragma unroll
+        for (int q = 0; q < NP; q++) {
+            const fe* cq = q == 0 ? c : c_second;
+            fe h = fe_load(cq + first + (mine - 1) * RED_THREADS);
+            for (size_t j = mine - 1; j-- > 0;) h = fe_add(fe_mulx(h, z256), fe_load(cq + first + j * RED_THREADS));
+            acc[q] = fe_mulx(h, zt);
+        }
+    }
+    __syncthreads();
+    if (mine && base) {
+        fe zb;
+#pragma unroll
+        for (int k = 0; k < 8; k++) zb.v[k] = s_zb[k];
+#pragma unroll
+        for (int q = 0; q < NP; q++) acc[q] = fe_mulx(acc[q], zb);
     }
     grid_finish_fe<NP>(acc, smem, partials, ticket, result, seq);
 }
@@ -876,36 +903,32 @@ int eval_univariate_multi(pk_ctx* ctx, const uint64_t* const* d_polys, unsigned 
     }
     int rc = reduction_scratch(ctx);
     if (rc) return rc;
-    // ~8 coefficients per lane, at most RED_MAX_BLOCKS (1024) blocks
+    // ~8 coefficients per lane, at most RED_MAX_BLOCKS (1024) workgroups, each over a contiguous segment of 256 * cnt coefficients
     size_t want = (n / 8 + RED_THREADS - 1) / RED_THREADS;
-    unsigned blocks = (unsigned)(want < 1 ? 1 : (want > RED_MAX_BLOCKS ? RED_MAX_BLOCKS : want));
-    const u64 T = (u64)blocks * RED_THREADS;
-    // z^(2^i) and z^T on the host (a few dozen products)
-    fe zf, zT = fe_one();
-    memcpy(zf.v, z, 32);
+    const size_t cap = want < 1 ? 1 : (want > RED_MAX_BLOCKS ? RED_MAX_BLOCKS : want);
+    const size_t cnt = (n + cap * RED_THREADS - 1) / (cap * RED_THREADS);
+    const unsigned blocks = (unsigned)((n + cnt * RED_THREADS - 1) / (cnt * RED_THREADS));
+    PK_REQUIRE(ctx, (n >> 28) == 0, "polynomial too long for the evaluation kernel (2^28 coefficients)");
+    if (!ctx->d_ztab) PK_HIP(ctx, hipMalloc(&ctx->d_ztab, 256 * 32));
+    // z^(2^i) on the host (27 squarings)
     pow2_args zp;
     {
-        fe b = zf;
-        for (int i = 0; i < 18; i++) {
+        fe b;
+        memcpy(b.v, z, 32);
+        for (int i = 0; i < 28; i++) {
             memcpy(zp.p[i].v, b.v, 32);
-            if ((T >> i) & 1) zT = fe_mulx(zT, b);
-            b = fe_mulx(b, b);
-        }
-        for (u64 e = T >> 18; e; e >>= 1) {  // T <= 2^18, so at most the top bit is left
-            if (e & 1) zT = fe_mulx(zT, b);
             b = fe_mulx(b, b);
         }
     }
-    fe_arg zTa;
-    memcpy(zTa.v, zT.v, 32);
     {
         ProfScope prof(ctx, "eval_univariate");
+        zpow_table_kernel<<<1, RED_THREADS, 0, ctx->stream>>>(zp, (fe*)ctx->d_ztab);
         if (np == 1)
-            horner_kernel<1><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_polys[0], nullptr, n, zp, zTa, red_partials(ctx), red_ticket(ctx),
-                                                                     red_result(ctx), next_seq(ctx));
-        else
-            horner_kernel<2><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_polys[0], (const fe*)d_polys[1], n, zp, zTa, red_partials(ctx),
+            horner_kernel<1><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_polys[0], nullptr, n, cnt, zp, (const fe*)ctx->d_ztab, red_partials(ctx),
                                                                      red_ticket(ctx), red_result(ctx), next_seq(ctx));
+        else
+            horner_kernel<2><<<blocks, RED_THREADS, 0, ctx->stream>>>((const fe*)d_polys[0], (const fe*)d_polys[1], n, cnt, zp, (const fe*)ctx->d_ztab,
+                                                                     red_partials(ctx), red_ticket(ctx), red_result(ctx), next_seq(ctx));
     }
     PK_LAUNCH_CHECK(ctx);
     return np == 1 ? collect_reduction<1>(ctx, out) : collect_reduction<2>(ctx, out);

@@ -107,34 +107,55 @@ __host__ __device__ __forceinline__ void chacha_block(const RngKey& key, u64 cou
     for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
 }
 #undef PK_QR
+// A lane walks its pairs j = g, g + stride, ... as a state machine (pair, attempt): one ChaCha block per loop iteration, whichever pair and
+// attempt the lane is at.  (Until round 5 the retry loop sat INSIDE the loop over pairs, so a wavefront repeated a pair's block until its
+// unluckiest lane -- 128 candidates, each rejected with probability 0.244 -- was done: ~4 blocks per pair instead of the 1.43 a lane needs.
+// Now the waiting averages out over a lane's pairs: launched with ~8 pairs per lane, a wavefront runs ~17 blocks for 8 pairs.)
 __global__ __launch_bounds__(256) void random_fe_kernel(fe* __restrict__ out, size_t n, RngKey key, u32 stream) {
     PK_LATENCY_PRIO();
     const size_t stride = (size_t)gridDim.x * blockDim.x, pairs = (n + 1) / 2;
-    for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < pairs; j += stride) {
-        bool done[2] = {false, 2 * j + 1 >= n};
-        for (u32 attempt = 0; !(done[0] && done[1]); attempt++) {
-            u32 blk[16];
-            chacha_block(key, (u64)j, stream, attempt, PK_RNG_ROUNDS, blk);
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 attempt = 0;
+    bool done0 = false, done1 = 2 * j + 1 >= n;
+    while (j < pairs) {
+        u32 blk[16];
+        chacha_block(key, (u64)j, stream, attempt, PK_RNG_ROUNDS, blk);
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-                if (done[half]) continue;
-                fe x;
+        for (int half = 0; half < 2; half++) {
+            if (half == 0 ? done0 : done1) continue;
+            fe x;
 #pragma unroll
-                for (int w = 0; w < 8; w++) x.v[w] = blk[8 * half + w];
-                x.v[7] &= 0x3fffffffu;  // < 2^254
-                u32 borrow = 0;
+            for (int w = 0; w < 8; w++) x.v[w] = blk[8 * half + w];
+            x.v[7] &= 0x3fffffffu;  // < 2^254
+            u32 borrow = 0;
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    u64 t = (u64)x.v[k] - kPlimb(k) - borrow;
-                    borrow = (u32)(t >> 32) & 1u;
-                }
-                if (borrow) {  // x < p: accepted
-                    fe_store(out + 2 * j + half, x);
-                    done[half] = true;
-                }
+            for (int k = 0; k < 8; k++) {
+                u64 t = (u64)x.v[k] - kPlimb(k) - borrow;
+                borrow = (u32)(t >> 32) & 1u;
+            }
+            if (borrow) {  // x < p: accepted
+                fe_store(out + 2 * j + half, x);
+                if (half == 0) done0 = true;
+                else done1 = true;
             }
         }
+        if (done0 && done1) {
+            j += stride;
+            attempt = 0;
+            done0 = false;
+            done1 = 2 * j + 1 >= n;
+        } else {
+            attempt++;
+        }
     }
+}
+// ~8 pairs per lane (see the kernel), at least one wavefront per SIMD's worth of workgroups when the draw is long enough
+inline unsigned random_fe_grid(const pk_ctx* ctx, size_t n) {
+    const size_t pairs = (n + 1) / 2;
+    size_t blocks = (pairs + 256 * 8 - 1) / (256 * 8);
+    const size_t cap = (size_t)ctx->num_cus * 8;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)(blocks < cap ? blocks : cap);
 }
 // draws of one proof (the `stream` word of the nonce)
 enum { RNG_MASK = 1, RNG_G = 2, RNG_BLIND = 3, RNG_MASK_B = 4, RNG_G_B = 5, RNG_FILL = 6 };
@@ -773,8 +794,8 @@ int batch_commit_compute(pk_ctx* ctx, Arena& A, unsigned m, const pk_whir_config
     CK(pk_memcpy_d2d(ctx, f, d_evals, 32 * n_evals));
     {
         ProfScope prof(ctx, "random_fe");
-        random_fe_kernel<<<grid_for(ctx, half, 256), 256, 0, ctx->stream>>>(f + half, half, key, stream_mask);
-        random_fe_kernel<<<grid_for(ctx, N, 256), 256, 0, ctx->stream>>>(g, N, key, stream_g);
+        random_fe_kernel<<<random_fe_grid(ctx, half), 256, 0, ctx->stream>>>(f + half, half, key, stream_mask);
+        random_fe_kernel<<<random_fe_grid(ctx, N), 256, 0, ctx->stream>>>(g, N, key, stream_g);
     }
     PK_LAUNCH_CHECK(ctx);
     // f, g hold the evaluation forms (kept for the weighted sums); the coefficient forms go to fc, gc
@@ -1461,7 +1482,7 @@ int pk_selftest_random_fe(pk_ctx* ctx, const uint8_t seed32[32], uint32_t stream
     if (!n) return PK_OK;
     RngKey k;
     memcpy(k.k, seed32, 32);
-    random_fe_kernel<<<grid_for(ctx, n, 256), 256, 0, ctx->stream>>>((fe*)d_out, n, k, stream);
+    random_fe_kernel<<<random_fe_grid(ctx, n), 256, 0, ctx->stream>>>((fe*)d_out, n, k, stream);
     PK_LAUNCH_CHECK(ctx);
     return PK_OK;
 }
