@@ -45,37 +45,6 @@ __device__ __forceinline__ void lds_put(uint4* lo, uint4* hi, int i, const fe& x
 // ---------------------------------------------------------------- T1: evals <-> coeffs
 // EvaluationsList::to_coeffs (call sites provekit/prover/src/whir_r1cs.rs:195,198): for every
 // variable (index bit) h: v[i | h] -= v[i].  SUB=false gives the inverse (to_evals).
-// The levels of a tile [2^L rows][BT adjacent elements] held in LDS, three index bits at a time IN REGISTERS: a lane takes the 8 rows that differ
-// in bits [b0, b0 + 3) of the row index, applies those three levels (the per-bit operations commute: the transform is a tensor product) and puts
-// back the seven rows that changed -- one trip through LDS per three levels and one index computation per 8 elements, where every level used to
-// read both operands from LDS, write one back and recompute its indices (round 5: 105 -> about half the vector-ALU time of a proof's to_coeffs).
-template <bool SUB, int BT, int D>
-__device__ __forceinline__ void wavelet_round(uint4* lo, uint4* hi, unsigned L, unsigned b0) {
-    const int groups = ((1 << L) >> D) * BT;
-    for (int t = threadIdx.x; t < groups; t += 256) {
-        const int b = t % BT, g = t / BT;
-        const int low = g & ((1 << b0) - 1), high = g >> b0;
-        const int j0 = (high << (b0 + D)) | low;
-        fe x[1 << D];
-#pragma unroll
-        for (int k = 0; k < (1 << D); k++) x[k] = lds_get(lo, hi, (j0 + (k << b0)) * BT + b);
-#pragma unroll
-        for (int s = 0; s < D; s++)
-#pragma unroll
-            for (int k = 0; k < (1 << D); k++)
-                if (!((k >> s) & 1)) x[k | (1 << s)] = SUB ? fe_sub(x[k | (1 << s)], x[k]) : fe_add(x[k | (1 << s)], x[k]);
-#pragma unroll
-        for (int k = 1; k < (1 << D); k++) lds_put(lo, hi, (j0 + (k << b0)) * BT + b, x[k]);
-    }
-    __syncthreads();
-}
-template <bool SUB, int BT>
-__device__ __forceinline__ void wavelet_tile(uint4* lo, uint4* hi, unsigned L) {
-    unsigned b0 = 0;
-    for (; b0 + 3 <= L; b0 += 3) wavelet_round<SUB, BT, 3>(lo, hi, L, b0);
-    if (L - b0 == 2) wavelet_round<SUB, BT, 2>(lo, hi, L, b0);
-    else if (L - b0 == 1) wavelet_round<SUB, BT, 1>(lo, hi, L, b0);
-}
 // low kernel: bits [0, LOGT) on a contiguous tile of 2^LOGT elements held in LDS.
 template <bool SUB>
 __global__ __launch_bounds__(256) void wavelet_low_kernel(const fe* src, fe* data, unsigned logt) {
@@ -92,7 +61,16 @@ __global__ __launch_bounds__(256) void wavelet_low_kernel(const fe* src, fe* dat
         hi[e] = q[1];
     }
     __syncthreads();
-    wavelet_tile<SUB, 1>(lo, hi, logt);
+    for (unsigned s = 0; s < logt; s++) {
+        const int h = 1 << s;
+        for (int t = threadIdx.x; t < T / 2; t += 256) {
+            int pos = t & (h - 1);
+            int i0 = ((t - pos) << 1) + pos, i1 = i0 + h;
+            fe a = lds_get(lo, hi, i0), b = lds_get(lo, hi, i1);
+            lds_put(lo, hi, i1, SUB ? fe_sub(b, a) : fe_add(b, a));
+        }
+        __syncthreads();
+    }
     for (int e = threadIdx.x; e < T; e += 256) {
         uint4* q = reinterpret_cast<uint4*>(base + e);
         q[0] = lo[e];
@@ -118,7 +96,17 @@ __global__ __launch_bounds__(256) void wavelet_high_kernel(fe* __restrict__ data
         hi[e] = q[1];
     }
     __syncthreads();
-    wavelet_tile<SUB, BT>(lo, hi, logr);
+    for (unsigned st = 0; st < logr; st++) {
+        const int h = 1 << st;
+        for (int t = threadIdx.x; t < (R / 2) * BT; t += 256) {
+            int b = t % BT, j = t / BT;
+            int pos = j & (h - 1);
+            int i0 = ((j - pos) << 1) + pos, i1 = i0 + h;
+            fe a = lds_get(lo, hi, i0 * BT + b), c = lds_get(lo, hi, i1 * BT + b);
+            lds_put(lo, hi, i1 * BT + b, SUB ? fe_sub(c, a) : fe_add(c, a));
+        }
+        __syncthreads();
+    }
     for (int e = threadIdx.x; e < TILE; e += 256) {
         int b = e % BT, r = e / BT;
         uint4* q = reinterpret_cast<uint4*>(base + ((size_t)r << s) + b);
