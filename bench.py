@@ -812,6 +812,30 @@ def main():
         return emit(single_stream_probe(provekit_amd, torch, local_rank, args.m, not args.no_latency_pass))
 
     m = args.m
+
+    def run_size_classes():
+        import subprocess
+
+        figs = {}
+        for mm in [int(x) for x in args.size_classes.split(",") if x.strip()]:
+            try:  # a fresh process per class on this GPU (see --size-class-probe)
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "PK_BENCH_FORCE_DIST")}
+                env["LOCAL_RANK"] = str(local_rank)  # the same device; no process group in the child
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--size-class-probe", str(mm)], env=env, capture_output=True, text=True,
+                                     timeout=600)
+                lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+                figs[str(mm)] = json.loads(lines[-1]) if out.returncode == 0 and lines else {"error": (out.stderr or "no output")[-200:]}
+            except Exception as e:  # noqa: BLE001
+                figs[str(mm)] = {"error": str(e)[:200]}
+        return figs
+
+    # On one GPU the size classes are measured FIRST, before this process creates a prover: taken after the main run they read 6-7 % low (m = 23:
+    # 59.6 against 64.2 proofs/s, m = 25: 14.2 against 15.1, alternating on one box; the headline is the same either way: 268.6 / 268.0) -- the chip has
+    # just spent seconds at its power limit and this process still holds queues on it.  Under several ranks they stay at the end (rank 0 would keep the
+    # others waiting inside the communicator probe's watchdog).
+    size_figs = {}
+    if os.environ.get("PK_BENCH_SIZE_CLASSES_LAST") != "1" and rank == 0 and m == 21 and not args.sharded and args.size_classes and world == 1:
+        size_figs = run_size_classes()
     # The one-proof-at-a-time figures of a process that will run its provers' threads in blocking-wait mode are taken by a FRESH process in
     # the default spinning mode, and FIRST, before this process creates a prover (a second process on a GPU where another holds two dozen idle
     # hardware queues runs ~3.5 % slower -- measured: 9.9 against 9.6 ms per proof)
@@ -1051,10 +1075,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         gpu_proof = workers[0][1].prove(workers[0][2], seed=cpu_seed)
     # (c) the other BASELINE size classes (configs[2] m = 23, configs[3] m = 25), rank 0's GPU only
-    size_figs = {}
-    if rank == 0 and m == 21 and not args.sharded and args.size_classes:
-        import subprocess
-
+    if rank == 0 and m == 21 and not args.sharded and args.size_classes and not size_figs:
         for c_, prover_, d_z_, r1cs_, _ in workers:
             prover_.close()
             d_z_.free()
@@ -1062,16 +1083,7 @@ def main():
             c_.close()
         workers.clear()
         torch.cuda.empty_cache()
-        for mm in [int(x) for x in args.size_classes.split(",") if x.strip()]:
-            try:  # a fresh process per class on this GPU (see --size-class-probe)
-                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "TORCHELASTIC_RUN_ID", "PK_BENCH_FORCE_DIST")}
-                env["LOCAL_RANK"] = str(local_rank)  # the same device; no process group in the child
-                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--size-class-probe", str(mm)], env=env, capture_output=True, text=True,
-                                     timeout=600)
-                lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-                size_figs[str(mm)] = json.loads(lines[-1]) if out.returncode == 0 and lines else {"error": (out.stderr or "no output")[-200:]}
-            except Exception as e:  # noqa: BLE001
-                size_figs[str(mm)] = {"error": str(e)[:200]}
+        size_figs = run_size_classes()
     if dist is not None and not hung_any:
         dist.barrier()
 
