@@ -40,7 +40,7 @@ def configs(m, m_0, pow_bits, queries=None):
     return vcfg(cw), vcfg(cb), create_io_pattern(m_0, cw, cb)
 
 
-@pytest.mark.parametrize("m,m_0,nc,n_in,pow_bits", [(9, 7, 100, 60, 5.0), (12, 9, 500, 700, 4.0)])
+@pytest.mark.parametrize("m,m_0,nc,n_in,pow_bits", [(9, 7, 100, 60, 5.0), (12, 9, 500, 700, 4.0), (16, 14, 12000, 3000, 6.0)])
 def test_oracle_prover_is_accepted_by_the_oracle_verifier(oracle, m, m_0, nc, n_in, pow_bits):
     import prover_ref as PR
     import verifier as V
