@@ -536,21 +536,9 @@ int pk_noir_prove(pk_ctx *ctx, pk_scheme *scheme, pk_witness_program *builders, 
                   const uint32_t *public_acir_idx, size_t n_public, const uint8_t *rng_seed32, uint8_t *transcript_out,
                   size_t cap, size_t *len);
 
-/* ------------------------------------------------------------------ self-test (host only, no device)
- * Runs the library's __host__ __device__ arithmetic (the same source the kernels compile) on the CPU:
- * op 0: a*b*2^-256 mod p (ark-ff mul)   1: Skyscraper v2 compress   2: v1 compress   3: from Montgomery
- * 4/5: the lazy 29-bit product / square followed by exact reduction.  n elements of 4 x u64 each. */
-/* host-only pieces of the transcript: domain-separator tag, one sponge permutation on canonical (l, r) */
-int pk_selftest_keccak_tag(const uint8_t *data, size_t len, uint8_t tag[32]);
-int pk_selftest_permute(uint64_t l[4], uint64_t r[4]);
-int pk_selftest_arith(int op, const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n);
-/* the proof RNG: one ChaCha block (host; RFC 8439 state layout, words 12-13 = counter, 14-15 = nonce; `rounds` = 20 for the
- * RFC's vectors, 12 is what the library runs -- rand's ThreadRng cipher) and the device draw of n uniform field elements
- * for (seed32, stream): elements 2j, 2j+1 take the first / second 254-bit candidate of blocks (counter j, nonce {stream,
- * attempt}), attempt = 0, 1, ... until the candidate is < p */
-int pk_selftest_chacha(const uint8_t key[32], uint64_t counter, uint32_t n0, uint32_t n1, int rounds, uint8_t out[64]);
-int pk_selftest_random_fe(pk_ctx *ctx, const uint8_t seed32[32], uint32_t stream, uint64_t *d_out, size_t n);
-/* Measurement probes (multiplier peak rates, round-trip costs), the device-side run of the op table above and the prototypes that
+/* The library also exports a handful of pk_selftest_* entry points (the host build of the device arithmetic, the proof RNG): test
+ * infrastructure for this repository's CPU suite, declared in tools/probes/pk_selftest.h -- not part of the binder's API.
+ * Measurement probes (multiplier peak rates, round-trip costs), the device-side run of the self-test op table and the prototypes that
  * were measured and rejected are NOT part of this library: tools/probes builds them into libpk_probes.so (tools/probes/pk_probes.h). */
 
 #ifdef __cplusplus

@@ -30,7 +30,7 @@
 // partly memory-bound (VALUBusy ~75 %): between the pure-ALU hash kernels (0) and the memory-bound kernels (2)
 #define PK_BASE_PRIO 1
 #include "ctx.hpp"
-#include "fe29.hpp"
+#include "ntt_regs.hpp"
 
 using namespace pk;
 
@@ -81,23 +81,29 @@ __global__ __launch_bounds__(256) void twiddle_scale_kernel(const fe* __restrict
     fe_store(Ws + j, fe_mulx(fe_load(W + j), c));
 }
 
-__global__ __launch_bounds__(256) void twiddle_unpack_kernel(const fe* __restrict__ W, u32* __restrict__ W29, size_t n) {
+// The register-radix kernel's multiplier table: entry j = the constant c_j that multiplying by X[j] in the Montgomery product amounts to
+// (c = X[j] * 2^-256 mod p: the plain w for the table of Montgomery images W, 32 w 2^-256 for the hash-ready table Ws), canonical, as
+// 29-bit limbs, followed by its Shoup quotient floor(c * 2^261 / p) (exact: 261 steps of long division, once per table).
+__global__ __launch_bounds__(256) void twiddle_shoup_kernel(const fe* __restrict__ X, u32* __restrict__ T, size_t n) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
-    fe29 t = unpack29<5>(fe_load(W + j));
+    const fe29 c = unpack29<0>(fe_from_montx(fe_load(X + j)));
+    const fe29 cq = shoup_quotient29(c);
 #pragma unroll
-    for (int l = 0; l < 9; l++) W29[9 * j + l] = t.v[l];
+    for (int l = 0; l < 9; l++) T[TW29S_WORDS * j + l] = c.v[l];
+#pragma unroll
+    for (int l = 0; l < 9; l++) T[TW29S_WORDS * j + 9 + l] = cq.v[l];
 }
 
-// T[k * row + v] = src29[(mul * k * v) & mask]: an inter-pass twiddle table re-ordered into the order the pass reads it
-__global__ __launch_bounds__(256) void twiddle_pass_table_kernel(const u32* __restrict__ src29, u32* __restrict__ T, size_t rows_k, size_t row, size_t mul,
+// T[k * row + v] = src[(mul * k * v) & mask]: an inter-pass twiddle table re-ordered into the order the pass reads it
+__global__ __launch_bounds__(256) void twiddle_pass_table_kernel(const u32* __restrict__ src, u32* __restrict__ T, size_t rows_k, size_t row, size_t mul,
                                                                  size_t mask) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows_k * row) return;
     const size_t k = i / row, v = i % row;
-    const u32* q = src29 + 9 * ((mul * k * v) & mask);
+    const u32* q = src + TW29S_WORDS * ((mul * k * v) & mask);
 #pragma unroll
-    for (int l = 0; l < 9; l++) T[9 * i + l] = q[l];
+    for (int l = 0; l < TW29S_WORDS; l++) T[TW29S_WORDS * i + l] = q[l];
 }
 
 struct PassParams {
@@ -111,10 +117,10 @@ struct PassParams {
     size_t in_nat_r, in_nat_v, in_nat_u;  // natural-index weights for the zero test
     const fe* W;        // w_N^e table, N entries
     const fe* Wtw;      // table the inter-pass twiddle is read from: W, or its hash-ready variant 32*w_N^e (see ntt_columns)
-    const u32* W29;     // W again, every entry already in the multiplier's operand form (9 limbs of 32*w): register-radix kernel
+    const u32* W29;     // W again as Shoup multipliers (ntt_regs.hpp tw29s: 9 limbs of the value + 9 of its quotient): register-radix kernel
     const u32* Wtw29;   // Wtw likewise
     const u32* Tpass29; // optional: the inter-pass twiddles of THIS pass in access order, T[k * tp_row + (v0 + b)] = w_N^(tw_mul k (v0+b))
-                        // in operand form (or its hash-ready variant) -- adjacent lanes read adjacent 36-byte entries instead of
+                        // in operand form (or its hash-ready variant) -- adjacent lanes read adjacent 72-byte entries instead of
                         // gathering from the size-N table at stride k; null = gather from Wtw29
     size_t tp_row;      // entries per k of Tpass29 (the extent of the v axis)
     size_t tiles;       // register-radix kernel: tiles per column, columns, and whether the XCD-aware block order applies
@@ -239,54 +245,6 @@ __global__ __launch_bounds__(NTHREADS) void ntt_pass_kernel(PassParams p) {
 // Tile index I (11 bits) = r * BT + b.  Round j transforms digit D_j of r (digits are taken from the top of r: DIF),
 // leaving the frequency digit a_j in the same bit positions; the output frequency is the digit reversal
 // k = a_0 + 2^d0 a_1 + 2^(d0+d1) a_2.  In round j a lane's 8 registers are indexed by (digit bits | low 3-d_j bits of b).
-__device__ __forceinline__ fe29 red29(fe29 x) {  // lazy non-negative limbs, value < 4p -> normalized, < p(1+2^-10)
-    reduce_almost29(x);
-    return x;
-}
-// a - b + 2p with borrow-proof limbs (b normalized, value < 2p): result limbs < 2^30.6, value < a + 2p
-__host__ __device__ __forceinline__ constexpr u32 c2p29(int k) {
-    return k == 0 ? kp29(2, 0) + (1u << 29) : (k < 8 ? kp29(2, k) + (1u << 29) - 1u : kp29(2, 8) - 1u);
-}
-__device__ __forceinline__ fe29 sub2p29(const fe29& a, const fe29& b) {
-    fe29 r;
-#pragma unroll
-    for (int k = 0; k < 9; k++) r.v[k] = a.v[k] + c2p29(k) - b.v[k];
-    return r;
-}
-__device__ __forceinline__ fe29 tw29(const fe* W, size_t idx) { return unpack29<5>(fe_load(W + idx)); }
-// the same operand from the pre-unpacked table (36 bytes per entry): no shifting and masking per multiplication
-__device__ __forceinline__ fe29 tw29u(const u32* __restrict__ W29, size_t idx) {
-    const u32* q = W29 + 9 * idx;
-    fe29 t;
-#pragma unroll
-    for (int l = 0; l < 9; l++) t.v[l] = q[l];
-    return t;
-}
-
-template <int D>  // radix-2^D DIF over the top D bits of the register index; low 3-D bits are independent batches
-__device__ __forceinline__ void dft_regs(fe29 (&x)[8], const fe29& w8_1, const fe29& w8_2, const fe29& w8_3) {
-    constexpr int E = 3 - D;
-#pragma unroll
-    for (int s = 0; s < D; s++) {
-#pragma unroll
-        for (int t = 0; t < 4; t++) {  // the 4 butterflies of this stage over 8 registers
-            const int bp = E + (D - 1 - s);  // register-index bit paired in this stage
-            const int i0 = ((t >> bp) << (bp + 1)) | (t & ((1 << bp) - 1)), i1 = i0 | (1 << bp);
-            const int half = 1 << (D - 1 - s);
-            const int pos = (i0 >> E) & (half - 1);
-            const int wexp = (pos << s) << (3 - D);  // exponent of w_8
-            const bool last = (s == D - 1);
-            fe29 a = x[i0], b = x[i1];
-            fe29 sum = add29(a, b);
-            fe29 dif = sub2p29(a, b);
-            x[i0] = last ? sum : red29(sum);  // the last stage's outputs go straight into the twiddle multiply
-            if (wexp == 0)
-                x[i1] = last ? dif : red29(dif);
-            else
-                x[i1] = mont261_29(dif, wexp == 1 ? w8_1 : (wexp == 2 ? w8_2 : w8_3));
-        }
-    }
-}
 __host__ __device__ __forceinline__ constexpr int bitrev_c(int v, int bits) {
     int r = 0;
     for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);
@@ -300,18 +258,19 @@ struct Ntt8Ctx {
     unsigned tid;
 };
 
+// LE = log2 of the elements a lane holds (NTT_LE = 2: four registers, radix-4 rounds, 512 lanes per tile).
 // one round (digit J) of the register NTT; everything about the digit layout is a compile-time constant
-template <int LOG_R, int J>
-__device__ __forceinline__ void ntt8_round(fe29 (&x)[8], const PassParams& p, const Ntt8Ctx& c, u32* planes, const fe29& w8_1,
-                                           const fe29& w8_2, const fe29& w8_3) {
+template <int LE, int LOG_R, int J>
+__device__ __forceinline__ void ntt8_round(fe29 (&x)[1 << LE], const PassParams& p, const Ntt8Ctx& c, u32* planes) {
+    constexpr int NX = 1 << LE;
     constexpr int LOGB = 11 - LOG_R, BTT = 1 << LOGB;
-    constexpr int NR = (LOG_R + 2) / 3;
-    constexpr int D0 = LOG_R - 3 * (NR - 1);
-    constexpr int D = J == 0 ? D0 : 3;
-    constexpr int DONE = J == 0 ? 0 : D0 + 3 * (J - 1);  // r bits consumed before this round
-    constexpr int POS = LOGB + LOG_R - DONE - D;          // bit offset of digit J inside the tile index
-    constexpr int E = 3 - D;
-    constexpr int REST = POS - LOGB;                      // r bits below this digit
+    constexpr int NR = (LOG_R + LE - 1) / LE;
+    constexpr int D0 = LOG_R - LE * (NR - 1);
+    constexpr int D = J == 0 ? D0 : LE;
+    constexpr int DONE = J == 0 ? 0 : D0 + LE * (J - 1);  // r bits consumed before this round
+    constexpr int POS = LOGB + LOG_R - DONE - D;           // bit offset of digit J inside the tile index
+    constexpr int E = LE - D;
+    constexpr int REST = POS - LOGB;                       // r bits below this digit
     constexpr int LO = POS - E;
     const unsigned tid = c.tid;
     // tile index of (tid, reg): [tid hi][digit][tid lo][extra]
@@ -319,7 +278,7 @@ __device__ __forceinline__ void ntt8_round(fe29 (&x)[8], const PassParams& p, co
 #define PK_TILE_INDEX(reg) (base_idx | ((reg) & ((1 << E) - 1)) | (((reg) >> E) << POS))
     if (J == 0) {
 #pragma unroll
-        for (int reg = 0; reg < 8; reg++) {
+        for (int reg = 0; reg < NX; reg++) {
             const int I = PK_TILE_INDEX(reg);
             const int r = I >> LOGB, b = I & (BTT - 1);
             size_t nat = c.nat0 + (size_t)r * p.in_nat_r + (size_t)b * p.in_nat_v;
@@ -330,47 +289,49 @@ __device__ __forceinline__ void ntt8_round(fe29 (&x)[8], const PassParams& p, co
     } else {
         __syncthreads();
 #pragma unroll
-        for (int reg = 0; reg < 8; reg++) {
+        for (int reg = 0; reg < NX; reg++) {
             const int I = PK_TILE_INDEX(reg);
 #pragma unroll
             for (int l = 0; l < 9; l++) x[reg].v[l] = planes[l * 2048 + I];
         }
         __syncthreads();
     }
-    dft_regs<D>(x, w8_1, w8_2, w8_3);
+    dft_regs<LE, D>(x);
     const int m = (base_idx >> LOGB) & ((1 << REST) - 1);  // r bits below the digit: index inside the sub-transform
     if (J + 1 < NR) {
         const size_t unit = p.wr_step << (LOG_R - D - REST);  // w_{2^(D+REST)} in units of w_N
 #pragma unroll
-        for (int reg = 0; reg < 8; reg++) {
-            constexpr int dummy = 0;
-            (void)dummy;
+        for (int reg = 0; reg < NX; reg++) {
             const int a = bitrev_c(reg >> E, D);
-            fe29 y = a == 0 ? red29(x[reg]) : mont261_29(x[reg], tw29u(p.W29, (size_t)(a * m) * unit));
+            fe29 y = a == 0 ? red29(x[reg]) : mul_tw(x[reg], tw29s_load(p.W29, (size_t)(a * m) * unit));  // a == 0: the sum of sums
             const int I = (PK_TILE_INDEX(reg) & ~(((1 << D) - 1) << POS)) | (a << POS);  // keep the true frequency digit
 #pragma unroll
             for (int l = 0; l < 9; l++) planes[l * 2048 + I] = y.v[l];
         }
     } else {
-        // frequency digits of the earlier rounds sit above this digit in the index (already true frequencies)
+        // frequency digits of the earlier rounds sit above this digit in the index (already true frequencies): digit j, d_j bits
+        // wide, sits d_0 + ... + d_j below the top of r and weighs 2^(d_0 + ... + d_(j-1)) in k
         const int rr = base_idx >> LOGB;
         int k_hi = 0;
-        if (J >= 1) k_hi |= (rr >> (LOG_R - D0)) & ((1 << D0) - 1);
-        if (J >= 2) k_hi |= ((rr >> (LOG_R - D0 - 3)) & 7) << D0;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int dj = j == 0 ? D0 : LE, done_j = j == 0 ? 0 : D0 + LE * (j - 1);
+            k_hi |= ((rr >> (LOG_R - done_j - dj)) & ((1 << dj) - 1)) << done_j;
+        }
         constexpr int KLO = DONE;
 #pragma unroll
-        for (int reg = 0; reg < 8; reg++) {
+        for (int reg = 0; reg < NX; reg++) {
             const int a = bitrev_c(reg >> E, D);
             const int b = PK_TILE_INDEX(reg) & (BTT - 1);
             const int k = k_hi | (a << KLO);
             fe29 y;
             if (p.tw_mul && p.Tpass29) {
-                y = mont261_29(x[reg], tw29u(p.Tpass29, (size_t)k * p.tp_row + (c.v0 + b)));
+                y = mul_tw(x[reg], tw29s_load(p.Tpass29, (size_t)k * p.tp_row + (c.v0 + b)));
             } else if (p.tw_mul) {
                 size_t ex = (p.tw_mul * (size_t)k * (c.v0 + b)) & p.n_mask;
-                y = mont261_29(x[reg], tw29u(p.Wtw29, ex));
+                y = mul_tw(x[reg], tw29s_load(p.Wtw29, ex));
             } else {
-                y = red29(x[reg]);
+                y = a == 0 ? red29(x[reg]) : red29w(x[reg]);
             }
             fe_store(c.out + (size_t)k * p.out_stride_r + (size_t)b * p.out_stride_v, pack29(p.lazy_store ? y : cond_sub_p29(y)));
         }
@@ -378,11 +339,19 @@ __device__ __forceinline__ void ntt8_round(fe29 (&x)[8], const PassParams& p, co
 #undef PK_TILE_INDEX
 }
 
-template <int LOG_R, bool IN_R_CONTIG>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ntt8_pass_kernel(PassParams p) {
+template <int LE, int LOG_R, int J>
+__device__ __forceinline__ void ntt8_rounds_from(fe29 (&x)[1 << LE], const PassParams& p, const Ntt8Ctx& c, u32* planes) {
+    constexpr int NR = (LOG_R + LE - 1) / LE;
+    if constexpr (J < NR) {
+        ntt8_round<LE, LOG_R, J>(x, p, c, planes);
+        ntt8_rounds_from<LE, LOG_R, J + 1>(x, p, c, planes);
+    }
+}
+
+template <int LE, int LOG_R, bool IN_R_CONTIG>
+__global__ __launch_bounds__(2048 >> LE) __attribute__((amdgpu_waves_per_eu(4, 4))) void ntt8_pass_kernel(PassParams p) {
     PK_LATENCY_PRIO();
     constexpr int LOGB = 11 - LOG_R;
-    constexpr int NR = (LOG_R + 2) / 3;
     extern __shared__ u32 planes[];  // [9][2048]
     const size_t vblocks = ((size_t)1 << p.log_v) >> LOGB;
     // block -> (tile, column).  Workgroup b runs on XCD b % 8 (observed placement, used for speed only): an XCD takes the tiles
@@ -404,12 +373,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2, 2))
     c.out = p.out + col * p.out_col_stride + u * p.out_stride_u + c.v0 * p.out_stride_v;
     c.nat0 = u * p.in_nat_u + c.v0 * p.in_nat_v;
     c.tid = threadIdx.x;
-    const size_t N8 = (p.n_mask + 1) >> 3;
-    const fe29 w8_1 = tw29u(p.W29, N8), w8_2 = tw29u(p.W29, 2 * N8), w8_3 = tw29u(p.W29, 3 * N8);
-    fe29 x[8];
-    ntt8_round<LOG_R, 0>(x, p, c, planes, w8_1, w8_2, w8_3);
-    if (NR > 1) ntt8_round<LOG_R, (NR > 1 ? 1 : 0)>(x, p, c, planes, w8_1, w8_2, w8_3);
-    if (NR > 2) ntt8_round<LOG_R, (NR > 2 ? 2 : 0)>(x, p, c, planes, w8_1, w8_2, w8_3);
+    fe29 x[1 << LE];
+    ntt8_rounds_from<LE, LOG_R, 0>(x, p, c, planes);
 }
 
 // c[2^k t + j] -> S[j][t]  (t < L): stride-2^k gather done through LDS so both sides coalesce
@@ -571,8 +536,8 @@ int get_twiddles29(pk_ctx* ctx, unsigned log_n, int which, const fe* W, const u3
     int rc = shared_table(ctx, ((which ? TK_WS29 : TK_W29) << 56) | log_n, &T, [&](void** made) {
         const size_t n = (size_t)1 << log_n;
         u32* U = nullptr;
-        PK_HIP(ctx, hipMalloc((void**)&U, 36 * (n < 2 ? 2 : n)));
-        twiddle_unpack_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(W, U, n);
+        PK_HIP(ctx, hipMalloc((void**)&U, 4 * TW29S_WORDS * (n < 2 ? 2 : n)));
+        twiddle_shoup_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(W, U, n);
         PK_LAUNCH_CHECK(ctx);
         *made = U;
         return (int)PK_OK;
@@ -599,7 +564,7 @@ int get_pass_table(pk_ctx* ctx, unsigned log_n, unsigned pass, bool scaled, cons
     int rc = shared_table(ctx, (TK_PASS << 56) | key, &T, [&](void** made) {
         u32* U = nullptr;
         const size_t n = rows_k * row;
-        PK_HIP(ctx, hipMalloc((void**)&U, 36 * n));
+        PK_HIP(ctx, hipMalloc((void**)&U, 4 * TW29S_WORDS * n));
         twiddle_pass_table_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(src29, U, rows_k, row, mul, ((size_t)1 << log_n) - 1);
         PK_LAUNCH_CHECK(ctx);
         *made = U;
@@ -614,6 +579,26 @@ int get_pass_table(pk_ctx* ctx, unsigned log_n, unsigned pass, bool scaled, cons
 // does a pass of radix 2^log_r over a v axis of 2^log_v take the register-radix kernel?
 inline bool pass_is_fast(unsigned log_r, unsigned log_v, size_t N) { return log_r >= 3 && log_v < 62 && log_v >= 11 - log_r && N >= 8; }
 
+// elements per lane of the register-radix kernel (log2): four per lane, 512 lanes per 2048-element tile, 118 registers -> four waves per
+// SIMD.  (Eight per lane -- radix-8 rounds, one LDS exchange fewer per three stages, 190 registers, two waves per SIMD -- measured 74 %
+// VALUBusy against 89 % and 6-9 % slower from 2^19 rows up: profiles/r06_ntt_le_ab.jsonl.)
+constexpr int NTT_LE = 2;
+
+template <int LE, int LOG_R, bool CONTIG>
+int launch_fast(pk_ctx* ctx, const PassParams& pp, unsigned grid) {
+    const size_t lds_bytes = 9 * 2048 * 4;
+    // the 72 KiB dynamic-LDS opt-in is a per-function, per-device attribute: set it once per device, not per launch
+    static std::atomic<unsigned long long> lds_set{0};
+    const unsigned long long dev_bit = 1ull << (ctx->device & 63);
+    if (!(lds_set.load(std::memory_order_acquire) & dev_bit)) {
+        PK_HIP(ctx, hipFuncSetAttribute((const void*)ntt8_pass_kernel<LE, LOG_R, CONTIG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        lds_set.fetch_or(dev_bit, std::memory_order_release);
+    }
+    ntt8_pass_kernel<LE, LOG_R, CONTIG><<<dim3(grid, 1), 2048 >> LE, lds_bytes, ctx->stream>>>(pp);
+    PK_LAUNCH_CHECK(ctx);
+    return PK_OK;
+}
+
 template <int LOG_R>
 int launch_pass_r(pk_ctx* ctx, const PassParams& p, bool in_r_contig, size_t tiles, unsigned ncols) {
     constexpr int R = 1 << LOG_R;
@@ -621,31 +606,14 @@ int launch_pass_r(pk_ctx* ctx, const PassParams& p, bool in_r_contig, size_t til
     if (pass_is_fast(LOG_R, p.log_v, p.n_mask + 1)) {
         ProfScope prof(ctx, in_r_contig ? "ntt_pass_last" : "ntt_pass");
         const size_t tiles8 = (tiles * BT) >> (11 - LOG_R);
-        const size_t lds_bytes = 9 * 2048 * 4;
         PassParams pp = p;
         pp.tiles = tiles8;
         pp.ncols = ncols;
         pp.xcd_tiles = (p.Tpass29 != nullptr && tiles8 % 8 == 0) ? 1 : 0;  // the XCD order exists to share the pass table's rows
         PK_REQUIRE(ctx, tiles8 * ncols < ((size_t)1 << 31), "NTT launch too large");
-        dim3 grid((unsigned)(tiles8 * ncols), 1);
-        // the 72 KiB dynamic-LDS opt-in is a per-function, per-device attribute: set it once per device, not per launch
-        static std::atomic<unsigned long long> lds_set[2] = {{0}, {0}};
-        const unsigned long long dev_bit = 1ull << (ctx->device & 63);
-        if (!(lds_set[in_r_contig].load(std::memory_order_acquire) & dev_bit)) {
-            if (in_r_contig)
-                PK_HIP(ctx, hipFuncSetAttribute((const void*)ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), true>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            else
-                PK_HIP(ctx, hipFuncSetAttribute((const void*)ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-            lds_set[in_r_contig].fetch_or(dev_bit, std::memory_order_release);
-        }
-        if (in_r_contig)
-            ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), true><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(pp);
-        else
-            ntt8_pass_kernel<(LOG_R >= 3 ? LOG_R : 3), false><<<grid, NTHREADS, lds_bytes, ctx->stream>>>(pp);
-        PK_LAUNCH_CHECK(ctx);
-        return PK_OK;
+        const unsigned grid = (unsigned)(tiles8 * ncols);
+        constexpr int LR = LOG_R >= 3 ? LOG_R : 3;
+        return in_r_contig ? launch_fast<NTT_LE, LR, true>(ctx, pp, grid) : launch_fast<NTT_LE, LR, false>(ctx, pp, grid);
     }
     ProfScope prof(ctx, in_r_contig ? "ntt_pass_last" : "ntt_pass");
     size_t lds_bytes = (size_t)(2 * R * BT + 2 * (R / 2 > 0 ? R / 2 : 1)) * 16;

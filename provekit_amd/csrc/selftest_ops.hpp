@@ -7,6 +7,7 @@
 #include "reduce.hpp"
 #include "feinv.hpp"
 #include "skyscraper29s.hpp"
+#include "ntt_regs.hpp"
 
 namespace pk {
 
@@ -81,6 +82,21 @@ PK_HD fe selftest_op(int op, const fe& x, const fe& y) {
             fe29 t = shoup261_29(a, w, shoup_quotient29(w));
             reduce_almost29(t);
             r = pack29(cond_sub_p29(t));
+            break;
+        }
+        case 26: {  // the in-register constants of the NTT (ntt_regs.hpp): w_8^e for e = x mod 4 (1..3), word 7 bit 31 set iff the stored
+                    // quotient differs from floor(w 2^261 / p) recomputed by long division
+            const int e = (int)(x.v[0] & 3u);
+            fe29 w, wq;
+            for (int k = 0; k < 9; k++) {
+                w.v[k] = e == 1 ? w8_29(1, k) : (e == 2 ? w8_29(2, k) : w8_29(3, k));
+                wq.v[k] = e == 1 ? w8q_29(1, k) : (e == 2 ? w8q_29(2, k) : w8q_29(3, k));
+            }
+            const fe29 q = shoup_quotient29(w);
+            bool same = true;
+            for (int k = 0; k < 9; k++) same = same && q.v[k] == wq.v[k];
+            r = pack29(w);
+            if (!same) r.v[7] |= 0x80000000u;
             break;
         }
         case 21: r = fe_inverse_mont(x); break;   // feinv.hpp: Montgomery in, Montgomery out (0 -> 0)

@@ -10,8 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "provekit_hip.h")
 
 
-def declared_symbols():
-    src = open(HEADER).read()
+SELFTEST_HEADER = os.path.join(ROOT, "tools", "probes", "pk_selftest.h")
+
+
+def declared_symbols(header=HEADER):
+    src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(pk_[a-z0-9_]+)\s*\(", src)))
 
@@ -33,6 +36,22 @@ def test_python_binding_covers_header():
     from provekit_amd import _lib
 
     assert sorted(_lib.SIGNATURES) == declared_symbols()
+    assert sorted(_lib.SELFTEST_SIGNATURES) == declared_symbols(SELFTEST_HEADER)
+
+
+def test_the_product_header_holds_only_the_binders_api():
+    """the self-test entry points are declared next to the probes (tools/probes/pk_selftest.h), not in include/provekit_hip.h; the
+    two headers together are exactly what the library exports"""
+    import subprocess
+
+    from provekit_amd import _lib
+
+    api, selftests = declared_symbols(), declared_symbols(SELFTEST_HEADER)
+    assert not [s for s in api if s.startswith(("pk_selftest", "pk_probe"))]
+    assert all(s.startswith("pk_selftest_") for s in selftests) and len(api) == 102
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r" T (pk_[a-z0-9_]+)$", nm, flags=re.M)))
+    assert exported == sorted(api + selftests)
 
 
 def test_no_gpu_fails_loudly():

@@ -217,3 +217,60 @@ def test_shoup_product_by_a_constant(oracle):
     a, b = oracle.ints_to_limbs(xs), oracle.ints_to_limbs(ys)
     assert oracle.limbs_to_ints(run(24, a, b)) == [x * (y % P) % P for x, y in zip(xs, ys)]
     assert oracle.limbs_to_ints(run(25, a, b)) == [((x % P) + (y % P)) * (y % P) % P for x, y in zip(xs, ys)]
+
+
+ROOT28 = 19103219067921713944291392827692070036145651957329286315305642004821462161904  # ark-bn254 Fr::TWO_ADIC_ROOT_OF_UNITY
+W8 = pow(ROOT28, 1 << 25, P)
+
+
+def test_ntt_w8_constants_and_their_shoup_quotients(oracle):
+    """ntt_regs.hpp: the three in-register multipliers w_8, w_8^2, w_8^3 of the NTT's butterfly network are compile-time constants;
+    recompute them from the two-adic root and check each stored quotient floor(w 2^261 / p) against the long division"""
+    assert pow(W8, 8, P) == 1 and pow(W8, 4, P) == P - 1
+    got = oracle.limbs_to_ints(run(26, oracle.ints_to_limbs([1, 2, 3])))
+    assert got == [pow(W8, e, P) for e in (1, 2, 3)]  # bit 255 clear: the quotients are the exact ones
+
+
+def dft_regs(le, d, xs, tw=None):
+    from provekit_amd._lib import lib
+
+    a = np.ascontiguousarray(xs, dtype=np.uint64).reshape(-1, 4)
+    assert a.shape[0] % (1 << le) == 0
+    out = np.empty_like(a)
+    t = np.ascontiguousarray(tw, dtype=np.uint64).reshape(-1, 4) if tw is not None else None
+    assert lib.pk_selftest_dft(a.ctypes.data, t.ctypes.data if t is not None else None, out.ctypes.data, le, d, a.shape[0] >> le) == 0
+    return out
+
+
+def dft_by_definition(le, d, xs, tw=None):
+    """register (bitrev_d(a) << e) | batch holds X[a][batch] = sum_n x[(n << e) | batch] w^(a n), w = w_(2^d), e = le - d"""
+    e, nx, out = le - d, 1 << le, []
+    w = pow(W8, 8 >> d, P)
+    for g in range(0, len(xs), nx):
+        y = [0] * nx
+        for a in range(1 << d):
+            ra = int(format(a, f"0{d}b")[::-1], 2)
+            for b in range(1 << e):
+                y[(ra << e) | b] = sum(xs[g + ((n << e) | b)] * pow(w, a * n, P) for n in range(1 << d)) % P
+        if tw is not None:
+            y = [v * t % P for v, t in zip(y, tw[g:g + nx])]
+        out += y
+    return out
+
+
+@pytest.mark.parametrize("le,d", [(3, 1), (3, 2), (2, 1), (2, 2)])
+def test_ntt_butterfly_network_on_the_host(oracle, le, d):
+    """ntt_regs.hpp dft_regs<le, d> -- the device source of the NTT pass's register rounds, Shoup products and lazy sums included --
+    against the definition of the DFT: random inputs, and the extremes of the network's input contract (normalised limbs, value
+    below 1.2p: what a pass loads or a round leaves), with and without the twiddle product the pass kernel applies to the network's
+    unreduced outputs"""
+    HI = 12 * P // 10
+    ALL_ONES = (((HI >> 232) - 1) << 232) | ((1 << 232) - 1)  # every limb below the top one at its maximum
+    edge = [0, 1, P - 1, P, P + 1, HI, ALL_ONES, (1 << 253), HI - (1 << 29)]
+    xs = rand_fe(8 * 300, 41 + d) + rand_fe(8 * 100, 51 + d, HI)
+    xs += [v for v in edge for _ in range(8)]  # all equal: sums reach 2^le x the value before the reductions
+    xs += [HI if (i >> k) & 1 else 0 for k in range(3) for i in range(8)]  # extremes alternating at every stride
+    xs += [0 if (i >> k) & 1 else HI for k in range(3) for i in range(8)]
+    tws = rand_fe(len(xs) - 16, 61 + d) + [P - 1] * 8 + [1] * 8
+    assert oracle.limbs_to_ints(dft_regs(le, d, oracle.ints_to_limbs(xs))) == dft_by_definition(le, d, xs)
+    assert oracle.limbs_to_ints(dft_regs(le, d, oracle.ints_to_limbs(xs), oracle.ints_to_limbs(tws))) == dft_by_definition(le, d, xs, tws)
