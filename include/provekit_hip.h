@@ -64,13 +64,17 @@ typedef struct pk_scheme pk_scheme;
 int pk_abi_version(void);
 int pk_device_count(int *n);
 /* How host threads wait for `device` (every blocking call of this library ends in a stream synchronisation; a proof makes ~65 of
- * them).  PK_WAIT_SPIN: HIP's default -- the waiting thread polls, lowest latency, one busy core per waiting thread: right for one
- * proof at a time.  PK_WAIT_BLOCK: the thread sleeps until the completion interrupt -- right for many provers per GPU: with 16
- * provers in flight spinning burns 16 cores for nothing, and on a host that grants fewer (a container CPU quota) the throttling
- * stalls every prover (measured: 24 provers under a 16-CPU quota, 186 proofs/s spinning, 257 blocking).
- * Process-wide for the device (hipSetDeviceFlags).  Choose it BEFORE creating contexts on the device and leave it: the runtime builds
- * its completion signals for the mode in force, and a wait that blocks on a signal made for polling never wakes (measured: switching
- * to blocking while provers were running hung one of them in its next synchronisation). */
+ * them).  PK_WAIT_SPIN: the waiting thread polls, lowest latency, one busy core per waiting thread: right for one proof at a time.
+ * (HIP's own default is hipDeviceScheduleAuto -- spin, then yield; on a device whose flag this library has never changed
+ * PK_WAIT_SPIN leaves it at that and only ends PK_WAIT_POLL, which is safe at any time.)  PK_WAIT_BLOCK: the thread sleeps until the
+ * completion interrupt -- right for many provers per GPU: with 16 provers in flight spinning burns 16 cores for nothing, and on a
+ * host that grants fewer (a container CPU quota) the throttling stalls every prover (measured: 24 provers under a 16-CPU quota, 186
+ * proofs/s spinning, 257 blocking).  Process-wide for the device (hipSetDeviceFlags).  Choose PK_WAIT_BLOCK BEFORE
+ * creating contexts on the device and leave it: the runtime builds its completion signals for the mode in force, and a wait that
+ * blocks on a signal made for polling never wakes (measured: switching to blocking while provers were running hung one of them in
+ * its next synchronisation).  The environment variable PK_HOST_WAIT = spin | block | poll makes pk_ctx_create apply the mode before it
+ * creates the context's stream (any other value: PK_ERR_BAD_ARG).  While it sleeps in PK_WAIT_POLL the calling thread's timer slack
+ * is lowered to 2 us and restored when the wait returns. */
 #define PK_WAIT_SPIN 0
 #define PK_WAIT_BLOCK 1
 #define PK_WAIT_POLL 2 /* the library's own wait: hipStreamQuery with sleeps of 20 .. 100 us in between -- the cheapest for the host (no core per
@@ -117,10 +121,13 @@ int pk_ctx_set_hash_version(pk_ctx *ctx, int version);
  *                       on one GPU included, which is how the multi-process launch is tested on a single-GPU box.
  * PK_ERR_RCCL: librccl could not be loaded (it is resolved with dlopen at first use), one of its calls failed, a host
  * transport's callback returned non-zero, or another rank of the set failed (the communicator is then unusable).
- * A rank whose sharded call fails before it reaches a collective aborts its communicator so that its peers do not wait for
- * it: the in-process group wakes them with PK_ERR_RCCL, an RCCL communicator is torn down with ncclCommAbort (the peers'
- * pending collective then fails through RCCL's asynchronous error path), a host transport's peers are the caller's to time
- * out.  After any of these: pk_comm_destroy on every rank and join again. */
+ * A rank whose sharded call fails before it reaches a collective aborts its communicator so that its peers do not wait for it
+ * for ever.  In-process group: the waiting ranks wake at once with PK_ERR_RCCL.  RCCL: ncclCommAbort is local -- the failing rank
+ * tears down its OWN communicator, nothing reaches its peers; every wait on a stream that carries a collective therefore has a
+ * deadline (environment PK_COMM_TIMEOUT_S, default 120 s; ncclCommGetAsyncError is polled meanwhile): a rank whose collective does
+ * not complete aborts its own communicator too and returns PK_ERR_RCCL.  Host transport: the peers are the caller's to time out.
+ * After any of these: pk_comm_destroy on every rank and join again.  (A refusal every rank makes identically before the call has
+ * enqueued a collective -- PK_ERR_BAD_ARG, PK_ERR_UNSATISFIED, PK_ERR_IO_PATTERN -- leaves an RCCL communicator usable.) */
 #define PK_MAX_RANKS 16
 #define PK_COMM_ID_BYTES 128
 #define PK_COMM_NONE 0

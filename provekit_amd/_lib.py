@@ -176,6 +176,7 @@ SELFTEST_SIGNATURES = {
     "pk_selftest_chacha": (C.c_int, [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, vp]),
     "pk_selftest_random_fe": (C.c_int, [vp, vp, C.c_uint32, vp, sz]),
     "pk_selftest_dft": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, sz]),
+    "pk_selftest_set_hook": (C.c_int, [C.c_int, C.c_long]),
 }
 
 for _name, (_res, _args) in list(SIGNATURES.items()) + list(SELFTEST_SIGNATURES.items()):

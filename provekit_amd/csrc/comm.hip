@@ -37,6 +37,7 @@ struct RcclApi {
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;  // optional
     ncclResult_t (*GetVersion)(int*) = nullptr;       // optional
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -83,6 +84,7 @@ RcclApi* rccl() {
         PK_SYM(GetErrorString, "ncclGetErrorString");
 #undef PK_SYM
         api.CommAbort = reinterpret_cast<decltype(api.CommAbort)>(dlsym(api.handle, "ncclCommAbort"));
+        api.CommGetAsyncError = reinterpret_cast<decltype(api.CommGetAsyncError)>(dlsym(api.handle, "ncclCommGetAsyncError"));
         api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(dlsym(api.handle, "ncclGetVersion"));
     });
     return &api;
@@ -194,8 +196,20 @@ struct pk_comm {
     char* h_stage = nullptr;
     size_t stage_bytes = 0;
     bool failed = false;  // sticky, like LocalGroup::aborted
+    unsigned long long issued = 0;  // collectives enqueued so far (any transport)
+    bool pending = false;  // RCCL: a collective was enqueued on the stream and no completed wait has been seen since (comm_wait)
     bool holds_token = false;  // LOCAL turnstile: between comm_turn_begin and comm_turn_end
 };
+
+static void rccl_abort_own(pk_comm* c) {
+    c->failed = true;
+    c->pending = false;
+    if (c->nccl) {
+        // once a collective has failed or timed out ncclCommDestroy may itself block on the stuck kernel: abort, never destroy
+        if (rccl()->CommAbort) (void)rccl()->CommAbort(c->nccl);  // frees the communicator
+        c->nccl = nullptr;  // (without ncclCommAbort the handle is leaked on purpose: destroying it could hang)
+    }
+}
 
 namespace pk {
 
@@ -209,9 +223,15 @@ int comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes)
         return PK_OK;
     }
     ProfScope prof(ctx, "comm_all_gather");
+    c->issued++;
     if (c->kind == PK_COMM_RCCL) {
         if (c->failed || !c->nccl) return set_err(ctx, PK_ERR_RCCL, "the communicator was aborted by an earlier failure of this rank");
-        PK_RCCL(ctx, rccl()->AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, ctx->stream));
+        c->pending = true;  // whoever waits for this stream next waits with a deadline (comm_wait)
+        const ncclResult_t r = rccl()->AllGather(d_send, d_recv, bytes, ncclUint8, c->nccl, ctx->stream);
+        if (r != ncclSuccess) {
+            rccl_abort_own(c);  // the ranks are out of step from here on: no later collective may be attempted on this communicator
+            return rccl_fail(ctx, "ncclAllGather", r);
+        }
         return PK_OK;
     }
     if (c->kind == PK_COMM_HOST) {
@@ -268,12 +288,16 @@ int comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes)
     return PK_OK;
 }
 
-// A rank that fails BEFORE reaching a collective (e.g. its encode ran out of memory) calls comm_abort so that the ranks already
-// waiting in the collective return an error instead of blocking forever.  LOCAL: the group's sticky flag wakes them.  RCCL:
-// ncclCommAbort tears this rank's communicator down, which makes the peers' pending and later collectives on it fail
-// (asynchronous error) instead of waiting for a rank that will not come; the communicator is unusable afterwards on every
-// rank (pk_comm_destroy + a fresh pk_comm_init_rank to continue).  HOST: this rank fails fast, its peers are the caller's
-// transport's to time out.
+// A rank that fails BEFORE reaching a collective (e.g. its encode ran out of memory) calls comm_abort.  What that does for the ranks
+// already waiting in the collective depends on the transport:
+//   LOCAL  the group's sticky flag wakes them at once with PK_ERR_RCCL.
+//   RCCL   nothing reaches the peers: ncclCommAbort is LOCAL -- it tears down THIS rank's communicator (and kills its own pending
+//          collective kernel); the peers' collective kernels keep waiting on xGMI for a rank that will not come.  They are rescued by
+//          their own deadline: every wait on a stream that carries a collective (comm_wait below) polls the stream and
+//          ncclCommGetAsyncError, and after PK_COMM_TIMEOUT_S seconds (default 120) aborts ITS OWN communicator -- which ends its
+//          stuck kernel -- and returns PK_ERR_RCCL.  The communicator is unusable afterwards on every rank (pk_comm_destroy + a fresh
+//          pk_comm_init_rank to continue).
+//   HOST   this rank fails fast, its peers are the caller's transport's to time out.
 // pk_prove brackets itself with these; no-ops unless the context's in-process group was created with the turnstile on
 void comm_turn_begin(pk_ctx* ctx) {
     pk_comm* c = ctx->comm;
@@ -295,11 +319,50 @@ void comm_abort(pk_ctx* ctx) {
     if (!c) return;
     if (c->kind == PK_COMM_LOCAL && c->grp) c->grp->abort();
     if (c->kind == PK_COMM_HOST) c->failed = true;  // this rank's later collectives fail fast; its peers are the caller's transport's to time out
-    if (c->kind == PK_COMM_RCCL && !c->failed) {
-        c->failed = true;
-        if (c->nccl && rccl()->CommAbort) {
-            (void)rccl()->CommAbort(c->nccl);  // frees the communicator
-            c->nccl = nullptr;
+    if (c->kind == PK_COMM_RCCL && !c->failed) rccl_abort_own(c);
+}
+
+static double comm_timeout_s() {
+    static const double t = [] {
+        const char* e = getenv("PK_COMM_TIMEOUT_S");
+        const double v = e ? atof(e) : 0.0;
+        return v > 0.0 ? v : 120.0;
+    }();
+    return t;
+}
+unsigned long long comm_collectives_issued(const pk_ctx* ctx) { return ctx->comm ? ctx->comm->issued : 0; }
+bool comm_rccl(const pk_ctx* ctx) { return ctx->comm && ctx->comm->kind == PK_COMM_RCCL; }
+bool comm_collective_pending(const pk_ctx* ctx) { return ctx->comm && ctx->comm->kind == PK_COMM_RCCL && ctx->comm->pending; }
+// The wait for a stream that carries an RCCL collective: a peer that died or aborted never arrives, and the collective kernel would
+// spin for ever.  Poll the stream; between polls ask RCCL for an asynchronous error; past the deadline abort this rank's own
+// communicator (which ends its kernel) and report.  hipSuccess = the stream drained and the collective completed.
+hipError_t comm_wait(pk_ctx* ctx) {
+    pk_comm* c = ctx->comm;
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned polls = 0;; polls++) {
+        const hipError_t e = hipStreamQuery(ctx->stream);
+        if (e != hipErrorNotReady) {
+            if (e == hipSuccess) c->pending = false;
+            return e;
+        }
+        if (polls < 64) continue;  // a collective over xGMI completes within microseconds when every rank is there
+        struct timespec ts = {0, polls < 1024 ? 20000 : 200000};
+        (void)nanosleep(&ts, nullptr);
+        if ((polls & 63) != 0) continue;
+        ncclResult_t async = ncclSuccess;
+        const bool broken = c->nccl && rccl()->CommGetAsyncError && rccl()->CommGetAsyncError(c->nccl, &async) == ncclSuccess && async != ncclSuccess &&
+                            async != ncclInProgress;
+        struct timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        const double waited = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        if (broken || waited > comm_timeout_s()) {
+            rccl_abort_own(c);
+            (void)hipStreamSynchronize(ctx->stream);  // the aborted kernel exits; drain what was queued behind it
+            set_err(ctx, PK_ERR_RCCL, broken ? "RCCL reported an asynchronous error (%s) while a collective was pending; this rank's communicator was aborted"
+                                             : "a collective did not complete within %s seconds (a rank of the device set failed or never arrived); this rank's communicator was aborted",
+                    broken ? (rccl()->GetErrorString ? rccl()->GetErrorString(async) : "rccl error") : std::to_string((int)comm_timeout_s()).c_str());
+            return hipErrorUnknown;
         }
     }
 }
@@ -310,7 +373,13 @@ int comm_all_reduce_sum_u64(pk_ctx* ctx, uint64_t* d_buf, size_t count) {
     ProfScope prof(ctx, "comm_all_reduce");
     if (c->kind == PK_COMM_RCCL) {
         if (c->failed || !c->nccl) return set_err(ctx, PK_ERR_RCCL, "the communicator was aborted by an earlier failure of this rank");
-        PK_RCCL(ctx, rccl()->AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, c->nccl, ctx->stream));
+        c->issued++;
+        c->pending = true;
+        const ncclResult_t r = rccl()->AllReduce(d_buf, d_buf, count, ncclUint64, ncclSum, c->nccl, ctx->stream);
+        if (r != ncclSuccess) {
+            rccl_abort_own(c);
+            return rccl_fail(ctx, "ncclAllReduce", r);
+        }
         return PK_OK;
     }
     const size_t need = (size_t)c->world * count * 8;
@@ -360,7 +429,10 @@ int comm_collect_fe(pk_ctx* ctx, int K, uint64_t* host_out) {
 void comm_release(pk_ctx* ctx) {
     pk_comm* c = ctx->comm;
     if (!c) return;
-    if (c->kind == PK_COMM_RCCL && c->nccl && rccl()->CommDestroy) (void)rccl()->CommDestroy(c->nccl);
+    if (c->kind == PK_COMM_RCCL && c->nccl) {
+        if (c->failed || c->pending) rccl_abort_own(c);  // a stuck collective would block ncclCommDestroy too
+        else if (rccl()->CommDestroy) (void)rccl()->CommDestroy(c->nccl);
+    }
     if (c->kind == PK_COMM_LOCAL && c->grp) {
         LocalGroup* g = c->grp;
         bool last;
@@ -481,10 +553,9 @@ int pk_ctx_create_set(const int* devices, int n, pk_ctx** out) {
         for (int j = 0; j < i; j++) distinct = distinct && devices[i] != devices[j];
     }
     if (!rc && n > 1) {
-        // PK_RCCL_SAME_DEVICE=1 (test-suite, together with PK_RCCL_LIB = the in-process stand-in): take the RCCL branch even
-        // for a repeated device -- real RCCL refuses two ranks on one GPU
-        const char* same_ok = getenv("PK_RCCL_SAME_DEVICE");
-        if (!distinct && !(same_ok && same_ok[0] == '1')) {
+        // test hook (pk_selftest_set_hook, together with PK_RCCL_LIB = the in-process stand-in): take the RCCL branch even for a
+        // repeated device -- real RCCL refuses two ranks on one GPU
+        if (!distinct && !test_hook(PK_HOOK_RCCL_SAME_DEVICE)) {
             rc = pk_comm_init_local(out, n);  // several ranks on one device: RCCL cannot, the in-process transport can
         } else {
             RcclApi* a = rccl();

@@ -12,33 +12,59 @@ using namespace pk;
 
 #define PK_MAX_DEVICES 64
 static std::atomic<int> g_poll_wait[PK_MAX_DEVICES];
+static std::atomic<long> g_test_hooks[pk::PK_HOOK_COUNT];
+// the runtime wait flag this library last set on a device: -1 (below: stored as 0 - 1 via init) = never touched (HIP's hipDeviceScheduleAuto)
+static std::atomic<int> g_runtime_wait[PK_MAX_DEVICES];
+static const bool g_runtime_wait_init = [] {
+    for (auto& w : g_runtime_wait) w.store(-1, std::memory_order_relaxed);
+    return true;
+}();
 
 namespace pk {
+long test_hook(int which) { return which >= 0 && which < PK_HOOK_COUNT ? g_test_hooks[which].load(std::memory_order_relaxed) : 0; }
 // PK_WAIT_POLL: a few immediate queries (work that ends within microseconds), then sleeps that lengthen from 20 us to 100 us.  A waiting
 // thread costs a query and a timer wake-up per interval instead of a core (spinning) or the runtime's spin-then-block (~0.2 ms of spinning
 // per wait: 65 waits per proof); it learns of completion up to one interval late, which a prover that shares the chip with others does not
 // notice and a lone prover does (keep PK_WAIT_SPIN for latency).
 hipError_t wait_stream(int device, hipStream_t stream) {
     if (device < 0 || device >= PK_MAX_DEVICES || !g_poll_wait[device].load(std::memory_order_relaxed)) return hipStreamSynchronize(stream);
-    static thread_local bool slack_set = false;
-    if (!slack_set) {  // the default timer slack (50 us) would round every short sleep up
-        (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0);
-        slack_set = true;
-    }
+    long slack = -1;  // the calling thread's timer slack (default 50 us) would round every short sleep up: lowered for the sleeps, then put back
+    hipError_t e;
     for (unsigned polls = 0;; polls++) {
-        const hipError_t e = hipStreamQuery(stream);
-        if (e != hipErrorNotReady) return e;
+        e = hipStreamQuery(stream);
+        if (e != hipErrorNotReady) break;
         if (polls < 4) continue;
+        if (slack < 0) {
+            slack = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+            if (slack > 2000) (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0);
+        }
         const long ns = polls < 12 ? 20000 : (polls < 40 ? 50000 : 100000);
         struct timespec ts = {0, ns};
         (void)nanosleep(&ts, nullptr);
     }
+    if (slack > 2000) (void)prctl(PR_SET_TIMERSLACK, (unsigned long)slack, 0, 0, 0);
+    return e;
+}
+hipError_t wait_ctx(pk_ctx* ctx) { return comm_collective_pending(ctx) ? comm_wait(ctx) : wait_stream(ctx->device, ctx->stream); }
+int wait_ctx_rc(pk_ctx* ctx) {
+    const bool collective = comm_collective_pending(ctx);
+    const hipError_t e = wait_ctx(ctx);
+    if (e == hipSuccess) return PK_OK;
+    if (collective && !comm_collective_pending(ctx)) return PK_ERR_RCCL;  // comm_wait gave up on the collective and said why
+    return set_err(ctx, e == hipErrorOutOfMemory ? PK_ERR_OOM : PK_ERR_HIP, "waiting for the stream failed: %s", hipGetErrorString(e));
 }
 }  // namespace pk
 
 extern "C" {
 
 int pk_abi_version(void) { return 2; }
+
+// test infrastructure (tools/probes/pk_selftest.h): the hooks the GPU suite uses to reach rare paths; nothing reads the environment
+int pk_selftest_set_hook(int which, long value) {
+    if (which < 0 || which >= pk::PK_HOOK_COUNT || value < 0) return PK_ERR_BAD_ARG;
+    g_test_hooks[which].store(value, std::memory_order_relaxed);
+    return PK_OK;
+}
 
 int pk_device_count(int* n) {
     if (!n) return PK_ERR_BAD_ARG;
@@ -60,12 +86,19 @@ int pk_device_set_host_wait(int device, int mode) {
         return PK_OK;
     }
     g_poll_wait[device].store(0, std::memory_order_relaxed);
+    // The runtime's own modes.  Its flag is touched only when it has to change: PK_WAIT_SPIN on a device whose flag this library never
+    // set (HIP's default, hipDeviceScheduleAuto: spin, then yield) just leaves polling -- safe with work in flight, unlike a flag change
+    // (a wait that blocks on a signal created for polling never wakes: choose PK_WAIT_BLOCK before the device has streams).
+    const int cur_flag = g_runtime_wait[device].load(std::memory_order_relaxed);
+    if (cur_flag == mode || (mode == PK_WAIT_SPIN && cur_flag < 0)) return PK_OK;
     int cur = 0;
     const bool have = hipGetDevice(&cur) == hipSuccess;
     if (hipSetDevice(device) != hipSuccess) return PK_ERR_BAD_ARG;
     const hipError_t e = hipSetDeviceFlags(mode == PK_WAIT_BLOCK ? hipDeviceScheduleBlockingSync : hipDeviceScheduleSpin);
     if (have) (void)hipSetDevice(cur);
-    return e == hipSuccess ? PK_OK : PK_ERR_HIP;
+    if (e != hipSuccess) return PK_ERR_HIP;
+    g_runtime_wait[device].store(mode, std::memory_order_relaxed);
+    return PK_OK;
 }
 
 int pk_ctx_create(int device, pk_ctx** out) {
@@ -74,6 +107,16 @@ int pk_ctx_create(int device, pk_ctx** out) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return PK_ERR_NO_DEVICE;
     if (device < 0 || device >= count) return PK_ERR_BAD_ARG;
+    {   // PK_HOST_WAIT=spin|block|poll: pk_device_set_host_wait for callers that cannot reach the API (A/B runs, tools/cpuuse.py); applied
+        // BEFORE this context's stream exists (a blocking wait must not meet a stream created for spinning)
+        const char* w = getenv("PK_HOST_WAIT");
+        if (w && *w) {
+            const int mode = !strcmp(w, "spin") ? PK_WAIT_SPIN : (!strcmp(w, "block") ? PK_WAIT_BLOCK : (!strcmp(w, "poll") ? PK_WAIT_POLL : -1));
+            if (mode < 0) return PK_ERR_BAD_ARG;  // an unknown value is refused, not read as "spin"
+            const int rc = pk_device_set_host_wait(device, mode);
+            if (rc) return rc;
+        }
+    }
     pk_ctx* ctx = new (std::nothrow) pk_ctx();
     if (!ctx) return PK_ERR_OOM;
     ctx->device = device;
@@ -83,10 +126,6 @@ int pk_ctx_create(int device, pk_ctx** out) {
         return PK_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    {   // PK_HOST_WAIT=block|spin: pk_device_set_host_wait for callers that cannot reach the API (A/B runs, tools/cpuuse.py)
-        const char* w = getenv("PK_HOST_WAIT");
-        if (w && *w) (void)pk_device_set_host_wait(device, w[0] == 'b' ? PK_WAIT_BLOCK : (w[0] == 'p' ? PK_WAIT_POLL : PK_WAIT_SPIN));
-    }
     pk::ntt_retain_ctx(ctx);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -98,7 +137,7 @@ int pk_ctx_create(int device, pk_ctx** out) {
 int pk_ctx_destroy(pk_ctx* ctx) {
     PK_ENTER(ctx);
     (void)hipSetDevice(ctx->device);
-    (void)wait_stream(ctx->device, ctx->stream);
+    (void)wait_ctx(ctx);
     pk::comm_release(ctx);
     pk::ntt_release_ctx(ctx);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -149,7 +188,7 @@ int pk_malloc(pk_ctx* ctx, size_t bytes, void** d_ptr) {
 int pk_free(pk_ctx* ctx, void* d_ptr) {
     PK_ENTER(ctx);
     if (!d_ptr) return PK_OK;
-    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
+    PK_WAIT(ctx);
     PK_HIP(ctx, hipFree(d_ptr));
     return PK_OK;
 }
@@ -158,7 +197,7 @@ int pk_memcpy_h2d(pk_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
     PK_REQUIRE(ctx, bytes == 0 || (d_dst && src), "null pointer");
     if (!bytes) return PK_OK;
     PK_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
+    PK_WAIT(ctx);
     return PK_OK;
 }
 int pk_memcpy_d2h(pk_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
@@ -166,7 +205,7 @@ int pk_memcpy_d2h(pk_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
     PK_REQUIRE(ctx, bytes == 0 || (dst && d_src), "null pointer");
     if (!bytes) return PK_OK;
     PK_HIP(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
+    PK_WAIT(ctx);
     return PK_OK;
 }
 int pk_memcpy_d2d(pk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
@@ -204,7 +243,7 @@ int pk_profile_enable(pk_ctx* ctx, int on) {
 }
 int pk_profile_reset(pk_ctx* ctx) {
     PK_ENTER(ctx);
-    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
+    PK_WAIT(ctx);
     for (auto& r : ctx->prof) {
         ctx->ev_pool.push_back(r.e0);
         ctx->ev_pool.push_back(r.e1);
@@ -214,7 +253,7 @@ int pk_profile_reset(pk_ctx* ctx) {
 }
 int pk_profile_read(pk_ctx* ctx, const char* name, uint64_t* launches, double* total_ms) {
     if (!ctx || !name || !launches || !total_ms) return PK_ERR_BAD_ARG;
-    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
+    PK_WAIT(ctx);
     *launches = 0;
     *total_ms = 0.0;
     for (auto& r : ctx->prof) {
@@ -254,7 +293,7 @@ namespace pk {
 int ensure_scratch(pk_ctx* ctx, size_t bytes) {
     if (ctx->scratch_bytes >= bytes) return PK_OK;
     if (ctx->d_scratch) {
-        PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
+        PK_WAIT(ctx);
         PK_HIP(ctx, hipFree(ctx->d_scratch));
         ctx->d_scratch = nullptr;
         ctx->scratch_bytes = 0;
@@ -273,7 +312,7 @@ int ensure_pinned(pk_ctx* ctx) {
     return PK_OK;
 }
 int sync_stream(pk_ctx* ctx) {
-    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
+    PK_WAIT(ctx);
     ctx->mail_off = 0;  // nothing in flight reads or writes the mailbox any more
     return PK_OK;
 }
@@ -299,7 +338,7 @@ int mail_alloc(pk_ctx* ctx, size_t bytes, void** out) {
 int ensure_ws(pk_ctx* ctx, size_t bytes) {
     if (ctx->ws_bytes >= bytes) return PK_OK;
     if (ctx->d_ws) {
-        PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
+        PK_WAIT(ctx);
         PK_HIP(ctx, hipFree(ctx->d_ws));
         ctx->d_ws = nullptr;
         ctx->ws_bytes = 0;

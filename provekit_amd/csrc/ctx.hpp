@@ -31,6 +31,7 @@ struct pk_ctx {
     int hash_version = 2;
     int num_cus = 256;
     char err[512] = {0};
+    int err_code = 0;  // the status the last set_err returned
     // small device scratch for reductions (partials + results)
     void* d_scratch = nullptr;
     size_t scratch_bytes = 0;
@@ -94,6 +95,7 @@ inline int set_err(pk_ctx* ctx, int code, const char* fmt, ...) {
         va_start(ap, fmt);
         vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
         va_end(ap);
+        ctx->err_code = code;
     }
     return code;
 }
@@ -105,6 +107,13 @@ inline int set_err(pk_ctx* ctx, int code, const char* fmt, ...) {
             return pk::set_err(ctx, _e == hipErrorOutOfMemory ? PK_ERR_OOM : PK_ERR_HIP,           \
                                "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
                                __LINE__);                                                          \
+    } while (0)
+
+// wait for the context's stream (with the collective deadline of comm.hip comm_wait while an RCCL collective is pending on it)
+#define PK_WAIT(ctx)                      \
+    do {                                  \
+        int _w = pk::wait_ctx_rc(ctx);    \
+        if (_w) return _w;                \
     } while (0)
 
 #define PK_REQUIRE(ctx, cond, msg)                                                \
@@ -169,7 +178,16 @@ int ensure_scratch(pk_ctx* ctx, size_t bytes);
 int ensure_pinned(pk_ctx* ctx);                               // the 4 KiB result page
 // Every wait of the library for a stream goes through here (pk_device_set_host_wait): the runtime's hipStreamSynchronize -- spinning or
 // blocking, whichever the device's scheduling flag says -- or, in PK_WAIT_POLL, the library's own loop: hipStreamQuery with short sleeps.
+// test hooks, settable only through pk_selftest_set_hook (tools/probes/pk_selftest.h); 0 = off: a gated kernel's spin bound, microseconds the
+// host sleeps before it publishes a gate's challenge, take the RCCL branch for a repeated device
+enum { PK_HOOK_GATE_SPINS = 0, PK_HOOK_GATE_STALL_US = 1, PK_HOOK_RCCL_SAME_DEVICE = 2, PK_HOOK_COUNT = 3 };
+long test_hook(int which);
 hipError_t wait_stream(int device, hipStream_t stream);
+hipError_t wait_ctx(pk_ctx* ctx);  // wait_stream on the context's stream; with a deadline while an RCCL collective is pending on it (comm.hip comm_wait)
+int wait_ctx_rc(pk_ctx* ctx);      // the same as a status: PK_OK, PK_ERR_RCCL (the collective failed or timed out; pk_last_error says which) or PK_ERR_HIP
+bool comm_collective_pending(const pk_ctx* ctx);
+bool comm_rccl(const pk_ctx* ctx);
+hipError_t comm_wait(pk_ctx* ctx);
 int sync_stream(pk_ctx* ctx);                                 // wait_stream + rewind the mailbox
 int mail_alloc(pk_ctx* ctx, size_t bytes, void** out);        // 64-B aligned; valid until the next sync_stream
 int read_root(pk_ctx* ctx, const uint64_t* d_nodes, size_t n_leaves, uint64_t root[4]);  // hash.hip: after pk_merkle_*
@@ -183,7 +201,8 @@ int comm_collect_fe(pk_ctx* ctx, int K, uint64_t* host_out);  // comm.hip: the c
 int red_across_begin(pk_ctx* ctx);                             // allocate d_xred if needed and set red_across
 void comm_turn_begin(pk_ctx* ctx);  // measurement aid of the in-process transport (comm.hip LocalGroup::turnstile)
 void comm_turn_end(pk_ctx* ctx);
-void comm_abort(pk_ctx* ctx);  // wake the ranks waiting in a collective this rank will never reach (in-process transport)
+unsigned long long comm_collectives_issued(const pk_ctx* ctx);  // collectives this context's communicator has enqueued so far
+void comm_abort(pk_ctx* ctx);  // this rank will not reach a collective its peers wait in: LOCAL wakes them; RCCL aborts its OWN communicator (the peers time out, comm_wait)
 void comm_release(pk_ctx* ctx);
 int eval_univariate_multi(pk_ctx* ctx, const uint64_t* const* d_polys, unsigned np, size_t n, const uint64_t z[4], uint64_t* out);  // mle.hip
 int dot_rows(pk_ctx* ctx, const uint64_t* d_w, size_t row_stride, unsigned nrows, const uint64_t* d_f, const uint64_t* d_g, size_t n, uint64_t* out);

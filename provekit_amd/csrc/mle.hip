@@ -765,6 +765,7 @@ int sumcheck_quadratic_launch(pk_ctx* ctx, const uint64_t* d_f, const uint64_t* 
 int sumcheck_collect_spin(pk_ctx* ctx, unsigned red_seq, uint64_t out[12]) { return collect_reduction_spin<3>(ctx, red_seq, out); }
 unsigned sumcheck_gate_next(pk_ctx* ctx) { return gate_next(ctx); }
 // 0 = no gated kernel of this context gave up on its challenge since the last call, else PK_ERR_HIP with the message set (reduce.hpp)
+void sumcheck_gate_clear(pk_ctx* ctx) { (void)gate_timed_out(ctx); }  // forget a give-up word without touching the error message
 int sumcheck_gate_check(pk_ctx* ctx) { return gate_timed_out(ctx) ? set_err(ctx, PK_ERR_HIP, "%s", PK_GATE_TIMEOUT_MSG) : PK_OK; }
 void sumcheck_gate_publish(pk_ctx* ctx, unsigned gate_seq, const uint64_t challenge[4]) {
     fe c;

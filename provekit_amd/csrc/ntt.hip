@@ -469,7 +469,7 @@ int shared_table(pk_ctx* ctx, unsigned long long key, void** out, Build build) {
     void* T = nullptr;
     int rc = build(&T);
     if (rc) return rc;
-    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));  // complete before another context's stream may read it
+    PK_WAIT(ctx);  // complete before another context's stream may read it
     S.tables[key] = T;
     *out = T;
     return PK_OK;
@@ -871,7 +871,7 @@ int pk_ntt(pk_ctx* ctx, const uint64_t* d_in, uint64_t* d_out, unsigned log_n, u
     if (log_n > 9) PK_HIP(ctx, hipMalloc((void**)&scratch, 32 * N * ncols));
     int rc = pk::ntt_columns(ctx, (const fe*)d_in, N, N, (fe*)d_out, N, scratch, log_n, ncols, false);
     if (scratch) {
-        hipError_t e = wait_stream(ctx->device, ctx->stream);
+        hipError_t e = wait_ctx(ctx);
         (void)hipFree(scratch);
         if (!rc && e != hipSuccess) rc = set_err(ctx, PK_ERR_HIP, "ntt failed: %s", hipGetErrorString(e));
     }

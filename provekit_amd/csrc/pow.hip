@@ -186,7 +186,7 @@ int pow_solve_x(pk_ctx* ctx, const uint8_t challenge[32], double bits, uint64_t*
             rc = comm_all_gather(ctx, d_x, d_x + 1, 8);
             if (rc) return rc;
             PK_HIP(ctx, hipMemcpyAsync(all, d_x + 1, 8 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
-            PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
+            PK_WAIT(ctx);
             for (unsigned r = 0; r < world; r++) best = all[r] < best ? all[r] : best;
         }
         if (best != ~0ull) break;

@@ -48,6 +48,7 @@ int sumcheck_quadratic_launch(pk_ctx* ctx, const uint64_t* d_f, const uint64_t* 
 int sumcheck_collect_spin(pk_ctx* ctx, unsigned red_seq, uint64_t out[12]);
 unsigned sumcheck_gate_next(pk_ctx* ctx);
 int sumcheck_gate_check(pk_ctx* ctx);
+void sumcheck_gate_clear(pk_ctx* ctx);
 void sumcheck_gate_publish(pk_ctx* ctx, unsigned gate_seq, const uint64_t challenge[4]);
 int witness_bounds_strided(pk_ctx* ctx, const pk_r1cs* r, const uint64_t* d_z, unsigned m0, unsigned stride, unsigned offset, uint64_t* d_a,
                            uint64_t* d_b, uint64_t* d_c);
@@ -169,10 +170,7 @@ struct PendingGate {
     void arm(unsigned s) { seq = s; }
     void publish(const fe& challenge) {
         if (!seq) return;
-        static const long stall_us = [] {  // PK_TEST_GATE_STALL_US: the test-suite's stand-in for a host thread that was stopped
-            const char* e = getenv("PK_TEST_GATE_STALL_US");
-            return e ? strtol(e, nullptr, 10) : 0L;
-        }();
+        const long stall_us = test_hook(PK_HOOK_GATE_STALL_US);  // the test-suite's stand-in for a host thread that was stopped
         if (stall_us > 0) usleep((useconds_t)stall_us);
         uint64_t w[4];
         h_store(w, challenge);
@@ -841,7 +839,7 @@ int proof_key(pk_ctx* ctx, const uint8_t* rng_seed32, RngKey& key) {
         rc = comm_all_gather(ctx, d_key, d_key + 32, 32);
         if (rc) return rc;
         PK_HIP(ctx, hipMemcpyAsync(key.k, d_key + 32, 32, hipMemcpyDeviceToHost, ctx->stream));
-        PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
+        PK_WAIT(ctx);
     }
     return PK_OK;
 }
@@ -1001,13 +999,28 @@ std::string io_pattern_mismatch(const std::string& theirs, unsigned m_0, const p
 // One proof over a device set: a rank that leaves early (arena exhausted, a HIP error, an unsatisfied witness on this rank only)
 // never reaches the collectives its peers are -- or will be -- waiting in.  Whatever the exit path, a failing rank aborts the
 // group (in-process transport: the waiting ranks wake with PK_ERR_RCCL; host transport: this rank's communicator is marked
-// failed), as include/provekit_hip.h promises for every sharded call.
+// failed; RCCL: this rank's OWN communicator is aborted -- its peers are rescued by their collective deadline, comm.hip comm_wait).
+// One exception, RCCL only, where an abort is irreversible: a refusal that every rank of the set makes identically (a bad argument,
+// an unsatisfied witness, an IO-pattern mismatch) BEFORE this call has enqueued any collective leaves the ranks in step, so the
+// communicator stays usable for the next call.
 struct AbortOnFailure {
     pk_ctx* c;
     bool ok = false;
-    explicit AbortOnFailure(pk_ctx* ctx) : c(ctx) {}
+    unsigned long long issued0;
+    explicit AbortOnFailure(pk_ctx* ctx) : c(ctx), issued0(comm_collectives_issued(ctx)) {}
     ~AbortOnFailure() {
-        if (!ok && comm_world(c) > 1) comm_abort(c);
+        if (ok) return;
+        struct Drain {  // whatever happens to the communicator, an abandoned proof leaves nothing behind on the stream: a gated kernel
+            pk_ctx* c;  // released with a zero challenge must have finished -- and its give-up word be cleared -- before the next proof starts
+            ~Drain() {
+                (void)wait_ctx(c);
+                sumcheck_gate_clear(c);
+            }
+        } drain{c};
+        if (comm_world(c) <= 1) return;
+        const bool same_everywhere = c->err_code == PK_ERR_BAD_ARG || c->err_code == PK_ERR_UNSATISFIED || c->err_code == PK_ERR_IO_PATTERN;
+        if (comm_rccl(c) && same_everywhere && comm_collectives_issued(c) == issued0) return;
+        comm_abort(c);
     }
 };
 
@@ -1018,7 +1031,7 @@ extern "C" {
 int pk_scheme_destroy(pk_ctx* ctx, pk_scheme* s) {
     PK_ENTER(ctx);
     if (!s) return PK_OK;
-    (void)wait_stream(ctx->device, ctx->stream);
+    (void)wait_ctx(ctx);
     (void)hipFree(s->arena);
     (void)hipFree(s->noir_witness);
     if (s->side) (void)pk_ctx_destroy(s->side);
@@ -1106,7 +1119,7 @@ int pk_prove(pk_ctx* ctx, pk_scheme* s, const uint64_t* d_witness, size_t n_witn
     auto t_start = now();
     auto lap = [&](const char* what) {
         if (!timing) return;
-        (void)wait_stream(ctx->device, ctx->stream);
+        (void)wait_ctx(ctx);
         auto t = now();
         fprintf(stderr, "[pk_prove] %-28s %8.3f ms (sponge: %u permutes, %.3f ms; hint serialisation so far %.3f ms)\n", what,
                 1e3 * std::chrono::duration<double>(t - t_start).count(), T.permutes, 1e3 * T.permute_seconds, 1e3 * T.hint_seconds);

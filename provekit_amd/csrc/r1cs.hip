@@ -203,7 +203,7 @@ extern "C" {
 int pk_r1cs_destroy(pk_ctx* ctx, pk_r1cs* r) {
     PK_ENTER(ctx);
     if (!r) return PK_OK;
-    (void)wait_stream(ctx->device, ctx->stream);
+    (void)wait_ctx(ctx);
     (void)hipFree(r->d_interner);
     for (int m = 0; m < 3; m++) {
         (void)hipFree(r->csr_ptr[m]); (void)hipFree(r->csr_idx[m]); (void)hipFree(r->csr_val[m]);
@@ -456,7 +456,7 @@ int pk_r1cs_test_witness_satisfaction(pk_ctx* ctx, const pk_r1cs* r, const uint6
     }
     unsigned long long bad = 0;
     PK_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
+    PK_WAIT(ctx);
     if (bad != ~0ull) {
         *first_failed_row = (int64_t)bad;
         return set_err(ctx, PK_ERR_UNSATISFIED, "Constraint %llu failed", bad);  // r1cs.rs:57

@@ -294,11 +294,8 @@ inline unsigned gate_next(pk_ctx* ctx) {
 }
 inline gate_args gate_none() { return gate_args{nullptr, nullptr, 0, 0}; }
 inline gate_args gate_for(pk_ctx* ctx, unsigned seq) {  // after reduction_scratch(ctx)
-    static const unsigned spins = [] {  // PK_TEST_GATE_SPINS: the test-suite's way to reach the give-up path in milliseconds
-        const char* e = getenv("PK_TEST_GATE_SPINS");
-        const unsigned long v = e ? strtoul(e, nullptr, 10) : 0;
-        return v ? (unsigned)v : PK_GATE_SPINS_LEADER;
-    }();
+    const long hook = test_hook(PK_HOOK_GATE_SPINS);  // the test-suite's way to reach the give-up path in milliseconds
+    const unsigned spins = hook > 0 ? (unsigned)hook : PK_GATE_SPINS_LEADER;
     return gate_args{(const unsigned*)((char*)ctx->h_pinned + PK_PIN_GATE), red_ticket(ctx) + 16, seq, spins};  // both 64-byte aligned
 }
 // the host's half: the challenge first, the sequence number last

@@ -209,7 +209,10 @@ int commit_into(pk_ctx* ctx, const uint64_t* const* d_coeffs, unsigned batch, un
     const unsigned g = (unsigned)comm_rank(ctx);
     // heap slots [2G, rows) are the inner nodes below the subtree roots: this rank fills only its own 1/G of them -- the rest is
     // zeroed, so that a caller who walks d_nodes himself reads zeros there, not whatever the buffer held (include/provekit_hip.h)
-    PK_HIP(ctx, hipMemsetAsync((fe*)d_nodes + 2 * (size_t)G, 0, 32 * (rows - 2 * (size_t)G), ctx->stream));
+    if (hipMemsetAsync((fe*)d_nodes + 2 * (size_t)G, 0, 32 * (rows - 2 * (size_t)G), ctx->stream) != hipSuccess) {
+        comm_abort(ctx);  // the peers are on their way to the all-gather of the subtree roots
+        return set_err(ctx, PK_ERR_HIP, "clearing the inner-node slots of the other ranks' subtrees failed");
+    }
     fe* H = gathered;  // 2 * loc <= rows entries
     PK_HIP(ctx, hipMemcpyAsync(H + loc, (fe*)d_nodes + rows + (size_t)g * loc, 32 * loc, hipMemcpyDeviceToDevice, ctx->stream));
     rc = pk_merkle_inner(ctx, (uint64_t*)H, loc);
@@ -248,7 +251,7 @@ extern "C" {
 int pk_tree_destroy(pk_ctx* ctx, pk_tree* t) {
     PK_ENTER(ctx);
     if (!t) return PK_OK;
-    (void)wait_stream(ctx->device, ctx->stream);
+    (void)wait_ctx(ctx);
     if (t->owns_leaves) (void)hipFree(t->d_leaves);
     (void)hipFree(t->d_nodes);
     delete t;
@@ -440,7 +443,7 @@ int pk_tree_open(pk_ctx* ctx, const pk_tree* t, const uint64_t* indices, size_t 
                                                                                           logn, m_idx, k, canonical_leaves, m_leaves, m_sib, m_path, t->scaled);
     }
     PK_LAUNCH_CHECK(ctx);
-    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));  // not sync_stream: the mailbox is read below
+    PK_WAIT(ctx);  // not sync_stream: the mailbox is read below
     memcpy(leaves_out, m_leaves, 32 * n1);
     if (logn) memcpy(sibling_digests, m_sib, 32 * k);
     if (plen) memcpy(auth_paths, m_path, 32 * k * plen);
@@ -472,7 +475,7 @@ int pk_gather_leaves_enc(pk_ctx* ctx, const uint64_t* d_leaves, size_t n_leaves,
     gather_opening_kernel<<<(unsigned)((n1 + 255) / 256), 256, 0, ctx->stream>>>((const fe*)d_leaves, nullptr, n_leaves, (unsigned)width, layout, 0, m_idx, k,
                                                                                 canonical_leaves, m_leaves, nullptr, nullptr, encoding == PK_LEAVES_SCALED32);
     PK_LAUNCH_CHECK(ctx);
-    PK_HIP(ctx, wait_stream(ctx->device, ctx->stream));
+    PK_WAIT(ctx);
     memcpy(leaves_out, m_leaves, 32 * n1);
     ctx->mail_off = 0;
     return PK_OK;

@@ -828,7 +828,7 @@ int pk_witness_program_placement(const pk_witness_program* p, size_t* n_levels, 
 int pk_witness_program_destroy(pk_ctx* ctx, pk_witness_program* p) {
     PK_ENTER(ctx);
     if (!p) return PK_OK;
-    (void)wait_stream(ctx->device, ctx->stream);
+    (void)wait_ctx(ctx);
     (void)hipFree(p->d_items);
     (void)hipFree(p->d_phase_begin);
     (void)hipFree(p->d_consts);

@@ -194,11 +194,12 @@ impl<'a> HipProver<'a> {
         let io = scheme.create_io_pattern();
         let bytes = io.as_bytes();
         let rc = unsafe { sys::pk_scheme_set_io_pattern(ctx.raw, raw, bytes.as_ptr(), bytes.len()) };
-        if rc != sys::PK_OK {
+        if rc == sys::PK_ERR_IO_PATTERN {
             // pk_last_error names the first operation that differs ("operation #k is ..., the prover performs ...")
             let why = unsafe { CStr::from_ptr(sys::pk_last_error(ctx.raw)) }.to_string_lossy().into_owned();
             return Err(anyhow::Error::new(IoPatternMismatch(why)));
         }
+        ctx.check(rc)?; // any other status (bad argument, out of memory, a HIP error) is a failure, not a reason to fall back
         Ok(this)
     }
 

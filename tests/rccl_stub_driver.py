@@ -1,5 +1,5 @@
 """Runs INSIDE a fresh process started by tests/test_gpu_rccl_stub.py with PK_RCCL_LIB = tests/stub_rccl/libpk_stub_rccl.so and
-PK_RCCL_SAME_DEVICE = 1: the library's RCCL transport (csrc/comm.hip, kind PK_COMM_RCCL) driven at G = 2, 4, 8 on the one GPU of
+pk_selftest_set_hook(2, 1): the library's RCCL transport (csrc/comm.hip, kind PK_COMM_RCCL) driven at G = 2, 4, 8 on the one GPU of
 the box, the "RCCL" being the in-process stand-in.  A fresh process because the library resolves its RCCL once (dlopen at first
 use).  Prints one JSON object: what was checked and what the stand-in was asked to do."""
 import ctypes as C
@@ -35,7 +35,7 @@ def run_ranks(ctxs, fn):
 
 
 def main():
-    assert os.environ.get("PK_RCCL_LIB", "").endswith("libpk_stub_rccl.so") and os.environ.get("PK_RCCL_SAME_DEVICE") == "1"
+    assert os.environ.get("PK_RCCL_LIB", "").endswith("libpk_stub_rccl.so")
     import torch
 
     torch.cuda.is_available()  # torch's HIP runtime first (see conftest.py)
@@ -44,6 +44,8 @@ def main():
     from provekit_amd._lib import lib
     from provekit_amd.field import random_field
     from provekit_amd.whir import commit_batch
+
+    assert lib.pk_selftest_set_hook(2, 1) == 0  # the RCCL branch also for a repeated device (the stand-in allows what real RCCL refuses)
 
     stub = C.CDLL(os.environ["PK_RCCL_LIB"])
     stub.ncclStubCalls.argtypes = [C.POINTER(C.c_ulonglong)]
@@ -60,7 +62,7 @@ def main():
 
     for G in sizes:
         before = calls()
-        ctxs = provekit_amd.Context.create_set([0] * G)  # ncclCommInitAll through the RCCL branch (PK_RCCL_SAME_DEVICE)
+        ctxs = provekit_amd.Context.create_set([0] * G)  # ncclCommInitAll through the RCCL branch (test hook 2)
         assert [c.comm_info() for c in ctxs] == [(r, G, 2) for r in range(G)]  # kind 2 = PK_COMM_RCCL
         n = 1000
 
@@ -162,7 +164,9 @@ def main():
         assert np.array_equal(got, np.stack([np.arange(64, dtype=np.uint64) + 100 * r for r in range(G)]))
     assert calls()["init_rank"] - before["init_rank"] == G
 
-    # a rank that fails before its collective aborts the communicator (ncclCommAbort): its peer returns PK_ERR_RCCL, nobody hangs
+    # a rank that fails before its collective aborts ITS OWN communicator (ncclCommAbort is local); its peer, already waiting in the
+    # all-gather, is not woken by that: its collective fails when the wait for the missing rank ends (the stand-in's timeout, shortened by
+    # the test; with the real library the deadline of comm.hip comm_wait) and it returns PK_ERR_RCCL.  Nobody hangs.
     n_vars = 14
     poly = random_field(1 << n_vars, 3)
 

@@ -9,6 +9,7 @@
 // What it is not: a transport.  Ranks are threads of one process; a collective drains the caller's stream, meets its peers at
 // a host barrier and copies device to device.  It also RECORDS every call (ncclStubCalls) so a test can assert what the
 // library asked for.
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -22,7 +23,13 @@
 namespace {
 
 constexpr int kMaxRanks = 64;
-constexpr auto kTimeout = std::chrono::seconds(120);
+// how long a rank waits for its peers before the collective fails: the real library would wait for ever (a collective kernel spinning on
+// xGMI), the stand-in gives up so that a test cannot hang.  PK_STUB_RCCL_TIMEOUT_S shortens it for the tests that make a rank stay away.
+static const auto kTimeout = std::chrono::milliseconds([] {
+    const char* e = getenv("PK_STUB_RCCL_TIMEOUT_S");
+    const double v = e ? atof(e) : 0.0;
+    return (long long)(1000.0 * (v > 0.0 ? v : 120.0));
+}());
 
 struct Group {
     int world = 0;
@@ -167,14 +174,10 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
     return ncclSuccess;
 }
 
+// LOCAL, like the real call: this rank's communicator is torn down, nothing reaches the peers -- a rank waiting for this one in a
+// collective keeps waiting (here: until the stand-in's timeout; with the real library: until its own deadline aborts it, comm.hip)
 ncclResult_t ncclCommAbort(ncclComm_t c) {
     if (!c) return ncclInvalidArgument;
-    Group* g = as_comm(c)->grp;
-    {
-        std::lock_guard<std::mutex> lk(g->mu);
-        g->aborted = true;
-        g->cv.notify_all();
-    }
     std::lock_guard<std::mutex> lk(g_mu);
     g_calls.abort++;
     delete as_comm(c);

@@ -1,7 +1,8 @@
 """GPU parity at BASELINE.json's full sizes (configs[4]: the 2^26-coefficient batch-2 WHIR commit, and the 3-pass NTT shapes it
 and the m >= 23 proofs use), through the C ABI:
   * pk_ntt at 2^21 .. 2^23 against the oracle's transform (the 3-pass tilings; test_gpu_ntt.py stops at 2^20);
-  * the 2^26 commit: opened leaves equal the DEFINITION leaf_i[b*16+j] = f_{b,j}(w^i) evaluated by the oracle on the downloaded
+  * the 2^26 commit: the root equals the root the ORACLE builds from the same coefficients (its own encode of the whole codeword, its own
+    268 M compressions); opened leaves equal the DEFINITION leaf_i[b*16+j] = f_{b,j}(w^i) evaluated by the oracle on the downloaded
     coefficients, their auth paths chain to the root under the oracle's Skyscraper, and the root equals the one the G = 8
     sharded encode (pk_rs_encode_shard, the multi-GPU path, all shards on this GPU) interleaves to."""
 import ctypes as C
@@ -60,7 +61,14 @@ def test_commit_2p26_batch2_against_definition_and_sharded_root(ctx, oracle):
         one = oracle.to_mont(oracle.ints_to_limbs([1]))[0]
         for b in range(batch):
             assert np.array_equal(leaves[0, b * fw + 3], oracle.eval_univariate(np.ascontiguousarray(host[b][3::fw]), one))
+        # (1b) the root itself against the oracle's own commit of the same coefficients: the whole 2^23 x 32 codeword re-encoded and all
+        # 268 M compressions redone on the host (~12 GB of host memory, about a minute of all cores)
+        want_leaves = oracle.rs_encode(np.stack(host), batch, n_vars, rate, fold)
         del host
+        assert np.array_equal(want_leaves[idx.astype(np.int64)], leaves)
+        want_root = oracle.merkle_commit(want_leaves)[1]
+        del want_leaves
+        assert np.array_equal(want_root, root), "pk_commit's 2^26 root differs from the oracle-built root"
         # (2) every opened leaf chains to the root under the oracle's Skyscraper (leaf fold, then the auth path)
         dig = oracle.leaf_hash(leaves)
         for q in range(k):

@@ -494,7 +494,7 @@ def test_a_gate_that_gives_up_fails_the_proof_instead_of_proving_with_zero():
     """in latency mode a gated sumcheck kernel whose host stalled past the device-side bound used to run on with a
     ZERO challenge and pk_prove returned PK_OK with a transcript that does not verify.  Now the giving-up workgroup leaves a word in
     the pinned page and the host abandons the proof with PK_ERR_HIP.  A fresh process: the two test hooks (a short device bound, a host
-    that sleeps before publishing each challenge) are read once per process."""
+    that sleeps before publishing each challenge) are process-wide (pk_selftest_set_hook)."""
     import os
     import subprocess
     import sys
@@ -510,6 +510,8 @@ from provekit_amd._lib import ProveKitHipError
 from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
 from provekit_amd.sparse_matrix import R1CS
 from test_gpu_prove import satisfiable_r1cs, to_sparse
+from provekit_amd._lib import lib
+assert lib.pk_selftest_set_hook(0, 64) == 0 and lib.pk_selftest_set_hook(1, 30000) == 0   # gate spin bound, host stall in us
 m, m_0, nc, n_in = 12, 9, 500, 700
 ctx = provekit_amd.Context(0)
 nw, z, coeffs, trips = satisfiable_r1cs(nc, n_in, 31)
@@ -527,8 +529,7 @@ for attempt in range(2):
 ctx.set_latency_mode(False)
 print("PLAIN_AGAIN", scheme.prove(d_z, seed=1) == plain)
 ''' % (os.path.dirname(here), here)
-    env = dict(os.environ, PK_TEST_GATE_SPINS="64", PK_TEST_GATE_STALL_US="30000")
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.split(" ")[0] in ("SILENT", "REFUSED", "PLAIN_AGAIN")]
     assert lines == ["REFUSED -3 True", "REFUSED -3 True", "PLAIN_AGAIN True"], (lines, out.stderr[-1500:])
@@ -576,11 +577,12 @@ def test_transcript_equals_the_oracle_provers(ctx, oracle, m, m_0, nc, n_in, pow
     r1cs.close()
 
 
-@pytest.mark.parametrize("m", [21, 23])
+@pytest.mark.parametrize("m", [21, 23, 25])
 def test_transcript_equals_the_oracle_provers_at_the_bench_size(ctx, oracle, m):
     """the same equality at BASELINE configs[1]'s size (m = 21, m_0 = 20) under the reference's own derived schedule (109 / 28 / 16 / 11
-    queries, grinding up to 19 bits): 260 KB of proof, byte for byte -- and at configs[2]'s size class (m = 23: 2^20-leaf trees, three-pass
-    NTTs, five WHIR rounds)"""
+    queries, grinding up to 19 bits): 260 KB of proof, byte for byte -- at configs[2]'s size class (m = 23: 2^20-leaf trees, three-pass
+    NTTs, five WHIR rounds) -- and at configs[3]'s (m = 25: 2^22-leaf trees, six WHIR rounds, 23-bit grinding; ~20 GB of host memory
+    and half a minute of all cores for the oracle's side)"""
     import prover_ref as PR
 
     from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for

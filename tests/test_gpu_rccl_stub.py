@@ -22,7 +22,7 @@ STUB = os.path.join(STUB_DIR, "libpk_stub_rccl.so")
 def test_sharded_prover_through_the_rccl_branch_with_an_in_process_stand_in():
     if not os.path.exists(STUB):
         subprocess.check_call(["make", "-C", STUB_DIR])
-    env = dict(os.environ, PK_RCCL_LIB=STUB, PK_RCCL_SAME_DEVICE="1")
+    env = dict(os.environ, PK_RCCL_LIB=STUB, PK_STUB_RCCL_TIMEOUT_S="4")
     out = subprocess.run([sys.executable, os.path.join(HERE, "rccl_stub_driver.py"), "2,4,8"], env=env, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("RCCL_STUB_REPORT ")][-1]

@@ -30,6 +30,12 @@ int pk_selftest_random_fe(pk_ctx *ctx, const uint8_t seed32[32], uint32_t stream
  * twiddles. */
 int pk_selftest_dft(const uint64_t *in, const uint64_t *tw, uint64_t *out, int le, int d, size_t n_groups);
 
+/* hooks of the GPU suite (process-wide, 0 = off; the library reads no test switch from the environment): which = 0 the spin bound of a
+ * latency-mode gated kernel (to reach its give-up path in milliseconds), 1 microseconds the host sleeps before publishing each gate's
+ * challenge (a stalled host thread), 2 non-zero = pk_ctx_create_set takes the RCCL branch for a repeated device (with PK_RCCL_LIB naming the
+ * in-process stand-in tests/stub_rccl: real RCCL refuses two ranks on one GPU) */
+int pk_selftest_set_hook(int which, long value);
+
 #ifdef __cplusplus
 }
 #endif
