@@ -17,6 +17,7 @@ lib = C.CDLL(LIB_PATH)
 SIGNATURES = {
     "pk_probe_arith_device": (C.c_int, [vp, C.c_int, vp, vp, vp, sz]),
     "pk_probe_modmul_rate": (C.c_int, [vp, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),
+    "pk_probe_sq_round_rate": (C.c_int, [vp, C.c_int, C.c_uint, C.c_uint, C.c_uint, C.POINTER(C.c_double)]),
     "pk_probe_fp52_sqr": (C.c_int, [vp, vp, sz]),
     "pk_probe_coop_round": (C.c_int, [vp, vp, vp, C.c_uint, vp, vp]),
     "pk_probe_fp52_sqr_device": (C.c_int, [vp, vp, vp, sz]),

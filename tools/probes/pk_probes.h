@@ -13,6 +13,11 @@ int pk_probe_arith_device(pk_ctx *ctx, int op, const uint64_t *d_a, const uint64
 /* measurement aid (SURVEY 8d "measured_peak_modmul_per_s"): rate of register-resident 9x29-bit Montgomery squarings,
  * ilp (1|2|4) independent chains per lane, waves_per_simd (1..8) resident waves, iters squarings per chain */
 int pk_probe_modmul_rate(pk_ctx *ctx, unsigned waves_per_simd, unsigned ilp, unsigned iters, double *modmul_per_s);
+/* VERDICT r05 item 3, the ceiling of a hand-allocated Skyscraper square round by ABLATION: rounds per second of the product's round
+ * (variant 0) and of the same round with the instructions assembly could fold away left out (1: the 8 additions of the round constant;
+ * 2: also the zero-extensions of r into the 64-bit columns; 3: also the 8 doublings) -- wrong results, the product's multiply-adds and
+ * dependency structure (tools/probes/probes.hip sq_round_ablated, tools/sq_round_ablation.py, profiles/r06_sq_round_ablation.json) */
+int pk_probe_sq_round_rate(pk_ctx *ctx, int variant, unsigned waves_per_simd, unsigned ilp, unsigned iters, double *rounds_per_s);
 /* PROTOTYPE, not on the product path (tools/probes/fe52.hpp): the reference's f64-FMA Montgomery square on 5 x 52-bit limbs
  * (skyscraper/block-multiplier/src/portable_simd.rs:17-196, utils.rs:66-147, constants.rs:100-133; round-toward-zero as
  * fp-rounding/src/lib.rs:57-78).  a: n values < 2^256 (4 x u64 each) -> out5: n x 5 limbs of x^2 * 2^-260 mod p, lazily

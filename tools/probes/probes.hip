@@ -39,6 +39,77 @@ __global__ __launch_bounds__(256) void modmul_rate_kernel(const fe* __restrict__
     if (acc.v[8] == 0xffffffffu) fe_store(out + i, pack29(acc));  // never true (limbs stay < 2^30); keeps the chain live
 }
 
+// ---- what hand register allocation of the square round could buy at most -----------------------------------------
+// The square round of skyscraper29s.hpp (sky_sq_round_s) is 126 multiply-adds + ~99 other instructions; ~23 of the others exist only
+// because the compiler cannot place r + rc into the accumulator columns for free: 8 additions r + rc, 7 moves (the zero high halves of
+// the 64-bit column initial values) and 8 shifts (the doubled operand of the cross products).  Assembly could fold the first two groups
+// (consecutive-register pairs with a shared zero high half; the constant through the reduction's low columns as the first
+// multiply-add's 64-bit scalar addend) and nothing else.  ABLATION: the same round with those instructions simply left out -- the
+// results are wrong, the multiply-add count and the dependency structure are the product's -- is an upper bound on what any
+// hand-written version of the round can reach:  variant 0 = the product's round; 1 = no round constant (drops the 8 additions);
+// 2 = neither r nor rc enter the columns (drops additions AND zero-extensions: the columns start from 0 like columns 0..8);
+// 3 = variant 2 and the cross products use l instead of 2l (drops the 8 doublings as well).
+template <int VARIANT>
+__device__ __forceinline__ void sq_round_ablated(fe29& l, fe29& r) {
+    if (VARIANT == 0) {
+        sky_sq_round_s<3>(l, r);
+        return;
+    }
+    u64 acc[17];
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[9 + k] = VARIANT == 1 ? (u64)r.v[k] : 0;
+    const u32 top = VARIANT == 1 ? r.v[8] : 0u;
+    u32 a2[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) a2[j] = VARIANT == 3 ? l.v[j] : l.v[j] << 1;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        acc[2 * i] += (u64)l.v[i] * l.v[i];
+#pragma unroll
+        for (int j = i + 1; j < 9; j++) acc[i + j] += (u64)l.v[i] * a2[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const u32 m = ((u32)acc[i] * NP29) & M29;
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            if (i + j < 17) acc[i + j] += (u64)m * p29(j);
+        acc[i + 1] += acc[i] >> 29;
+    }
+    fe29 s;
+#pragma unroll
+    for (int k = 9; k < 16; k++) {
+        acc[k + 1] += acc[k] >> 29;
+        s.v[k - 9] = (u32)acc[k] & M29;
+    }
+    s.v[7] = (u32)acc[16] & M29;
+    s.v[8] = ((u32)(acc[16] >> 29) + top) & M29;  // (keeps the wrong values inside the column bound)
+    r = l;
+    l = s;
+}
+template <int VARIANT, int ILP>
+__global__ __launch_bounds__(256) void sq_round_rate_kernel(const fe* __restrict__ in, fe* __restrict__ out, unsigned iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    fe29 l[ILP], r[ILP];
+#pragma unroll
+    for (int k = 0; k < ILP; k++) {
+        l[k] = unpack_reduce29(fe_load(in + (i % 64)));
+        r[k] = unpack_reduce29(fe_load(in + ((i + 7) % 64)));
+        l[k].v[0] += (u32)k;
+    }
+    for (unsigned it = 0; it < iters; it++) {
+#pragma unroll
+        for (int k = 0; k < ILP; k++) sq_round_ablated<VARIANT>(l[k], r[k]);
+    }
+    fe29 acc = l[0];
+#pragma unroll
+    for (int k = 1; k < ILP; k++) acc = add29(acc, l[k]);
+    normalize29(acc);
+    if (acc.v[8] == 0xffffffffu) fe_store(out + i, pack29(acc));  // never true; keeps the chains live
+}
+
 // ---- the f64-FMA multiplier prototype (fe52.hpp) ----------------------------------------------------------------------------
 // general products by a constant: Montgomery (mont261_29) against Shoup (shoup261_29), register-resident chains
 template <int ILP, bool SHOUP>
@@ -296,6 +367,38 @@ int pk_probe_constmul_rate(pk_ctx* ctx, unsigned waves_per_simd, unsigned ilp, u
     PK_LAUNCH_CHECK(ctx);
     if ((rc = pk_timer_stop(ctx, &ms))) return rc;
     *modmul_per_s = (double)blocks * 256.0 * ilp * iters / (ms * 1e-3);
+    return PK_OK;
+}
+
+// square rounds per second of the hash's round and of its ablated variants (see sq_round_ablated): ilp = independent (l, r) chains per lane
+int pk_probe_sq_round_rate(pk_ctx* ctx, int variant, unsigned waves_per_simd, unsigned ilp, unsigned iters, double* rounds_per_s) {
+    if (!ctx || !rounds_per_s) return PK_ERR_BAD_ARG;
+    PK_ENTER(ctx);
+    PK_REQUIRE(ctx, variant >= 0 && variant <= 3 && waves_per_simd >= 1 && waves_per_simd <= 8 && (ilp == 1 || ilp == 2) && iters >= 1, "bad argument");
+    int rc = ensure_scratch(ctx, 1 << 20);
+    if (rc) return rc;
+    const unsigned blocks = (unsigned)ctx->num_cus * waves_per_simd;
+    fe* in = (fe*)ctx->d_scratch;
+    fe* out = in + 64;
+    PK_HIP(ctx, hipMemsetAsync(in, 0x11, 64 * 32, ctx->stream));
+    auto launch = [&](unsigned n) {
+#define PK_SQR(V)                                                                              \
+    if (ilp == 1) sq_round_rate_kernel<V, 1><<<blocks, 256, 0, ctx->stream>>>(in, out, n);     \
+    else sq_round_rate_kernel<V, 2><<<blocks, 256, 0, ctx->stream>>>(in, out, n)
+        if (variant == 0) { PK_SQR(0); }
+        else if (variant == 1) { PK_SQR(1); }
+        else if (variant == 2) { PK_SQR(2); }
+        else { PK_SQR(3); }
+#undef PK_SQR
+    };
+    launch(16);
+    PK_LAUNCH_CHECK(ctx);
+    float ms = 0;
+    if ((rc = pk_timer_start(ctx))) return rc;
+    launch(iters);
+    PK_LAUNCH_CHECK(ctx);
+    if ((rc = pk_timer_stop(ctx, &ms))) return rc;
+    *rounds_per_s = (double)blocks * 256.0 * ilp * iters / (ms * 1e-3);
     return PK_OK;
 }
 
