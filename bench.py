@@ -466,6 +466,11 @@ def sharded_proof_probe(provekit_amd, torch, rank, local_rank, world, dist, one_
     return out
 
 
+# provers in flight per size class on one MI355X (the memory allows 37 at m = 23 and 9 at m = 25): where more stop paying -- m = 23: 14 -> 66.2,
+# 20 -> 67.0, 24 -> 65.8 proofs/s; m = 25: 3 -> 15.7-15.9, 6 -> 15.9-16.1, 8 -> 16.0 (three provers' kernels already fill the chip): profiles/r06_size_class_sweep.jsonl
+SIZE_CLASS_PROVERS_CAP = {23: 20, 25: 6}
+
+
 def size_class_probe(provekit_amd, torch, local_rank, m, proofs_per_prover=3):
     """Secondary figure of the default line: another BASELINE size class (configs[2]: m = 23, configs[3]: m = 25) on this GPU --
     the reference's own derived WHIR schedule for that size, a satisfiable synthetic R1CS of the same construction as the bench's
@@ -473,14 +478,20 @@ def size_class_probe(provekit_amd, torch, local_rank, m, proofs_per_prover=3):
     A handful of proofs each: throughput with all provers in flight, then one proof at a time."""
     import threading
 
-    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, blinding_config_for
+    from provekit_amd.scheme import WhirConfig, WhirR1CSScheme, arena_bytes, blinding_config_for
 
     m_0 = m - 1
     n_wit = (1 << (m - 1)) - 5
     cfg_w, cfg_b = WhirConfig.derive(m), blinding_config_for(m_0)
     torch.cuda.empty_cache()  # the commit probe's coefficient tensors
     free, total = torch.cuda.mem_get_info(local_rank)
-    conc = max(1, min(16, int(min(0.5 * total, 0.8 * free) / (40 * 32 * (1 << m)))))
+    # what a prover really holds: its arena (pk_scheme_arena_bytes: every buffer of one proof), its copy of the witness, its context's
+    # scratch; the R1CS and the twiddle tables are shared by the provers of a device.  As many as fit in 80 % of the free HBM, up to
+    # the count past which more provers in flight stop paying (profiles/r06_size_class_sweep.jsonl); PK_BENCH_SIZE_CLASS_PROVERS overrides.
+    per_prover = arena_bytes(m, m_0, n_wit, cfg_w) + 32 * n_wit + (256 << 20)
+    conc = max(1, min(SIZE_CLASS_PROVERS_CAP.get(m, 16), int(0.8 * free / per_prover)))
+    if os.environ.get("PK_BENCH_SIZE_CLASS_PROVERS"):
+        conc = max(1, min(int(os.environ["PK_BENCH_SIZE_CLASS_PROVERS"]), int(0.95 * free / per_prover)))
     c0 = provekit_amd.Context(local_rank)
     r1cs, _, _, nc, n_in = synth_r1cs(c0, m_0, n_wit, seed=4321 + m)
     d_z, z_host = satisfying_witness(c0, r1cs, n_wit, nc, n_in, 7 + m)
@@ -501,7 +512,8 @@ def size_class_probe(provekit_amd, torch, local_rank, m, proofs_per_prover=3):
 
     from provekit_amd.hostinfo import usable_cores
 
-    if conc > usable_cores()["usable"]:
+    wait = os.environ.get("PK_BENCH_SIZE_CLASS_WAIT") or ("poll" if conc > usable_cores()["usable"] else "spin")
+    if wait == "poll":
         provekit_amd.Context.set_host_wait(local_rank, "poll")  # more provers than cores: the library's own query-and-sleep wait (switchable)
     wave(900000, 1)
     torch.cuda.synchronize()
@@ -518,7 +530,8 @@ def size_class_probe(provekit_amd, torch, local_rank, m, proofs_per_prover=3):
     out = {"m": m, "m_0": m_0, "schedule": "derived by pk_whir_config_derive (a restatement of WhirConfig::new pinned against the reference at n = 21 and n = 8 only: "
                                        "queries / pow_bits at this size are an extrapolation)",
            "constraints": nc, "witnesses": n_wit, "queries": list(cfg_w.num_queries) + [cfg_w.final_queries],
-           "pow_bits": list(cfg_w.pow_bits) + [cfg_w.final_pow_bits], "provers": conc, "proofs_timed": conc * proofs_per_prover,
+           "pow_bits": list(cfg_w.pow_bits) + [cfg_w.final_pow_bits], "provers": conc, "host_wait": wait, "arena_bytes_per_prover": per_prover,
+           "proofs_timed": conc * proofs_per_prover,
            "proofs_per_s": conc * proofs_per_prover / dt, "single_proof_ms": 1e3 * sorted(singles)[1]}
     for p in provers:
         p.close()
@@ -865,9 +878,12 @@ def main():
     cfg_w = WhirConfig.derive(m)  # the reference's own schedule (new_whir_config_for_size): queries, OOD samples, pow_bits
     cfg_b = blinding_config_for(m_0)
     conc = 1 if args.sharded else max(1, args.concurrency)
-    # every prover owns an arena of 26 x 32 B x 2^m (+ workspace, R1CS copy): keep the provers within half of the HBM
-    per_prover = 40 * 32 * (1 << m)
-    conc = max(1, min(conc, int(float(os.environ.get("PK_BENCH_HBM_FRACTION", "0.5")) * torch.cuda.get_device_properties(local_rank).total_memory / per_prover)))
+    # every prover owns its arena (pk_scheme_arena_bytes, ~20.6 x 32 B x 2^m), a copy of the statement and of the witness and a workspace:
+    # keep the provers within 80 % of the HBM
+    from provekit_amd.scheme import arena_bytes
+
+    per_prover = arena_bytes(m, m_0, n_wit, cfg_w) + 8 * 32 * (1 << m_0) + (256 << 20)
+    conc = max(1, min(conc, int(float(os.environ.get("PK_BENCH_HBM_FRACTION", "0.8")) * torch.cuda.get_device_properties(local_rank).total_memory / per_prover)))
     from provekit_amd.device_set import join_device_set, max_over_ranks
 
     workers = []  # (ctx, prover, witness): one independent prover per worker, all on this rank's GPU

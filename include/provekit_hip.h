@@ -477,6 +477,9 @@ int pk_whir_r1cs_io_pattern(unsigned m_0, const pk_whir_config *whir_witness, co
 int pk_io_pattern_check(const uint8_t *pattern, size_t n, unsigned m_0, const pk_whir_config *whir_witness,
                         const pk_whir_config *whir_for_hiding_spartan, char *why, size_t why_cap);
 int pk_scheme_domain_separator(const pk_scheme *scheme, char *buf, size_t cap, size_t *len);
+/* host only, for capacity planning: the device memory pk_scheme_create will allocate for a prover of this shape (its arena: every
+ * buffer one proof needs, ~20.6 x 32 bytes x 2^m at rate 1/2, fold 16, batch 2) -- how many provers fit next to each other */
+int pk_scheme_arena_bytes(unsigned m, unsigned m_0, size_t num_witnesses, const pk_whir_config *whir_witness, size_t *bytes);
 
 /* ------------------------------------------------------------------ X4: the R1CS witness builders
  * R1CSSolver::solve_witness_vec (provekit/prover/src/r1cs.rs:29-40): the loop over &[WitnessBuilder] calling

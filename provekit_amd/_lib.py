@@ -151,6 +151,7 @@ SIGNATURES = {
     "pk_scheme_destroy": (C.c_int, [vp, vp]),
     "pk_prove": (C.c_int, [vp, vp, vp, sz, vp, vp, sz, C.POINTER(sz)]),
     "pk_scheme_domain_separator": (C.c_int, [vp, vp, sz, C.POINTER(sz)]),
+    "pk_scheme_arena_bytes": (C.c_int, [C.c_uint, C.c_uint, sz, vp, C.POINTER(sz)]),
     "pk_ctx_set_latency_mode": (C.c_int, [vp, C.c_int]),
     "pk_scheme_set_io_pattern": (C.c_int, [vp, vp, vp, sz]),
     "pk_whir_r1cs_io_pattern": (C.c_int, [C.c_uint, vp, vp, vp, sz, C.POINTER(sz)]),

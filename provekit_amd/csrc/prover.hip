@@ -1039,6 +1039,23 @@ int pk_scheme_destroy(pk_ctx* ctx, pk_scheme* s) {
     return PK_OK;
 }
 
+// arena = the sum of pk_prove's allocations (nothing is freed inside a proof).  With N = 2^m, R = 2^starting_log_inv_rate,
+// F = 2^folding_factor: f, g in both forms 4N; initial codeword batch*R*N and its tree 2R/F N; working polynomial and the
+// sumcheck ping-pong 4N; round codewords (domain halves each round) < R N, their trees < 2R/F N, folded polynomials
+// < 2/F N; deferred eq table N; a, b, c, eq and the second eq table 5*2^m_0; external rows 3*num_witnesses.  The small
+// blinding scheme (2^(nb+1) <= 2^9 elements) and alignment are covered by the constant.
+static size_t scheme_arena_bytes(unsigned m, unsigned m_0, size_t num_witnesses, const pk_whir_config& w) {
+    const double N = (double)((size_t)1 << m), R = (double)((size_t)1 << w.starting_log_inv_rate), F = (double)((size_t)1 << w.folding_factor);
+    const double units = 4.0 + w.batch_size * R + 2.0 * R / F + 4.0 + R + 2.0 * R / F + 2.0 / F + 1.0;
+    const double fes = units * N + 5.0 * (double)((size_t)1 << m_0) + 3.0 * (double)num_witnesses;
+    return (size_t)(1.05 * 32.0 * fes) + ((size_t)64 << 20);
+}
+int pk_scheme_arena_bytes(unsigned m, unsigned m_0, size_t num_witnesses, const pk_whir_config* whir_witness, size_t* bytes) {
+    if (!whir_witness || !bytes || m > 28 || m_0 > m) return PK_ERR_BAD_ARG;
+    *bytes = scheme_arena_bytes(m, m_0, num_witnesses, *whir_witness);
+    return PK_OK;
+}
+
 int pk_scheme_create(pk_ctx* ctx, const pk_r1cs* r1cs, size_t num_constraints, size_t num_witnesses, unsigned m, unsigned m_0,
                      const pk_whir_config* whir_witness, const pk_whir_config* whir_for_hiding_spartan, pk_scheme** out) {
     if (!ctx || !out) return PK_ERR_BAD_ARG;
@@ -1075,18 +1092,7 @@ int pk_scheme_create(pk_ctx* ctx, const pk_r1cs* r1cs, size_t num_constraints, s
     s->whir_witness = *whir_witness;
     s->whir_hiding = *whir_for_hiding_spartan;
     s->domain_separator = whir_r1cs_io_pattern(s->m_0, s->whir_witness, s->whir_hiding);
-    // arena = the sum of pk_prove's allocations (nothing is freed inside a proof).  With N = 2^m, R = 2^starting_log_inv_rate,
-    // F = 2^folding_factor: f, g in both forms 4N; initial codeword batch*R*N and its tree 2R/F N; working polynomial and the
-    // sumcheck ping-pong 4N; round codewords (domain halves each round) < R N, their trees < 2R/F N, folded polynomials
-    // < 2/F N; deferred eq table N; a, b, c, eq and the second eq table 5*2^m_0; external rows 3*num_witnesses.  The small
-    // blinding scheme (2^(nb+1) <= 2^9 elements) and alignment are covered by the constant.
-    {
-        const pk_whir_config& w = s->whir_witness;
-        const double N = (double)((size_t)1 << m), R = (double)((size_t)1 << w.starting_log_inv_rate), F = (double)((size_t)1 << w.folding_factor);
-        const double units = 4.0 + w.batch_size * R + 2.0 * R / F + 4.0 + R + 2.0 * R / F + 2.0 / F + 1.0;
-        const double fes = units * N + 5.0 * (double)((size_t)1 << m_0) + 3.0 * (double)num_witnesses;
-        s->arena_bytes = (size_t)(1.05 * 32.0 * fes) + ((size_t)64 << 20);
-    }
+    s->arena_bytes = scheme_arena_bytes(m, m_0, num_witnesses, s->whir_witness);
     if (hipMalloc((void**)&s->arena, s->arena_bytes) != hipSuccess) {
         delete s;
         return set_err(ctx, PK_ERR_OOM, "hipMalloc of the %zu MiB prover arena failed", s->arena_bytes >> 20);

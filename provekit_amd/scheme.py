@@ -94,6 +94,15 @@ def io_pattern_check(pattern: bytes, m_0: int, whir_witness: WhirConfig, whir_fo
     return "" if rc == 0 else (why.value.decode() or f"error {rc}")
 
 
+def arena_bytes(m: int, m_0: int, num_witnesses: int, whir_witness: WhirConfig) -> int:
+    """device memory one prover of this shape allocates at creation (pk_scheme_arena_bytes; host only): capacity planning"""
+    cw = _cfg_struct(whir_witness)
+    n = C.c_size_t()
+    if lib.pk_scheme_arena_bytes(m, m_0, num_witnesses, C.byref(cw), C.byref(n)):
+        raise ValueError("pk_scheme_arena_bytes: bad scheme shape")
+    return n.value
+
+
 def blinding_config_for(m_0: int, test_pow_bits: float | None = None) -> WhirConfig:
     """new_whir_config_for_size(next_power_of_two(4*m_0) + 1, 2) (provekit/r1cs-compiler/src/whir_r1cs.rs:31-34)"""
     nb = max((4 * m_0 - 1).bit_length(), 0)

@@ -48,7 +48,7 @@ def test_the_product_header_holds_only_the_binders_api():
 
     api, selftests = declared_symbols(), declared_symbols(SELFTEST_HEADER)
     assert not [s for s in api if s.startswith(("pk_selftest", "pk_probe"))]
-    assert all(s.startswith("pk_selftest_") for s in selftests) and len(api) == 102
+    assert all(s.startswith("pk_selftest_") for s in selftests) and len(api) == 103
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
     exported = sorted(set(re.findall(r" T (pk_[a-z0-9_]+)$", nm, flags=re.M)))
     assert exported == sorted(api + selftests)
