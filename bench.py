@@ -131,7 +131,8 @@ def proof_algorithmic_bytes(m, m_0, n_wit, cfg_w, cfg_b):
 def ntt_roofline(prof, steps, m, cfg_w, cfg_b, peak_modmul=None):
     """RS-encode kernels (deinterleave + NTT passes) of one proof, one proof at a time: 64 B per codeword element; and the
     second roofline: modular multiplications -- 0.5 log2(N) butterfly products plus one inter-pass twiddle per
-    element and pass boundary -- over the measured peak rate."""
+    element and pass boundary -- over the measured peak rate of the product the NTT is made of (the Shoup product by a constant,
+    a GENERAL product: 143 multiply-adds; not the squaring's 126 the hash's peak is measured on)."""
     elems, muls = 0, 0.0
 
     def encode(rows, cols):
@@ -157,7 +158,7 @@ def ntt_roofline(prof, steps, m, cfg_w, cfg_b, peak_modmul=None):
     if peak_modmul and ms:
         rate = muls / (ms * 1e-3)
         out["alu"] = {"achieved": rate / 1e12, "peak": peak_modmul / 1e12, "unit": "T modmul/s", "frac": rate / peak_modmul,
-                      "modmul_per_proof": muls}
+                      "modmul_per_proof": muls, "peak_is": "register-resident Shoup products by a constant (tools/probes pk_probe_constmul_rate), best over occupancy / ILP"}
     return out
 
 
@@ -375,8 +376,9 @@ def single_stream_figures(torch, ctx, prover, d_z, latency_pass, sharded, iso_st
         finally:
             ctx.set_latency_mode(False)
     # SURVEY 8d's second roofline: peak rate of the register-resident Montgomery squaring, best over occupancy / ILP
-    peak_modmul = 0.0
-    try:  # the probe lives in tools/libpk_probes.so (the lab), not in the product library
+    # ... and, for the NTT (whose products are all by constants), the peak rate of the register-resident Shoup product it is made of
+    peak_modmul, peak_constmul = 0.0, 0.0
+    try:  # the probes live in tools/libpk_probes.so (the lab), not in the product library
         from tools.pk_probes import lib as probes
 
         for waves in (2, 4, 8):
@@ -384,9 +386,11 @@ def single_stream_figures(torch, ctx, prover, d_z, latency_pass, sharded, iso_st
                 r = C.c_double()
                 ctx._check(probes.pk_probe_modmul_rate(ctx.handle, waves, ilp, 2000, C.byref(r)))
                 peak_modmul = max(peak_modmul, r.value)
+                ctx._check(probes.pk_probe_constmul_rate(ctx.handle, waves, ilp, 1500, 1, C.byref(r)))
+                peak_constmul = max(peak_constmul, r.value)
     except ImportError as e:
         print(f"[bench] no multiplier-peak probe ({e}): roofline.alu.peak is null", file=sys.stderr)
-    return {"iso_dt": iso_dt, "lat_dt": lat_dt, "prof_iso": prof_iso, "iso_steps": iso_steps, "peak_modmul": peak_modmul}
+    return {"iso_dt": iso_dt, "lat_dt": lat_dt, "prof_iso": prof_iso, "iso_steps": iso_steps, "peak_modmul": peak_modmul, "peak_constmul": peak_constmul}
 
 
 def single_stream_probe(provekit_amd, torch, local_rank, m, latency_pass):
@@ -991,7 +995,7 @@ def main():
         ss = single_stream_figures(torch, ctx, workers[0][1], workers[0][2], not args.no_latency_pass, args.sharded)
         ss["how"] = "this process, after the timed region, spinning waits" + (" -- NO: blocking-wait mode, a single prover pays ~20 us per synchronisation for it" if block_wait else "")
     if ss is None:
-        ss = {"iso_dt": float("nan"), "lat_dt": None, "prof_iso": {}, "iso_steps": 8, "peak_modmul": 0.0, "how": "rank 0 only"}
+        ss = {"iso_dt": float("nan"), "lat_dt": None, "prof_iso": {}, "iso_steps": 8, "peak_modmul": 0.0, "peak_constmul": 0.0, "how": "rank 0 only"}
     iso_dt, lat_dt, prof_iso, iso_steps, peak_modmul = ss["iso_dt"], ss["lat_dt"], ss["prof_iso"], ss["iso_steps"], ss["peak_modmul"]
 
     # ---- secondary figures of the default line (each guarded: none may break the line) -----------------------------------
@@ -1206,7 +1210,7 @@ def main():
             "step_algorithmic_bytes": step_bytes,
             # BASELINE.json's metric also asks for achieved HBM GB/s on the WHIR NTT: algorithmic bytes = 64 B per codeword
             # element (one logical read + write) over the measured time of all encode kernels of a proof
-            "roofline_ntt": ntt_roofline(prof_iso, iso_steps, m, cfg_w, cfg_b, peak_modmul),
+            "roofline_ntt": ntt_roofline(prof_iso, iso_steps, m, cfg_w, cfg_b, ss.get("peak_constmul") or None),
             "single_stream": {"ms_per_proof": 1e3 * iso_dt, "proofs_per_s": 1.0 / iso_dt,
                               "latency_mode_ms_per_proof": None if lat_dt is None else 1e3 * lat_dt,
                               "note": "one proof at a time; latency_mode = pk_ctx_set_latency_mode (sumcheck rounds enqueued one ahead "

@@ -38,7 +38,7 @@ struct pk_ctx {
     void* h_pinned = nullptr;  // pinned host staging for small results
     size_t pinned_bytes = 0;
     std::map<unsigned, void*> twiddles;  // log2(N) -> device table of w_N^e, N entries (owned; ntt.hip)
-    std::map<unsigned, void*> twiddles29[2];  // [0] of twiddles, [1] of twiddles_scaled: 9 x u32 per entry, limbs of 32*value (ntt.hip)
+    std::map<unsigned, void*> twiddles29[2];  // [0] of twiddles, [1] of twiddles_scaled: 18 x u32 per entry, the Shoup multiplier form (ntt_regs.hpp tw29s)
     std::map<unsigned, void*> twiddles_pass;   // inter-pass twiddles in access order, per (size, pass, variant) (ntt.hip get_pass_table)
     std::map<unsigned, void*> twiddles_scaled;  // log2(N) -> 32 * w_N^e as plain integers: the hash-ready output scaling (ntt.hip)
     unsigned red_seq = 0;  // sequence number of the last reduction launch (completion flag in h_pinned)

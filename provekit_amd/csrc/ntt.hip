@@ -236,15 +236,16 @@ __global__ __launch_bounds__(NTHREADS) void ntt_pass_kernel(PassParams p) {
 
 // ------------------------------------------------------------------------------------------------------
 // Fast path: the same pass (same PassParams, same index maps) with the butterflies kept in REGISTERS.
-// A 256-lane workgroup owns a 2048-element tile = [R = 2^LOG_R rows] x [BT = 2048/R adjacent elements]; each lane
-// holds 8 elements in the 9x29-bit lazy form (fe29.hpp) and runs a radix-2^d DIF butterfly network on them
-// (d = 3 except possibly the first round), so LDS is touched only BETWEEN rounds: ceil(LOG_R/3)-1 exchanges instead
-// of LOG_R read-modify-write sweeps.  Twiddles come from the same w_N^e table (an entry is turned into the
-// pre-shifted 29-bit form on the fly: mont261(a, 32*w) = a*w*2^-256).
+// A 512-lane workgroup owns a 2048-element tile = [R = 2^LOG_R rows] x [BT = 2048/R adjacent elements]; each lane holds 2^LE = 4
+// elements in the 9x29-bit lazy form (fe29.hpp) and runs a radix-2^d DIF butterfly network on them (ntt_regs.hpp; d = 2 except
+// possibly the first round), so LDS is touched only BETWEEN rounds: ceil(LOG_R/2)-1 exchanges instead of LOG_R read-modify-write
+// sweeps.  Every multiplication is by a constant known before the launch and takes the Shoup form (value + precomputed quotient, 72
+// bytes per table entry; the powers of w_8 are compile-time constants).  118 registers per lane: four waves per SIMD -- the
+// multiply-add pipe needs two ready waves to run at its rate, and a wave of this kernel waits (loads, barriers) a third of the time.
 //
 // Tile index I (11 bits) = r * BT + b.  Round j transforms digit D_j of r (digits are taken from the top of r: DIF),
 // leaving the frequency digit a_j in the same bit positions; the output frequency is the digit reversal
-// k = a_0 + 2^d0 a_1 + 2^(d0+d1) a_2.  In round j a lane's 8 registers are indexed by (digit bits | low 3-d_j bits of b).
+// k = a_0 + 2^d0 a_1 + 2^(d0+d1) a_2 + ...  In round j a lane's registers are indexed by (digit bits | low LE-d_j bits of b).
 __host__ __device__ __forceinline__ constexpr int bitrev_c(int v, int bits) {
     int r = 0;
     for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i);
@@ -548,10 +549,11 @@ int get_twiddles29(pk_ctx* ctx, unsigned log_n, int which, const fe* W, const u3
     return PK_OK;
 }
 
-// Pass-ordered tables pay where the size-N operand table no longer fits the caches (36 B x 2^20 = 36 MiB > the 32 MiB of L2): there
-// the strided gathers cost 2.6x the data traffic of a pass.  Below that both tables are cache-resident and the gathers are free;
-// measured at the proof's 2^18 the re-ordered table + XCD order ran the strided passes 3-8 % slower, so small sizes keep the gather.
-constexpr unsigned PASS_TABLE_MIN_LOG_N = 20;
+// Pass-ordered tables pay where the size-N multiplier table no longer fits the caches (72 B x 2^19 = 36 MiB > the 32 MiB of L2): there
+// the strided gathers cost 2.6x the data traffic of a pass.  Below that both tables are cache-resident and the gathers are free.
+// Measured on the 2^22 / 2^21-coefficient encodes (rows 2^19 / 2^18), same box, alternating: threshold 20 -> 1.705 / 0.783 ms,
+// 19 -> 1.634 / 0.793, 18 -> 1.641 / 0.814.
+constexpr unsigned PASS_TABLE_MIN_LOG_N = 19;
 // the pass-ordered table of one (size, pass, variant): key = log_n | pass << 8 | scaled << 12
 int get_pass_table(pk_ctx* ctx, unsigned log_n, unsigned pass, bool scaled, const u32* src29, size_t rows_k, size_t row, size_t mul, const u32** out) {
     const unsigned key = log_n | (pass << 8) | ((scaled ? 1u : 0u) << 12);
