@@ -27,7 +27,7 @@ for f in glob.glob(f"{src}/VALUBusy/**/*counter_collection.csv", recursive=True)
         k = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
         if "leaf_hash_kernel" in k:
             leaf.append((dur[r["Dispatch_Id"]], float(r["Counter_Value"])))
-        if not any(x in k for x in ("_kernel", "Kernel")) or k.startswith(("at::", "__amd", "modmul_rate")):  # the peak probe is not part of a proof
+        if not any(x in k for x in ("_kernel", "Kernel")) or k.startswith(("at::", "__amd", "modmul_rate", "constmul_rate", "sq_round_rate")):  # the peak probe is not part of a proof
             continue
         d = dur[r["Dispatch_Id"]] * 1e-6
         agg[k][0] += 1
