@@ -882,8 +882,6 @@ def main():
     cfg_w = WhirConfig.derive(m)  # the reference's own schedule (new_whir_config_for_size): queries, OOD samples, pow_bits
     cfg_b = blinding_config_for(m_0)
     conc = 1 if args.sharded else max(1, args.concurrency)
-    if one_gpu and world > 1:  # development mode: the ranks share ONE GPU, so they share its memory and its provers too
-        conc = max(1, conc // world)
     # every prover owns its arena (pk_scheme_arena_bytes, ~20.6 x 32 B x 2^m), a copy of the statement and of the witness and a workspace:
     # keep the provers within 80 % of the HBM
     from provekit_amd.scheme import arena_bytes
