@@ -144,6 +144,20 @@ PK_HD fe29 cond_sub_p29(const fe29& a) {
     return r;
 }
 
+// the same exact reduction delivered as 8 x u32: pack first, then ONE conditional subtraction of p as a borrow chain over the eight
+// 32-bit words (8 subtract-with-borrow + 8 selects, against three instructions a limb for the signed sweep above and its select)
+PK_HD fe pack_canon29(const fe29& a) {  // normalized value < 2p  ->  canonical [0, p) as 8 x u32
+    const fe w = pack29(a);
+    fe d;
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d.v[i] = __builtin_subc(w.v[i], kPlimb(i), borrow, &borrow);
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.v[i] = borrow ? w.v[i] : d.v[i];
+    return r;
+}
+
 // ---- products ---------------------------------------------------------------------------------
 // column sums of a*b.  Requires 9*max(a)*max(b) + 9*2^58 + 2^36 < 2^64 (e.g. limbs < 2^30 each).
 PK_HD void mul_cols29(const fe29& a, const fe29& b, u64 (&acc)[17]) {
@@ -363,14 +377,14 @@ PK_HD void dot29_add(dot29& d, const fe29& a, const fe29& b) {
 // the sum as a fully reduced field element: sum_t a_t * y_t * 2^-256 (the Montgomery product's scaling, as fe_mul29)
 PK_HD fe dot29_result(dot29& d) {
     if (d.pending) dot29_flush(d);
-    return pack29(cond_sub_p29(d.run));
+    return pack_canon29(d.run);
 }
 
 // ---- drop-in for the 8x32 API of fe.hpp ---------------------------------------------------------
 // a, b < p (ark-ff semantics) -> a*b*2^-256 mod p, fully reduced
 PK_HD fe fe_mul29(const fe& a, const fe& b) {
     fe29 r = mont261_29(unpack29<0>(a), unpack29<5>(b));  // < 32 p^2 / 2^261 + p < 1.2 p
-    return pack29(cond_sub_p29(r));
+    return pack_canon29(r);
 }
 
 PK_HD fe fe_mulx(const fe& a, const fe& b) { return fe_mul29(a, b); }
@@ -378,7 +392,7 @@ PK_HD fe fe_mulx(const fe& a, const fe& b) { return fe_mul29(a, b); }
 PK_HD fe fe_sqrx(const fe& a) {
     u64 acc[17];
     sqr_cols29(unpack29<0>(a), acc);
-    return pack29(cond_sub_p29(reduce256_29(acc)));
+    return pack_canon29(reduce256_29(acc));
 }
 // Montgomery -> canonical (x < p)
 PK_HD fe fe_from_montx(const fe& a) {
@@ -388,7 +402,7 @@ PK_HD fe fe_from_montx(const fe& a) {
     for (int k = 0; k < 9; k++) acc[k] = x.v[k];
 #pragma unroll
     for (int k = 9; k < 17; k++) acc[k] = 0;
-    return pack29(cond_sub_p29(reduce256_29(acc)));
+    return pack_canon29(reduce256_29(acc));
 }
 // canonical (< p) -> Montgomery: x * R^2 * 2^-256
 PK_HD fe fe_to_montx(const fe& a) {

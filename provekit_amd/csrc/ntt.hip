@@ -334,7 +334,7 @@ __device__ __forceinline__ void ntt8_round(fe29 (&x)[1 << LE], const PassParams&
             } else {
                 y = a == 0 ? red29(x[reg]) : red29w(x[reg]);
             }
-            fe_store(c.out + (size_t)k * p.out_stride_r + (size_t)b * p.out_stride_v, pack29(p.lazy_store ? y : cond_sub_p29(y)));
+            fe_store(c.out + (size_t)k * p.out_stride_r + (size_t)b * p.out_stride_v, p.lazy_store ? pack29(y) : pack_canon29(y));
         }
     }
 #undef PK_TILE_INDEX
