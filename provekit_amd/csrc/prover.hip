@@ -130,10 +130,7 @@ __global__ __launch_bounds__(256) void random_fe_kernel(fe* __restrict__ out, si
             x.v[7] &= 0x3fffffffu;  // < 2^254
             u32 borrow = 0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                u64 t = (u64)x.v[k] - kPlimb(k) - borrow;
-                borrow = (u32)(t >> 32) & 1u;
-            }
+            for (int k = 0; k < 8; k++) (void)__builtin_subc(x.v[k], kPlimb(k), borrow, &borrow);
             if (borrow) {  // x < p: accepted
                 fe_store(out + 2 * j + half, x);
                 if (half == 0) done0 = true;

@@ -48,9 +48,7 @@ __host__ __device__ __forceinline__ fe wide_reduce(const wide& w) {
 #pragma unroll
     for (int i = 0; i < 9; i++) {
         mc += (u64)q * (i < 8 ? kPlimb(i) : 0u);
-        u64 t = (u64)a[i] - (u32)mc - borrow;
-        a[i] = (u32)t;
-        borrow = (u32)(t >> 32) & 1u;
+        a[i] = __builtin_subc(a[i], (u32)mc, borrow, &borrow);
         mc >>= 32;
     }
 #pragma unroll
@@ -58,11 +56,7 @@ __host__ __device__ __forceinline__ fe wide_reduce(const wide& w) {
         u32 d[9];
         u32 b = 0;
 #pragma unroll
-        for (int i = 0; i < 9; i++) {
-            u64 t = (u64)a[i] - (i < 8 ? kPlimb(i) : 0u) - b;
-            d[i] = (u32)t;
-            b = (u32)(t >> 32) & 1u;
-        }
+        for (int i = 0; i < 9; i++) d[i] = __builtin_subc(a[i], i < 8 ? kPlimb(i) : 0u, b, &b);
 #pragma unroll
         for (int i = 0; i < 9; i++) a[i] = b ? a[i] : d[i];
     }
