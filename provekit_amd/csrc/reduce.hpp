@@ -118,18 +118,58 @@ __device__ __forceinline__ fe fe_load_sc1(const fe* p) {
     for (int i = 0; i < 8; i++) v.v[i] = __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return v;
 }
+// Sum K field elements per thread across the 256-thread block: thread k (k < K) returns sum number k, fully reduced; the others
+// return garbage.  Column sums through LDS instead of wavefront shuffles: every thread parks its 8K words in a [word][thread]
+// table (rows padded by one: conflict-free both ways), then 8K x PARTS lanes of the FIRST wavefront each add up one word over
+// 256/PARTS threads (a sum of 256 words fits 40 bits) and thread k collects its 8 limb sums.  The block's other three wavefronts
+// are done after one store per word: ~600 wave-instructions per block for K = 3 where the shuffle tree of 64-bit limb sums
+// (block_reduce_wide, still used by the one-sum kernels) took ~4,800.
+template <int K>
+__device__ __forceinline__ fe block_reduce_fe(const fe (&acc)[K]) {
+    constexpr int W = 8 * K;
+    constexpr int PARTS = W <= 8 ? 8 : (W <= 16 ? 4 : (W <= 32 ? 2 : 1));
+    constexpr int LEN = RED_THREADS / PARTS;
+    static_assert(W * PARTS <= 64, "one wavefront sums the columns");
+    __shared__ u32 cols[W][RED_THREADS + 1];
+    __shared__ u64 part_sums[PARTS][W];
+    const unsigned tid = threadIdx.x;
+    __syncthreads();  // the tables of an earlier call in this kernel are no longer being read
+#pragma unroll
+    for (int k = 0; k < K; k++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) cols[8 * k + i][tid] = acc[k].v[i];
+    __syncthreads();
+    if (tid < W * PARTS) {
+        const unsigned w = tid % W, part = tid / W;
+        const u32* col = &cols[w][part * LEN];
+        u64 s0 = 0, s1 = 0, s2 = 0, s3 = 0;  // four independent chains: the LDS reads of one hide behind the adds of the others
+#pragma unroll 4
+        for (int t = 0; t < LEN; t += 4) {
+            s0 += col[t];
+            s1 += col[t + 1];
+            s2 += col[t + 2];
+            s3 += col[t + 3];
+        }
+        part_sums[part][w] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    wide t = wide_zero();
+    if (tid < K) {
+#pragma unroll
+        for (int p = 0; p < PARTS; p++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) t.l[i] += part_sums[p][8 * tid + i];
+    }
+    return wide_reduce(t);  // limb sums of 256 values < p
+}
+
 template <int K>
 __device__ __forceinline__ void grid_finish_fe(fe (&acc)[K], uint4* smem, fe* __restrict__ partials, unsigned* __restrict__ ticket,
                                                fe* __restrict__ result, unsigned seq = 0) {
     static_assert(K <= 64, "the K results live in the first wavefront");
     __shared__ unsigned s_last;
-    wide w[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        w[k] = wide_zero();
-        wide_add_fe(w[k], acc[k]);
-    }
-    fe mine = block_reduce_wide<K>(w, smem);  // thread k holds sum k
+    (void)smem;
+    fe mine = block_reduce_fe<K>(acc);  // thread k holds sum k
     const unsigned tid = threadIdx.x;
     if (gridDim.x == 1) {  // a single workgroup (the late, tiny rounds): its sums are the results -- no ticket, no second pass
         if (tid < 64) {
@@ -153,13 +193,14 @@ __device__ __forceinline__ void grid_finish_fe(fe (&acc)[K], uint4* smem, fe* __
     }
     __syncthreads();
     if (!s_last) return;
+    fe tot[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) w[k] = wide_zero();
+    for (int k = 0; k < K; k++) tot[k] = fe_zero();
     for (unsigned b = tid; b < gridDim.x; b += RED_THREADS) {  // gridDim.x <= RED_MAX_BLOCKS: at most 4 per thread
 #pragma unroll
-        for (int k = 0; k < K; k++) wide_add_fe(w[k], fe_load_sc1(partials + (size_t)b * K + k));
+        for (int k = 0; k < K; k++) tot[k] = fe_add(tot[k], fe_load_sc1(partials + (size_t)b * K + k));
     }
-    mine = block_reduce_wide<K>(w, smem);
+    mine = block_reduce_fe<K>(tot);
     if (tid < 64) {
         unsigned* out = reinterpret_cast<unsigned*>(result);  // pinned, fine-grained host memory
         if (tid < K) {
@@ -326,10 +367,11 @@ inline int collect_reduction_spin(pk_ctx* ctx, unsigned seq, uint64_t* host_out)
     return PK_OK;
 }
 
-// Work items per thread of a reduction kernel.  A thread's epilogue (its share of the block reduction: ~1,200 instructions for three
-// sums) costs as much as one or two items, so with one item per thread a quarter of such a kernel's vector work is epilogue.  Four
-// items per thread: headline +1.6 % (284.3 -> 288.8 proofs/s, same box, alternating), one proof at a time +1 % slower (fewer waves
-// to hide latency with; 8 items: +1.9 % / +3.5 % slower, 16: +1.4 % / +10 % slower) -- so latency mode keeps one item per thread.
+// Work items per thread of a reduction kernel.  With the shuffle-tree epilogue (~1,200 instructions per thread for three sums) one
+// item per thread made a quarter of such a kernel's vector work epilogue: four items per thread gave +1.6 % on the headline.  With
+// the LDS column sums (block_reduce_fe) the epilogue is an eighth of that and the choice hardly matters any more (same box,
+// alternating: 1 item 293.2 proofs/s / 8.77 ms one proof at a time, 2: 292.3 / 8.81, 4: 293.9 / 8.88); four stays for the
+// many-prover mode, one for latency mode.  profiles/r06_reduction_items_ab.txt
 inline unsigned reduction_blocks(const pk_ctx* ctx, size_t work_items) {
     const size_t per_thread = ctx->latency_mode ? 1 : 4;
     size_t need = (work_items + RED_THREADS * per_thread - 1) / (RED_THREADS * per_thread);
