@@ -162,3 +162,20 @@ def test_pow_reference_solve_verify_case(ctx, oracle):
             assert nonce.value == 0  # pow.rs:34-36
         else:
             assert nonce.value == oracle.pow_solve(chw, bits)  # both return the smallest nonce under the biased threshold
+
+
+def test_host_wait_environment_is_applied_before_the_stream_and_unknown_values_are_refused():
+    """PK_HOST_WAIT = spin | block | poll makes pk_ctx_create choose the wait mode BEFORE it creates the context's stream; anything else
+    is PK_ERR_BAD_ARG, not silently 'spin' (ADVICE r05).  Fresh processes: the mode is process-wide."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\nimport torch; torch.cuda.is_available()\nimport provekit_amd\n"
+            "from provekit_amd._lib import ProveKitHipError\n"
+            "try:\n    c = provekit_amd.Context(0); c.sync(); print('CREATED')\nexcept ProveKitHipError as e:\n    print('REFUSED', e.code)\n") % root
+    for value, want in (("poll", "CREATED"), ("block", "CREATED"), ("spin", "CREATED"), ("b", "REFUSED -1"), ("sleepy", "REFUSED -1")):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PK_HOST_WAIT=value), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.strip().splitlines()[-1] == want, (value, out.stdout, out.stderr[-500:])

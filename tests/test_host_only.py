@@ -177,3 +177,39 @@ def test_derived_pow_bits_are_consistent_with_the_reference_proofs_nonces():
     assert ours > loglik([16.0] * 7) and ours > loglik([10.0] * 7) and loglik([0.0] * 7) == -math.inf
     dev = [math.log2(n + 1) - d for d, n in zip(bits, nonces)]
     assert -1.6 < sum(dev) / len(dev) < -0.1, dev
+
+
+def test_scheme_arena_bytes_is_the_sum_of_a_proofs_buffers():
+    """pk_scheme_arena_bytes (host only): what pk_scheme_create will allocate for a prover of a given shape -- ~20.6 x 32 B x 2^m at
+    rate 1/2, fold 16, batch 2; bench.py sizes its prover counts from it.  Monotone in every argument, refuses nonsense."""
+    import ctypes as C
+
+    from provekit_amd._lib import lib
+    from provekit_amd.scheme import WhirConfig, _cfg_struct, arena_bytes
+
+    sizes = {m: arena_bytes(m, m - 1, (1 << (m - 1)) - 5, WhirConfig.derive(m)) for m in (13, 17, 21, 23, 25)}
+    for m, b in sizes.items():
+        assert 19.0 < (b - (64 << 20)) / (32.0 * (1 << m)) < 22.0, (m, b)  # the arena itself, without the 64 MiB constant
+    assert sizes[21] < 1.6e9 and 22e9 < sizes[25] < 24e9
+    assert arena_bytes(21, 20, 1 << 20, WhirConfig.derive(21)) > arena_bytes(21, 20, 1 << 19, WhirConfig.derive(21))
+    n = C.c_size_t()
+    cw = _cfg_struct(WhirConfig.derive(21))
+    assert lib.pk_scheme_arena_bytes(21, 22, 1 << 20, C.byref(cw), C.byref(n)) == -1  # m_0 > m
+    assert lib.pk_scheme_arena_bytes(21, 20, 1 << 20, None, C.byref(n)) == -1
+    assert lib.pk_scheme_arena_bytes(21, 20, 1 << 20, C.byref(cw), None) == -1
+
+
+def test_test_hooks_are_an_entry_point_not_the_environment():
+    """the GPU suite's hooks (a gated kernel's spin bound, a stalled host, the RCCL branch for a repeated device) are set through
+    pk_selftest_set_hook; the library reads no test switch from the environment"""
+    import os
+
+    from provekit_amd._lib import lib
+
+    assert lib.pk_selftest_set_hook(0, 0) == 0 and lib.pk_selftest_set_hook(2, 0) == 0
+    assert lib.pk_selftest_set_hook(3, 1) == -1 and lib.pk_selftest_set_hook(-1, 1) == -1 and lib.pk_selftest_set_hook(0, -5) == -1
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "provekit_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".hpp")):
+            txt = open(os.path.join(csrc, f)).read()
+            assert "PK_TEST_" not in txt and "PK_RCCL_SAME_DEVICE" not in txt, f
