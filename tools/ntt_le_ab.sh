@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of the register NTT's elements per lane (PK_NTT_LE = 3: eight, two waves per SIMD; 2: four, four waves per SIMD), same binary,
-# alternating, same box.  One JSON line per run.
+# alternating, same box.  One JSON line per run.  HISTORICAL: the switch existed only in the intermediate build of round 6 that produced
+# profiles/r06_ntt_le_ab.jsonl (commit 32f6759's parent state); the tree keeps four per lane only, so today both arms run the same kernel.
 Q='--no-cpu-baseline --no-commit-probe --size-classes= --no-h2d-probe --no-latency-pass'
 for i in $(seq 1 ${ROUNDS:-2}); do for LE in ${LES:-3 2}; do
   export PK_NTT_LE=$LE

@@ -1,5 +1,7 @@
 #!/bin/bash
-# A/B: the blinding commitment + external rows on a side stream in PLAIN mode too (PK_BLINDING_OVERLAP=1) against the default (latency mode only)
+# A/B: the blinding commitment + external rows on a side stream in PLAIN mode too (PK_BLINDING_OVERLAP=1) against the default (latency mode only).
+# HISTORICAL: the switch was a one-line development patch of prover.hip (overlap_blinding) that produced profiles/r06_side_stream_plain_mode_ab.jsonl
+# and was not kept (the library reads no such variable).
 Q='--no-cpu-baseline --no-commit-probe --size-classes= --no-h2d-probe'
 for i in $(seq 1 ${ROUNDS:-3}); do for ov in 0 1; do
   if [ $ov = 1 ]; then export PK_BLINDING_OVERLAP=1; else unset PK_BLINDING_OVERLAP; fi
