@@ -13,7 +13,7 @@ using namespace pk;
 #define PK_MAX_DEVICES 64
 static std::atomic<int> g_poll_wait[PK_MAX_DEVICES];
 static std::atomic<long> g_test_hooks[pk::PK_HOOK_COUNT];
-// the runtime wait flag this library last set on a device: -1 (below: stored as 0 - 1 via init) = never touched (HIP's hipDeviceScheduleAuto)
+// the runtime wait mode this library last set on a device (PK_WAIT_SPIN / PK_WAIT_BLOCK); -1 = never touched: HIP's hipDeviceScheduleAuto
 static std::atomic<int> g_runtime_wait[PK_MAX_DEVICES];
 static const bool g_runtime_wait_init = [] {
     for (auto& w : g_runtime_wait) w.store(-1, std::memory_order_relaxed);
