@@ -123,9 +123,10 @@ int pk_ctx_set_hash_version(pk_ctx *ctx, int version);
  * transport's callback returned non-zero, or another rank of the set failed (the communicator is then unusable).
  * A rank whose sharded call fails before it reaches a collective aborts its communicator so that its peers do not wait for it
  * for ever.  In-process group: the waiting ranks wake at once with PK_ERR_RCCL.  RCCL: ncclCommAbort is local -- the failing rank
- * tears down its OWN communicator, nothing reaches its peers; every wait on a stream that carries a collective therefore has a
- * deadline (environment PK_COMM_TIMEOUT_S, default 120 s; ncclCommGetAsyncError is polled meanwhile): a rank whose collective does
- * not complete aborts its own communicator too and returns PK_ERR_RCCL.  Host transport: the peers are the caller's to time out.
+ * tears down its OWN communicator, nothing reaches its peers; every collective therefore has a deadline (environment
+ * PK_COMM_TIMEOUT_S, default 120 s, measured on an event recorded right behind the collective -- work queued after it does not count;
+ * ncclCommGetAsyncError is polled meanwhile): the first wait that finds its collective overdue aborts this rank's own communicator
+ * too (which ends its stuck kernel) and returns PK_ERR_RCCL.  Host transport: the peers are the caller's to time out.
  * After any of these: pk_comm_destroy on every rank and join again.  (A refusal every rank makes identically before the call has
  * enqueued a collective -- PK_ERR_BAD_ARG, PK_ERR_UNSATISFIED, PK_ERR_IO_PATTERN -- leaves an RCCL communicator usable.) */
 #define PK_MAX_RANKS 16

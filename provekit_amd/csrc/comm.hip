@@ -197,7 +197,8 @@ struct pk_comm {
     size_t stage_bytes = 0;
     bool failed = false;  // sticky, like LocalGroup::aborted
     unsigned long long issued = 0;  // collectives enqueued so far (any transport)
-    bool pending = false;  // RCCL: a collective was enqueued on the stream and no completed wait has been seen since (comm_wait)
+    bool pending = false;  // RCCL: a collective was enqueued on the stream and has not been seen complete yet (comm_wait)
+    hipEvent_t done = nullptr;  // RCCL: recorded on the stream right behind the latest collective: the deadline is the collective's, not the stream's
     bool holds_token = false;  // LOCAL turnstile: between comm_turn_begin and comm_turn_end
 };
 
@@ -209,6 +210,13 @@ static void rccl_abort_own(pk_comm* c) {
         if (rccl()->CommAbort) (void)rccl()->CommAbort(c->nccl);  // frees the communicator
         c->nccl = nullptr;  // (without ncclCommAbort the handle is leaked on purpose: destroying it could hang)
     }
+}
+// an event on the stream right behind the collective just enqueued: comm_wait's deadline watches THIS, so that hours of honest work
+// queued behind a collective are never mistaken for a collective that hangs
+static int rccl_mark(pk_ctx* ctx, pk_comm* c) {
+    if (!c->done) PK_HIP(ctx, hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+    PK_HIP(ctx, hipEventRecord(c->done, ctx->stream));
+    return PK_OK;
 }
 
 namespace pk {
@@ -232,7 +240,7 @@ int comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes)
             rccl_abort_own(c);  // the ranks are out of step from here on: no later collective may be attempted on this communicator
             return rccl_fail(ctx, "ncclAllGather", r);
         }
-        return PK_OK;
+        return rccl_mark(ctx, c);
     }
     if (c->kind == PK_COMM_HOST) {
         if (c->failed) return set_err(ctx, PK_ERR_RCCL, "the host transport failed earlier; the communicator is unusable");
@@ -293,8 +301,8 @@ int comm_all_gather(pk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes)
 //   LOCAL  the group's sticky flag wakes them at once with PK_ERR_RCCL.
 //   RCCL   nothing reaches the peers: ncclCommAbort is LOCAL -- it tears down THIS rank's communicator (and kills its own pending
 //          collective kernel); the peers' collective kernels keep waiting on xGMI for a rank that will not come.  They are rescued by
-//          their own deadline: every wait on a stream that carries a collective (comm_wait below) polls the stream and
-//          ncclCommGetAsyncError, and after PK_COMM_TIMEOUT_S seconds (default 120) aborts ITS OWN communicator -- which ends its
+//          their own deadline: every wait behind a collective (comm_wait below) polls an event recorded right after that collective
+//          and ncclCommGetAsyncError, and after PK_COMM_TIMEOUT_S seconds (default 120) aborts ITS OWN communicator -- which ends its
 //          stuck kernel -- and returns PK_ERR_RCCL.  The communicator is unusable afterwards on every rank (pk_comm_destroy + a fresh
 //          pk_comm_init_rank to continue).
 //   HOST   this rank fails fast, its peers are the caller's transport's to time out.
@@ -340,22 +348,29 @@ hipError_t comm_wait(pk_ctx* ctx) {
     pk_comm* c = ctx->comm;
     struct timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (unsigned polls = 0;; polls++) {
-        const hipError_t e = hipStreamQuery(ctx->stream);
-        if (e != hipErrorNotReady) {
-            if (e == hipSuccess) c->pending = false;
-            return e;
+    double waited = 0.0;
+    for (unsigned polls = 1; c->pending; polls++) {
+        const hipError_t e = c->done ? hipEventQuery(c->done) : hipStreamQuery(ctx->stream);
+        if (e == hipSuccess) {
+            c->pending = false;  // the collective itself is through; whatever is queued behind it is ordinary work
+            break;
         }
-        if (polls < 64) continue;  // a collective over xGMI completes within microseconds when every rank is there
-        struct timespec ts = {0, polls < 1024 ? 20000 : 200000};
-        (void)nanosleep(&ts, nullptr);
-        if ((polls & 63) != 0) continue;
+        if (e != hipErrorNotReady) return e;
+        // a healthy collective is over within a millisecond: the first 5 ms are a plain spin (a sharded proof waits ~65 times and
+        // must not pay a timer for each); after that nothing is urgent any more -- sleep between polls
+        if (waited >= 5e-3) {
+            struct timespec ts = {0, 200000};
+            (void)nanosleep(&ts, nullptr);
+        } else if ((polls & 255) != 0) {
+            continue;
+        }
+        struct timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        waited = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        if (waited < 5e-3) continue;
         ncclResult_t async = ncclSuccess;
         const bool broken = c->nccl && rccl()->CommGetAsyncError && rccl()->CommGetAsyncError(c->nccl, &async) == ncclSuccess && async != ncclSuccess &&
                             async != ncclInProgress;
-        struct timespec t1;
-        clock_gettime(CLOCK_MONOTONIC, &t1);
-        const double waited = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
         if (broken || waited > comm_timeout_s()) {
             rccl_abort_own(c);
             (void)hipStreamSynchronize(ctx->stream);  // the aborted kernel exits; drain what was queued behind it
@@ -365,6 +380,7 @@ hipError_t comm_wait(pk_ctx* ctx) {
             return hipErrorUnknown;
         }
     }
+    return wait_stream(ctx->device, ctx->stream);
 }
 
 int comm_all_reduce_sum_u64(pk_ctx* ctx, uint64_t* d_buf, size_t count) {
@@ -380,7 +396,7 @@ int comm_all_reduce_sum_u64(pk_ctx* ctx, uint64_t* d_buf, size_t count) {
             rccl_abort_own(c);
             return rccl_fail(ctx, "ncclAllReduce", r);
         }
-        return PK_OK;
+        return rccl_mark(ctx, c);
     }
     const size_t need = (size_t)c->world * count * 8;
     if (c->tmp_bytes < need) {
@@ -444,6 +460,7 @@ void comm_release(pk_ctx* ctx) {
         }
         if (last) delete g;
     }
+    if (c->done) (void)hipEventDestroy(c->done);
     if (c->d_tmp) (void)hipFree(c->d_tmp);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     delete c;

@@ -50,7 +50,7 @@ int wait_ctx_rc(pk_ctx* ctx) {
     const bool collective = comm_collective_pending(ctx);
     const hipError_t e = wait_ctx(ctx);
     if (e == hipSuccess) return PK_OK;
-    if (collective && !comm_collective_pending(ctx)) return PK_ERR_RCCL;  // comm_wait gave up on the collective and said why
+    if (collective && ctx->err_code == PK_ERR_RCCL && e == hipErrorUnknown) return PK_ERR_RCCL;  // comm_wait gave up on the collective and said why
     return set_err(ctx, e == hipErrorOutOfMemory ? PK_ERR_OOM : PK_ERR_HIP, "waiting for the stream failed: %s", hipGetErrorString(e));
 }
 }  // namespace pk

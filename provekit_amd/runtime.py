@@ -126,10 +126,13 @@ class Context:
         except Exception:
             pass
 
+    def last_error(self) -> str:
+        msg = lib.pk_last_error(self.handle)
+        return msg.decode() if msg else ""
+
     def _check(self, rc: int):
         if rc != 0:
-            msg = lib.pk_last_error(self.handle)
-            raise ProveKitHipError(rc, msg.decode() if msg else "")
+            raise ProveKitHipError(rc, self.last_error())
 
     # -- memory ------------------------------------------------------------
     def alloc(self, nbytes: int) -> DeviceBuffer:

@@ -6,6 +6,7 @@ import ctypes as C
 import json
 import os
 import sys
+import time
 import threading
 
 import numpy as np
@@ -187,6 +188,29 @@ def main():
     assert res[0][1] == -4 and res[1][1] == -4, res
     assert calls()["abort"] - before["abort"] >= 1
     for c in ctxs:
+        c.close()
+
+    # a collective that HANGS on the stream (its peer never joins -- what a dead rank looks like to the real library): the wait behind it has a
+    # deadline (PK_COMM_TIMEOUT_S, 2 s here): the rank aborts its OWN communicator, which ends its stuck kernel, and reports PK_ERR_RCCL; honest
+    # work queued behind a collective that DID complete is not mistaken for a hang
+    uid = provekit_amd.Context.comm_unique_id()
+    pair = [provekit_amd.Context(0) for _ in range(2)]
+    run_ranks(pair, lambda r, c: c.comm_init_rank(uid, 2, r))
+    c0 = pair[0]
+    x, y = c0.upload(np.arange(8, dtype=np.uint64)), c0.alloc(128)
+    stub.ncclStubHangNext(1)
+    before = calls()
+    assert lib.pk_comm_all_gather(c0.handle, x.ptr, y.ptr, 64) == 0  # enqueued: the call itself cannot know
+    t0 = time.time()
+    rc = lib.pk_ctx_sync(c0.handle)
+    waited = time.time() - t0
+    assert rc == -4 and "did not complete within" in c0.last_error(), (rc, c0.last_error())
+    assert 1.5 < waited < 30.0, waited
+    assert calls()["abort"] - before["abort"] == 1
+    assert lib.pk_comm_all_gather(c0.handle, x.ptr, y.ptr, 64) == -4  # the communicator is gone
+    assert lib.pk_ctx_sync(c0.handle) == 0  # the stream is usable: the aborted "kernel" ended
+    report["hang_deadline_s"] = round(waited, 2)
+    for c in pair:
         c.close()
     ctx.close()
     report["stub_calls"] = calls()

@@ -59,7 +59,9 @@ struct Group {
 struct Comm {
     Group* grp;
     int rank, world, device;
+    unsigned* hang_flag = nullptr;  // set while a "collective" of this communicator hangs on the stream (ncclStubHangNext)
 };
+int g_hang_next = 0;  // the next that-many collectives are enqueued as a stream wait nobody satisfies -- until the communicator is aborted
 
 std::mutex g_mu;
 std::map<unsigned long long, Group*> g_groups;  // by unique id
@@ -180,7 +182,8 @@ ncclResult_t ncclCommAbort(ncclComm_t c) {
     if (!c) return ncclInvalidArgument;
     std::lock_guard<std::mutex> lk(g_mu);
     g_calls.abort++;
-    delete as_comm(c);
+    if (as_comm(c)->hang_flag) __atomic_store_n(as_comm(c)->hang_flag, 1u, __ATOMIC_RELEASE);  // like the real call: it ends this rank's own stuck kernel
+    delete as_comm(c);  // (the flag's page is leaked: the stream may still be reading it)
     return ncclSuccess;
 }
 
@@ -190,6 +193,18 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
     if (!c || !es || (count && (!send || !recv))) return ncclInvalidArgument;
     const size_t bytes = count * es;
     Group* g = c->grp;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_hang_next > 0) {  // a collective a peer never joins, the way the real library shows it: enqueued fine, then the stream never gets past it
+            g_hang_next--;
+            if (!c->hang_flag) {
+                if (hipHostMalloc((void**)&c->hang_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return ncclUnhandledCudaError;
+                *c->hang_flag = 0;
+            }
+            if (hipStreamWaitValue32(stream, c->hang_flag, 1u, hipStreamWaitValueEq, 0xffffffffu) != hipSuccess) return ncclUnhandledCudaError;
+            return ncclSuccess;
+        }
+    }
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;  // everything that produced `send` is done
     g->send[c->rank] = send;
     g->bytes[c->rank] = bytes;
@@ -234,6 +249,12 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataT
         if (send == recv) g_calls.in_place_reduce++;
     }
     return ncclSuccess;
+}
+
+// test hook: the next n all-gathers hang on their stream (until their communicator is aborted), as a collective does whose peer never comes
+void ncclStubHangNext(int n) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_hang_next = n;
 }
 
 // test hook: what the library asked of "RCCL" so far
