@@ -69,7 +69,7 @@ int pk_device_count(int *n);
  * PK_WAIT_SPIN leaves it at that and only ends PK_WAIT_POLL, which is safe at any time.)  PK_WAIT_BLOCK: the thread sleeps until the
  * completion interrupt -- right for many provers per GPU: with 16 provers in flight spinning burns 16 cores for nothing, and on a
  * host that grants fewer (a container CPU quota) the throttling stalls every prover (measured: 24 provers under a 16-CPU quota, 186
- * proofs/s spinning, 257 blocking).  Process-wide for the device (hipSetDeviceFlags).  Choose PK_WAIT_BLOCK BEFORE
+ * proofs/s spinning, 257 blocking; docs/HISTORY_r01-r05.md 5).  Process-wide for the device (hipSetDeviceFlags).  Choose PK_WAIT_BLOCK BEFORE
  * creating contexts on the device and leave it: the runtime builds its completion signals for the mode in force, and a wait that
  * blocks on a signal made for polling never wakes (measured: switching to blocking while provers were running hung one of them in
  * its next synchronisation).  The environment variable PK_HOST_WAIT = spin | block | poll makes pk_ctx_create apply the mode before it
