@@ -1,7 +1,8 @@
 #!/bin/bash
 # A/B of NTT builds: alternating, same box; libs = tools/_ab/*.so named on the command line + the tree's build.
 # One JSON line per run: isolated rs_encode timings + digests, the bench headline (m = 21), the size classes (23, 25) and the 2^26 commit.
-LIBS="${LIBS:-tools/_ab/libprovekit_hip_r05.so provekit_amd/lib/libprovekit_hip.so}"
+# LIBS: the builds to compare, e.g. a copy of an older commit's libprovekit_hip.so under tools/ab/ (git-ignored as *.so, but it travels with gpurun) and the tree's
+LIBS="${LIBS:-provekit_amd/lib/libprovekit_hip.so}"
 Q='--no-cpu-baseline --no-commit-probe --size-classes= --no-h2d-probe --no-latency-pass'
 for i in $(seq 1 ${ROUNDS:-2}); do for L in $LIBS; do
   export PK_LIB_PATH=$PWD/$L
